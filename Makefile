@@ -1,0 +1,26 @@
+# Build recipe (no cmake needed): product library (HIP, gfx950), synthetic-frame helper (C),
+# and the CPU oracle (C++, test infrastructure).  `python -c "import __graft_entry__ as g; g.build()"` runs this.
+HIPCC      ?= /opt/rocm/bin/hipcc
+CXX        ?= g++
+CC         ?= gcc
+ARCH       ?= gfx950
+HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude -Iorb_slam_amd/csrc
+ORBX_SRCS  := $(wildcard orb_slam_amd/csrc/*.hip)
+ORBX_HDRS  := $(wildcard orb_slam_amd/csrc/*.h orb_slam_amd/csrc/*.inc include/*.h)
+
+all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
+
+orb_slam_amd/liborbx.so: $(ORBX_SRCS) $(ORBX_HDRS)
+	$(HIPCC) $(HIPFLAGS) -shared $(ORBX_SRCS) -o $@
+
+orb_slam_amd/libsynthframes.so: orb_slam_amd/csrc/synth_frames.c
+	$(CC) -O2 -fPIC -shared $< -o $@
+
+# oracle: scalar restatement, ISO float evaluation (no FMA contraction), the CPU baseline build flags of SURVEY §8d
+oracle/liborb_oracle.so: oracle/orb_oracle.cpp oracle/orb_pattern_points.inc
+	$(CXX) -O3 -march=native -ffp-contract=off -std=c++17 -fPIC -shared $< -o $@
+
+clean:
+	rm -f orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
+
+.PHONY: all clean
