@@ -1,0 +1,143 @@
+/* orbx.h — C ABI of the MI355X-native ORB front-end (liborbx.so).
+ *
+ * Drop-in boundary for ORB_SLAM's per-frame hot path.  Every entry point uses plain pointers and
+ * sizes only (no C++/torch types) so the reference's C++ classes — or any FFI — can bind it.
+ * The reference-side shim that keeps `ORB_SLAM::ORBextractor` / `ORB_SLAM::ORBmatcher` source
+ * compatible lives in orb_slam_amd/cpp/ (see INTEGRATION.md).
+ *
+ * Reference interfaces replaced (paths relative to /root/reference):
+ *   orbx_create / orbx_destroy      <- ORBextractor::ORBextractor(int,float,int,int,int)   include/ORBextractor.h:38, src/ORBextractor.cc:457-511
+ *   orbx_extract                    <- ORBextractor::operator()(InputArray,InputArray,vector<KeyPoint>&,OutputArray)
+ *                                                                                           include/ORBextractor.h:43-45, src/ORBextractor.cc:718-779
+ *   orbx_get_levels                 <- ORBextractor::GetLevels()                           include/ORBextractor.h:47-48
+ *   orbx_get_scale_factor           <- ORBextractor::GetScaleFactor()                      include/ORBextractor.h:50-51
+ *   orbx_extract_batch_device       <- the same operator(), throughput form (device-resident frames, many per call)
+ *   orbm_hamming256                 <- ORBmatcher::DescriptorDistance(const Mat&,const Mat&) include/ORBmatcher.h:44, src/ORBmatcher.cc:1794-1810
+ *   orbm_match_top2[_device|_batch_device]
+ *                                   <- the best / second-best scan shared by every ORBmatcher search
+ *                                      (src/ORBmatcher.cc:87-111, :201-222, :454-474, :629-650, ...)
+ *   orbm_count_accepted             <- accept rule `best<=TH && (float)best < mfNNratio*(float)second` (src/ORBmatcher.cc:224-226)
+ *
+ * All compute runs in hand-written HIP kernels for gfx950.  There is NO CPU fallback: every
+ * compute entry point returns ORBX_ERR_DEVICE when no usable GPU / kernel image is present.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes */
+#define ORBX_OK             0
+#define ORBX_EMPTY          1   /* empty image: nothing done, outputs untouched (reference src/ORBextractor.cc:721-722) */
+#define ORBX_ERR_ARG       -1
+#define ORBX_ERR_DEVICE    -2   /* no GPU, HIP error, or kernel image missing */
+#define ORBX_ERR_CAPACITY  -3   /* caller buffer or internal list too small */
+#define ORBX_ERR_GEOMETRY  -4   /* image/grid geometry the reference itself cannot process (cv::Exception / div-by-zero there) */
+
+/* ORBextractor::{HARRIS_SCORE, FAST_SCORE} (include/ORBextractor.h:36) */
+#define ORBX_HARRIS_SCORE 0
+#define ORBX_FAST_SCORE   1
+
+/* GaussianBlur column rounding: what an x86-64 OpenCV 2.4 does (SSE2 column filter:
+ * ties-to-even for x < (w & ~3), half-up for the scalar tail) or half-up everywhere (non-SIMD build) */
+#define ORBX_BLUR_X86_SSE2 0
+#define ORBX_BLUR_HALF_UP  1
+
+/* identical to OpenCV 2.4's cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id */
+typedef struct orbx_keypoint {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} orbx_keypoint;
+
+typedef struct orbx_params {
+    /* the five reference constructor arguments, same meaning and defaults (1000, 1.2f, 8, FAST_SCORE, 20) */
+    int32_t nfeatures;
+    float   scale_factor;
+    int32_t nlevels;
+    int32_t score_type;
+    int32_t fast_th;
+    /* device-side additions */
+    int32_t device;         /* HIP device ordinal */
+    int32_t max_batch;      /* frames processed per launch group by orbx_extract_batch_device (>=1) */
+    int32_t blur_rounding;  /* ORBX_BLUR_* */
+    int32_t reserved[8];    /* must be zero */
+} orbx_params;
+
+typedef struct orbx_extractor orbx_extractor;   /* opaque; not thread-safe (same as the reference instance) */
+
+void  orbx_default_params(orbx_params* p);
+int   orbx_create(const orbx_params* p, orbx_extractor** out);
+void  orbx_destroy(orbx_extractor* h);
+int   orbx_get_levels(const orbx_extractor* h);
+float orbx_get_scale_factor(const orbx_extractor* h);
+/* upper bound on keypoints per frame (= sum of the per-level quotas; == nfeatures for sane parameters) */
+int   orbx_max_keypoints(const orbx_extractor* h);
+const char* orbx_last_error(const orbx_extractor* h);
+
+/* One frame, host buffers (the operator() drop-in).  img: 8-bit single channel, `stride` bytes per row.
+ * kps[cap], desc[cap*32] are caller buffers, cap >= orbx_max_keypoints().  *n_out = number of features.
+ * Keypoint order, coordinates, angle, response, octave and descriptors are bit-identical to the
+ * reference algorithm (see DESIGN.md "Parity").  Synchronous. */
+int orbx_extract(orbx_extractor* h, const uint8_t* img, int w, int hgt, ptrdiff_t stride,
+                 orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* Throughput form.  d_imgs: DEVICE pointer to nframes frames, frame f at d_imgs + f*frame_stride,
+ * rows `row_stride` bytes apart.  d_kps[nframes*cap], d_desc[nframes*cap*32], d_n[nframes]: DEVICE
+ * buffers.  Work is enqueued on `stream` (a hipStream_t, may be NULL) and NOT synchronised.
+ * d_status[nframes] (optional DEVICE int32 buffer) receives ORBX_OK / ORBX_ERR_CAPACITY per frame. */
+int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int nframes, int w, int hgt,
+                              ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                              orbx_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, int cap,
+                              int32_t* d_status, void* stream);
+
+/* ---- matcher ---------------------------------------------------------------------------------- */
+/* Hamming distance of two 256-bit descriptors (pure, re-entrant, host). */
+int orbm_hamming256(const uint8_t* a, const uint8_t* b);
+
+/* For each of nq query descriptors (32 B each) scan all nt train descriptors:
+ *   best[q], second[q] = the two smallest distances WITH multiplicity; best_idx[q] = FIRST index
+ *   attaining best (strict '<' update order of the reference loops); nt==0 -> -1, INT_MAX, INT_MAX.
+ * Host-pointer form (copies in/out, synchronous) and device-pointer form (async on `stream`). */
+int orbm_match_top2(const uint8_t* Q, int nq, const uint8_t* T, int nt,
+                    int32_t* best_idx, int32_t* best, int32_t* second, int device);
+int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
+                           int32_t* d_best_idx, int32_t* d_best, int32_t* d_second, void* stream);
+/* nbatch independent problems with per-problem sizes read on the device:
+ * problem i: queries dQ + i*cap*32 (d_nq[i] of them), train dT + i*cap*32 (d_nt[i]); outputs at i*cap. */
+int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const uint8_t* dT, const int32_t* d_nt,
+                                 int nbatch, int cap, int32_t* d_best_idx, int32_t* d_best, int32_t* d_second,
+                                 void* stream);
+/* number of queries passing  best <= th && (float)best < ratio*(float)second  (host arrays) */
+int orbm_count_accepted(const int32_t* best, const int32_t* second, int nq, int th, float ratio);
+
+/* ---- diagnostics (stage dumps for the parity tests; not part of the drop-in surface) ------------ */
+#define ORBX_DBG_PLANE      0   /* unblurred level plane, tight w*h bytes */
+#define ORBX_DBG_BLUR       1   /* blurred level plane, tight w*h bytes */
+#define ORBX_DBG_NMS        2   /* per-pixel FAST score of NMS survivors (0 elsewhere), tight w*h bytes */
+#define ORBX_DBG_LEVEL_KPS  3   /* selected keypoints of a level before orientation: int32 triples (x,y,response bits) */
+/* run the kernel sequence only up to `stage` (0 pyramid, 1 FAST+NMS, 2 cell lists, 3 quotas, 4 per-cell
+ * retainBest, 5 per-level cap, 6 blur, 7 describe); <0 = everything (default) */
+int orbx_debug_set_stop_after(orbx_extractor* h, int stage);
+/* per-stage GPU time from HIP events recorded on the launch stream: enable = 0 off, 1 on, 2 on + reset totals.
+ * orbx_debug_stage_time synchronises the device and returns the accumulated ms / launch-group count of a stage. */
+int orbx_debug_stage_timing(orbx_extractor* h, int enable);
+int orbx_debug_stage_time(orbx_extractor* h, int stage, double* total_ms, long* launches);
+int orbx_debug_level_size(const orbx_extractor* h, int level, int* w, int* hgt);
+/* copies stage data of `frame` (index inside the last batch) / `level` into host memory; returns bytes or <0 */
+long orbx_debug_fetch(orbx_extractor* h, int what, int frame, int level, void* host_out, long cap_bytes);
+/* evaluate the device arithmetic on arrays (kind 0: fast_atan2(in0,in1)->out0; kind 1: sincos(in0)->out0,out1) */
+int orbx_debug_eval_math(int kind, const float* in0, const float* in1, float* out0, float* out1, int n, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

@@ -426,7 +426,7 @@ void gaussian_blur7_inplace(Level& L, int blur_mode) {
 
 // ---------------------------------------------------------------------------- ORBextractor
 struct CellDump {           // stage dump: what cv::FAST returned for one grid cell (cell-local coords)
-    int level, row, col, iniX, iniY, used_fallback;
+    int level, row, col, iniX, iniY, used_fallback, cw, ch;
     std::vector<KeyPoint> kps;
 };
 
@@ -562,7 +562,7 @@ struct Extractor {
                     }
                     if (scoreType == 0 /*HARRIS_SCORE*/) HarrisResponses(cellImage, pyr[level].stride, ck, 7, HARRIS_K);
                     if (keep_dumps) {
-                        CellDump cd = {level, i, j, (int)iniX, (int)iniY, fb, ck};
+                        CellDump cd = {level, i, j, (int)iniX, (int)iniY, fb, cw, ch, ck};
                         cells.push_back(cd);
                     }
                     const int nKeys = ck.size();
@@ -717,11 +717,11 @@ int orc_level_keypoints(void* h, int level, orc_keypoint* out, int cap) {
     return n;
 }
 int orc_num_cells(void* h) { return (int)((Extractor*)h)->cells.size(); }
-// info[6] = {level,row,col,iniX,iniY,used_fallback}; returns count (cell-local coords, raster order)
+// info[8] = {level,row,col,iniX,iniY,used_fallback,view_w,view_h}; returns count (cell-local coords, raster order)
 int orc_cell(void* h, int idx, int* info, orc_keypoint* out, int cap) {
     Extractor* e = (Extractor*)h;
     const CellDump& c = e->cells[idx];
-    info[0] = c.level; info[1] = c.row; info[2] = c.col; info[3] = c.iniX; info[4] = c.iniY; info[5] = c.used_fallback;
+    info[0] = c.level; info[1] = c.row; info[2] = c.col; info[3] = c.iniX; info[4] = c.iniY; info[5] = c.used_fallback; info[6] = c.cw; info[7] = c.ch;
     int n = (int)c.kps.size();
     if (out) { if (n > cap) return -2; memcpy(out, c.kps.data(), sizeof(KeyPoint) * n); }
     return n;

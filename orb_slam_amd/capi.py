@@ -1,0 +1,246 @@
+"""ctypes binding of the C ABI in include/orbx.h (liborbx.so).  Plumbing only: tests and bench.py
+drive the library through this module; the drop-in for ORB_SLAM itself is the C++ shim in
+orb_slam_amd/cpp/ (ORBextractor.h / ORBmatcher.h) which calls the same C ABI.
+
+There is no CPU fallback anywhere in this module: if liborbx.so is missing or no GPU is usable,
+calls raise OrbxError."""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbx.so")
+
+ORBX_OK, ORBX_EMPTY = 0, 1
+ORBX_ERR_ARG, ORBX_ERR_DEVICE, ORBX_ERR_CAPACITY, ORBX_ERR_GEOMETRY = -1, -2, -3, -4
+HARRIS_SCORE, FAST_SCORE = 0, 1
+BLUR_X86_SSE2, BLUR_HALF_UP = 0, 1
+DBG_PLANE, DBG_BLUR, DBG_NMS, DBG_LEVEL_KPS = 0, 1, 2, 3
+(ST_PYRAMID, ST_FAST_NMS, ST_COMPACT, ST_QUOTA, ST_CELL_SELECT, ST_LEVEL_SELECT, ST_BLUR, ST_DESCRIBE) = range(8)
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+# every symbol include/orbx.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "orbx_default_params", "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_scale_factor",
+    "orbx_max_keypoints", "orbx_last_error", "orbx_extract", "orbx_extract_batch_device",
+    "orbm_hamming256", "orbm_match_top2", "orbm_match_top2_device", "orbm_match_top2_batch_device",
+    "orbm_count_accepted", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
+    "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time",
+]
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("orbx error %d %s" % (code, msg))
+        self.code = code
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("nfeatures", ctypes.c_int32), ("scale_factor", ctypes.c_float), ("nlevels", ctypes.c_int32),
+                ("score_type", ctypes.c_int32), ("fast_th", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("max_batch", ctypes.c_int32), ("blur_rounding", ctypes.c_int32), ("reserved", ctypes.c_int32 * 8)]
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise OrbxError(ORBX_ERR_DEVICE, "liborbx.so not built: run `make` / __graft_entry__.build()")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  If torch
+        # is imported first, liborbx binds to that copy and torch streams / device pointers are directly usable;
+        # the other order loads a second runtime next to torch's and torch then sees no GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = ctypes.CDLL(LIB_PATH)
+        vp, ci, cl, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+        pd = ctypes.c_ssize_t
+        L.orbx_default_params.argtypes = [ctypes.POINTER(Params)]
+        L.orbx_default_params.restype = None
+        L.orbx_create.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(vp)]
+        L.orbx_destroy.argtypes = [vp]
+        L.orbx_destroy.restype = None
+        L.orbx_get_levels.argtypes = [vp]
+        L.orbx_get_scale_factor.argtypes = [vp]
+        L.orbx_get_scale_factor.restype = cf
+        L.orbx_max_keypoints.argtypes = [vp]
+        L.orbx_last_error.argtypes = [vp]
+        L.orbx_last_error.restype = ctypes.c_char_p
+        L.orbx_extract.argtypes = [vp, vp, ci, ci, pd, vp, vp, ci, ctypes.POINTER(ci)]
+        L.orbx_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, pd, pd, vp, vp, vp, ci, vp, vp]
+        L.orbm_hamming256.argtypes = [vp, vp]
+        L.orbm_match_top2.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci]
+        L.orbm_match_top2_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp]
+        L.orbm_match_top2_batch_device.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, vp]
+        L.orbm_count_accepted.argtypes = [vp, vp, ci, ci, cf]
+        L.orbx_debug_set_stop_after.argtypes = [vp, ci]
+        L.orbx_debug_level_size.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.orbx_debug_fetch.argtypes = [vp, ci, ci, ci, vp, cl]
+        L.orbx_debug_fetch.restype = cl
+        L.orbx_debug_eval_math.argtypes = [ci, vp, vp, vp, vp, ci, ci]
+        L.orbx_debug_stage_timing.argtypes = [vp, ci]
+        L.orbx_debug_stage_time.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(cl)]
+        _LIB = L
+    return _LIB
+
+
+class ORBextractor:
+    """Same constructor arguments as the reference ORBextractor(nfeatures, scaleFactor, nlevels, scoreType, fastTh)
+    (include/ORBextractor.h:38) plus device placement; __call__(image) is operator()."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, scoreType=FAST_SCORE, fastTh=20,
+                 device=0, max_batch=1, blur_rounding=BLUR_X86_SSE2):
+        L = lib()
+        p = Params()
+        L.orbx_default_params(ctypes.byref(p))
+        p.nfeatures, p.scale_factor, p.nlevels, p.score_type, p.fast_th = nfeatures, scaleFactor, nlevels, scoreType, fastTh
+        p.device, p.max_batch, p.blur_rounding = device, max_batch, blur_rounding
+        h = ctypes.c_void_p()
+        rc = L.orbx_create(ctypes.byref(p), ctypes.byref(h))
+        if rc != ORBX_OK:
+            raise OrbxError(rc, "orbx_create (is a gfx950 GPU visible?)")
+        self.h = h
+        self.L = L
+        self.max_keypoints = L.orbx_max_keypoints(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def GetLevels(self):
+        return self.L.orbx_get_levels(self.h)
+
+    def GetScaleFactor(self):
+        return self.L.orbx_get_scale_factor(self.h)
+
+    def _err(self, rc):
+        return OrbxError(rc, self.L.orbx_last_error(self.h).decode())
+
+    def __call__(self, image):
+        """image: 2-D uint8 array.  Returns (keypoints[N] (KP_DTYPE), descriptors[N,32] uint8)."""
+        img = np.asarray(image)
+        if img.size == 0:
+            return None   # reference: silent return, outputs untouched
+        assert img.dtype == np.uint8 and img.ndim == 2
+        if img.strides[1] != 1:
+            img = np.ascontiguousarray(img)
+        hh, w = img.shape
+        cap = self.max_keypoints
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = ctypes.c_int(0)
+        rc = self.L.orbx_extract(self.h, img.ctypes.data, w, hh, img.strides[0], kps.ctypes.data, desc.ctypes.data, cap, ctypes.byref(n))
+        if rc != ORBX_OK:
+            raise self._err(rc)
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch_device(self, d_imgs, nframes, w, h, row_stride, frame_stride, d_kps, d_desc, d_n, cap, d_status=0, stream=0):
+        """All pointer arguments are integer device addresses (e.g. torch tensor.data_ptr()).  Asynchronous."""
+        rc = self.L.orbx_extract_batch_device(self.h, d_imgs, nframes, w, h, row_stride, frame_stride, d_kps, d_desc, d_n, cap,
+                                              d_status or None, stream or None)
+        if rc != ORBX_OK:
+            raise self._err(rc)
+
+    # diagnostics
+    def set_stop_after(self, stage):
+        self.L.orbx_debug_set_stop_after(self.h, stage)
+
+    STAGE_NAMES = ["pyramid", "fast_nms", "compact", "quota", "cell_select", "level_select", "blur", "describe"]
+
+    def stage_timing(self, enable):
+        """0 off, 1 on, 2 on + reset"""
+        self.L.orbx_debug_stage_timing(self.h, enable)
+
+    def stage_times(self):
+        """-> {stage: (total_ms, launch_groups)} measured with HIP events on the launch stream"""
+        res = {}
+        for i, name in enumerate(self.STAGE_NAMES):
+            ms, n = ctypes.c_double(), ctypes.c_long()
+            self.L.orbx_debug_stage_time(self.h, i, ctypes.byref(ms), ctypes.byref(n))
+            res[name] = (ms.value, n.value)
+        return res
+
+    def level_size(self, level):
+        w, hh = ctypes.c_int(), ctypes.c_int()
+        rc = self.L.orbx_debug_level_size(self.h, level, ctypes.byref(w), ctypes.byref(hh))
+        if rc != ORBX_OK:
+            raise self._err(rc)
+        return w.value, hh.value
+
+    def fetch_plane(self, what, level, frame=0):
+        w, hh = self.level_size(level)
+        out = np.empty((hh, w), dtype=np.uint8)
+        rc = self.L.orbx_debug_fetch(self.h, what, frame, level, out.ctypes.data, out.nbytes)
+        if rc < 0:
+            raise self._err(rc)
+        return out
+
+    def fetch_level_keypoints(self, level, frame=0):
+        out = np.zeros((4 * self.max_keypoints + 64, 3), dtype=np.int32)
+        rc = self.L.orbx_debug_fetch(self.h, DBG_LEVEL_KPS, frame, level, out.ctypes.data, out.nbytes)
+        if rc < 0:
+            raise self._err(rc)
+        n = rc // 12
+        xy = out[:n, :2].copy()
+        resp = out[:n, 2].copy().view(np.float32)
+        return xy, resp
+
+
+def hamming256(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    assert a.size == 32 and b.size == 32
+    return lib().orbm_hamming256(a.ctypes.data, b.ctypes.data)
+
+
+def match_top2(Q, T, device=0):
+    """Host arrays [nq,32], [nt,32] uint8 -> (best_idx, best, second) int32 arrays (GPU computed)."""
+    Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 32)
+    T = np.ascontiguousarray(T, dtype=np.uint8).reshape(-1, 32)
+    nq, nt = len(Q), len(T)
+    idx = np.empty(nq, np.int32)
+    best = np.empty(nq, np.int32)
+    sec = np.empty(nq, np.int32)
+    rc = lib().orbm_match_top2(Q.ctypes.data, nq, T.ctypes.data, nt, idx.ctypes.data, best.ctypes.data, sec.ctypes.data, device)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbm_match_top2")
+    return idx, best, sec
+
+
+def match_top2_device(dQ, nq, dT, nt, d_idx, d_best, d_second, stream=0):
+    rc = lib().orbm_match_top2_device(dQ, nq, dT, nt, d_idx, d_best, d_second, stream or None)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbm_match_top2_device")
+
+
+def match_top2_batch_device(dQ, d_nq, dT, d_nt, nbatch, cap, d_idx, d_best, d_second, stream=0):
+    rc = lib().orbm_match_top2_batch_device(dQ, d_nq, dT, d_nt, nbatch, cap, d_idx, d_best, d_second, stream or None)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbm_match_top2_batch_device")
+
+
+def count_accepted(best, second, th=50, ratio=0.6):
+    best = np.ascontiguousarray(best, dtype=np.int32)
+    second = np.ascontiguousarray(second, dtype=np.int32)
+    return lib().orbm_count_accepted(best.ctypes.data, second.ctypes.data, len(best), th, ratio)
+
+
+def eval_math(kind, in0, in1=None, device=0):
+    in0 = np.ascontiguousarray(in0, dtype=np.float32)
+    in1 = np.ascontiguousarray(in1 if in1 is not None else in0, dtype=np.float32)
+    out0 = np.empty_like(in0)
+    out1 = np.empty_like(in0)
+    rc = lib().orbx_debug_eval_math(kind, in0.ctypes.data, in1.ctypes.data, out0.ctypes.data, out1.ctypes.data, in0.size, device)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbx_debug_eval_math")
+    return out0, out1

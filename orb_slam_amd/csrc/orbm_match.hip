@@ -1,0 +1,231 @@
+// Brute-force 256-bit Hamming matching for gfx950: the inner loop of every ORBmatcher search
+// (reference src/ORBmatcher.cc:201-222 and siblings: DescriptorDistance + running best/second-best
+// with strict '<') lifted to a dense N x M kernel.
+//
+// Mapping (integer/bitwise work, no MFMA): a lane owns QPL query descriptors in VGPRs (8 dwords
+// each).  The train descriptor of the current step is the same for the whole wave, so it is read
+// with wave-uniform (scalar, SGPR) loads and costs no VGPRs, no LDS and no per-lane memory traffic.
+// Per pair: 8 v_xor + 8 v_bcnt_u32_b32 (accumulating popcount) + 3 ops for the top-2 update.
+//
+// Top-2 with the reference's tie rules as ONE associative reduction: key = (distance << 22) | index.
+// Keys are unique, min(key) is the smallest distance at its FIRST index, and the second-smallest
+// key carries the second-smallest distance counted with multiplicity — exactly what the
+// `if(d<best){best2=best;best=d;idx=i}else if(d<best2)best2=d` scan produces.  Because it is a
+// plain two-smallest reduction, the train set can be split across workgroups and merged in any order.
+#include <climits>
+#include <cstring>
+
+#include "orb_math.h"
+#include "orbx_internal.h"
+
+namespace orbx {
+
+constexpr int KEY_SHIFT = 22;                       // index bits; distance (<=256) sits above
+constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
+constexpr int QPL = 2;                              // queries per lane
+constexpr int MATCH_BLOCK = 256;
+constexpr int Q_PER_BLOCK = MATCH_BLOCK * QPL;
+
+__device__ __forceinline__ void top2_update(uint32_t& k1, uint32_t& k2, uint32_t key) {
+    k2 = min(k2, max(k1, key));
+    k1 = min(k1, key);
+}
+
+// Scan train descriptors [t0, t1) for the block's queries.  T must be wave-uniform readable.
+template <bool GUARD>
+__device__ __forceinline__ void scan_range(const uint32_t* __restrict__ T, int t0, int t1, const uint32_t (&q)[QPL][8],
+                                           uint32_t (&k1)[QPL], uint32_t (&k2)[QPL]) {
+#pragma unroll 4
+    for (int t = t0; t < t1; t++) {
+        const uint32_t* tp = T + (long long)t * 8;
+        uint32_t tw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) tw[i] = tp[i];   // uniform address -> s_load
+#pragma unroll
+        for (int j = 0; j < QPL; j++) {
+            uint32_t d = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) d += __popc(q[j][i] ^ tw[i]);
+            top2_update(k1[j], k2[j], (d << KEY_SHIFT) | (uint32_t)t);
+        }
+    }
+}
+
+__device__ __forceinline__ void load_queries(const uint32_t* __restrict__ Q, int nq, int qbase, uint32_t (&q)[QPL][8]) {
+#pragma unroll
+    for (int j = 0; j < QPL; j++) {
+        const int qi = qbase + j * MATCH_BLOCK;
+        if (qi < nq) {
+            const uint4* p = reinterpret_cast<const uint4*>(Q + (long long)qi * 8);
+            const uint4 a = p[0], c = p[1];
+            q[j][0] = a.x; q[j][1] = a.y; q[j][2] = a.z; q[j][3] = a.w;
+            q[j][4] = c.x; q[j][5] = c.y; q[j][6] = c.z; q[j][7] = c.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) q[j][i] = 0;
+        }
+    }
+}
+
+__device__ __forceinline__ void write_result(uint32_t k1, uint32_t k2, int32_t* idx, int32_t* best, int32_t* second) {
+    *idx = (k1 == KEY_NONE) ? -1 : (int32_t)(k1 & ((1u << KEY_SHIFT) - 1));
+    *best = (k1 == KEY_NONE) ? INT_MAX : (int32_t)(k1 >> KEY_SHIFT);
+    *second = (k2 == KEY_NONE) ? INT_MAX : (int32_t)(k2 >> KEY_SHIFT);
+}
+
+// Large single problem: grid = (query blocks, train splits); partial (k1,k2) per (split, query).
+__global__ __launch_bounds__(MATCH_BLOCK) void k_match_split(const uint32_t* __restrict__ Q, int nq, const uint32_t* __restrict__ T, int nt,
+                                                             int chunk, uint32_t* __restrict__ pk1, uint32_t* __restrict__ pk2) {
+    const int qbase = blockIdx.x * Q_PER_BLOCK + threadIdx.x;
+    const int t0 = blockIdx.y * chunk, t1 = min(nt, t0 + chunk);
+    uint32_t q[QPL][8], k1[QPL], k2[QPL];
+    load_queries(Q, nq, qbase, q);
+#pragma unroll
+    for (int j = 0; j < QPL; j++) { k1[j] = KEY_NONE; k2[j] = KEY_NONE; }
+    scan_range<false>(T, t0, t1, q, k1, k2);
+#pragma unroll
+    for (int j = 0; j < QPL; j++) {
+        const int qi = qbase + j * MATCH_BLOCK;
+        if (qi < nq) {
+            pk1[(long long)blockIdx.y * nq + qi] = k1[j];
+            pk2[(long long)blockIdx.y * nq + qi] = k2[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_match_merge(const uint32_t* __restrict__ pk1, const uint32_t* __restrict__ pk2, int nq, int nsplit,
+                                                     int32_t* __restrict__ idx, int32_t* __restrict__ best, int32_t* __restrict__ second) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+    for (int s = 0; s < nsplit; s++) {
+        top2_update(k1, k2, pk1[(long long)s * nq + qi]);
+        top2_update(k1, k2, pk2[(long long)s * nq + qi]);
+    }
+    write_result(k1, k2, idx + qi, best + qi, second + qi);
+}
+
+// Many small problems (frame-to-frame matching): blockIdx.y = problem, sizes read on the device.
+__global__ __launch_bounds__(MATCH_BLOCK) void k_match_batch(const uint32_t* __restrict__ Q, const int32_t* __restrict__ nqs,
+                                                             const uint32_t* __restrict__ T, const int32_t* __restrict__ nts, int cap,
+                                                             int32_t* __restrict__ idx, int32_t* __restrict__ best, int32_t* __restrict__ second) {
+    const int prob = blockIdx.y;
+    const int nq = min(nqs[prob], cap), nt = min(nts[prob], cap);
+    const int qbase = blockIdx.x * Q_PER_BLOCK + threadIdx.x;
+    if (blockIdx.x * Q_PER_BLOCK >= nq) return;
+    const uint32_t* Qp = Q + (long long)prob * cap * 8;
+    const uint32_t* Tp = T + (long long)prob * cap * 8;
+    uint32_t q[QPL][8], k1[QPL], k2[QPL];
+    load_queries(Qp, nq, qbase, q);
+#pragma unroll
+    for (int j = 0; j < QPL; j++) { k1[j] = KEY_NONE; k2[j] = KEY_NONE; }
+    scan_range<false>(Tp, 0, nt, q, k1, k2);
+#pragma unroll
+    for (int j = 0; j < QPL; j++) {
+        const int qi = qbase + j * MATCH_BLOCK;
+        if (qi < nq) {
+            const long long o = (long long)prob * cap + qi;
+            write_result(k1[j], k2[j], idx + o, best + o, second + o);
+        }
+    }
+}
+
+struct MatchScratch {
+    uint32_t* buf = nullptr;
+    size_t bytes = 0;
+    int device = -1;
+};
+static thread_local MatchScratch t_scratch;
+
+static int ensure_scratch(size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return ORBX_ERR_DEVICE;
+    if (t_scratch.buf && t_scratch.bytes >= bytes && t_scratch.device == dev) return ORBX_OK;
+    if (t_scratch.buf) (void)hipFree(t_scratch.buf);
+    t_scratch.buf = nullptr;
+    if (hipMalloc(&t_scratch.buf, bytes) != hipSuccess) return ORBX_ERR_DEVICE;
+    t_scratch.bytes = bytes;
+    t_scratch.device = dev;
+    return ORBX_OK;
+}
+
+}  // namespace orbx
+
+using namespace orbx;
+
+extern "C" {
+
+int orbm_hamming256(const uint8_t* a, const uint8_t* b) {
+    uint32_t wa[8], wb[8];
+    memcpy(wa, a, 32);
+    memcpy(wb, b, 32);
+    return hamming256_words(wa, wb);
+}
+
+int orbm_count_accepted(const int32_t* best, const int32_t* second, int nq, int th, float ratio) {
+    int n = 0;
+    for (int q = 0; q < nq; q++)
+        if (best[q] <= th && (float)best[q] < ratio * (float)second[q]) n++;
+    return n;
+}
+
+int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt, int32_t* d_best_idx, int32_t* d_best,
+                           int32_t* d_second, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nq < 0 || nt < 0 || nt >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
+    if (nq == 0) return ORBX_OK;
+    if (((uintptr_t)dQ & 15) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
+    const int qblocks = (nq + Q_PER_BLOCK - 1) / Q_PER_BLOCK;
+    // enough workgroups to fill 256 CUs several times over, but chunks of >= 256 train descriptors
+    int nsplit = std::max(1, std::min((nt + 255) / 256, (4096 + qblocks - 1) / qblocks));
+    const int chunk = nt > 0 ? (nt + nsplit - 1) / nsplit : 1;
+    nsplit = nt > 0 ? (nt + chunk - 1) / chunk : 1;
+    const size_t need = (size_t)2 * nsplit * nq * sizeof(uint32_t);
+    if (ensure_scratch(need) != ORBX_OK) return ORBX_ERR_DEVICE;
+    uint32_t* pk1 = t_scratch.buf;
+    uint32_t* pk2 = pk1 + (size_t)nsplit * nq;
+    hipLaunchKernelGGL(k_match_split, dim3(qblocks, nsplit), dim3(MATCH_BLOCK), 0, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt,
+                       chunk, pk1, pk2);
+    if (hipGetLastError() != hipSuccess) return ORBX_ERR_DEVICE;
+    hipLaunchKernelGGL(k_match_merge, dim3((nq + 255) / 256), dim3(256), 0, stream, pk1, pk2, nq, nsplit, d_best_idx, d_best, d_second);
+    if (hipGetLastError() != hipSuccess) return ORBX_ERR_DEVICE;
+    return ORBX_OK;
+}
+
+int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const uint8_t* dT, const int32_t* d_nt, int nbatch, int cap,
+                                 int32_t* d_best_idx, int32_t* d_best, int32_t* d_second, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nbatch < 0 || cap < 1 || cap >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
+    if (nbatch == 0) return ORBX_OK;
+    if (((uintptr_t)dQ & 15) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
+    hipLaunchKernelGGL(k_match_batch, dim3((cap + Q_PER_BLOCK - 1) / Q_PER_BLOCK, nbatch), dim3(MATCH_BLOCK), 0, stream, (const uint32_t*)dQ,
+                       d_nq, (const uint32_t*)dT, d_nt, cap, d_best_idx, d_best, d_second);
+    return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbm_match_top2(const uint8_t* Q, int nq, const uint8_t* T, int nt, int32_t* best_idx, int32_t* best, int32_t* second, int device) {
+    if (nq < 0 || nt < 0) return ORBX_ERR_ARG;
+    if (nq == 0) return ORBX_OK;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    uint8_t *dQ = nullptr, *dT = nullptr;
+    int32_t* dout = nullptr;
+    int rc = ORBX_ERR_DEVICE;
+    if (hipMalloc(&dQ, (size_t)nq * 32) == hipSuccess && hipMalloc(&dT, (size_t)std::max(nt, 1) * 32) == hipSuccess &&
+        hipMalloc(&dout, (size_t)nq * 3 * sizeof(int32_t)) == hipSuccess &&
+        hipMemcpy(dQ, Q, (size_t)nq * 32, hipMemcpyHostToDevice) == hipSuccess &&
+        (nt == 0 || hipMemcpy(dT, T, (size_t)nt * 32, hipMemcpyHostToDevice) == hipSuccess)) {
+        rc = orbm_match_top2_device(dQ, nq, dT, nt, dout, dout + nq, dout + 2 * (size_t)nq, nullptr);
+        if (rc == ORBX_OK) {
+            if (hipMemcpy(best_idx, dout, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(best, dout + nq, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(second, dout + 2 * (size_t)nq, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = ORBX_ERR_DEVICE;
+        }
+    }
+    if (dQ) (void)hipFree(dQ);
+    if (dT) (void)hipFree(dT);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,335 @@
+// C ABI of the extractor (include/orbx.h): handle, device memory, launch orchestration.
+// All pixel work happens in orbx_kernels.hip; there is no host fallback.
+#include <cstdio>
+#include <cstring>
+
+#include "orbx_internal.h"
+
+namespace orbx {
+int launch_eval_math(int kind, const float* in0, const float* in1, float* out0, float* out1, int n);
+void stage_timer_collect(StageTimer& t);
+}
+using namespace orbx;
+
+struct orbx_extractor {
+    orbx_params p;
+    std::string err;
+    // geometry for the current image size
+    int gw = 0, gh = 0;
+    HostGeom hg;
+    DevGeom* d_g = nullptr;
+    CellGeom* d_cells = nullptr;
+    ResizeX* d_tabx = nullptr;
+    ResizeY* d_taby = nullptr;
+    uint8_t *d_flagx = nullptr, *d_flagy = nullptr;
+    // per-batch working set (max_batch frames)
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_nms = nullptr;
+    Cand *d_cand = nullptr, *d_sel = nullptr;
+    CellState* d_cstate = nullptr;
+    CellSel* d_csel = nullptr;
+    int32_t *d_level_total = nullptr, *d_level_count = nullptr, *d_status = nullptr;
+    // single-frame staging for orbx_extract
+    uint8_t* d_img1 = nullptr;
+    size_t img1_bytes = 0;
+    int img1_stride = 0;
+    orbx_keypoint* d_kps1 = nullptr;
+    uint8_t* d_desc1 = nullptr;
+    int32_t* d_n1 = nullptr;   // [2]: n, status
+    int out1_cap = 0;
+    // diagnostics
+    int stop_after = -1;
+    StageTimer timer;
+    Batch last;
+    bool have_last = false;
+};
+
+#define HIPCHK(h, call)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return ORBX_ERR_DEVICE;                                                          \
+        }                                                                                    \
+    } while (0)
+
+template <typename T>
+static void dev_free(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+static void free_geometry(orbx_extractor* h) {
+    dev_free(h->d_g); dev_free(h->d_cells); dev_free(h->d_tabx); dev_free(h->d_taby);
+    dev_free(h->d_flagx); dev_free(h->d_flagy);
+    dev_free(h->d_pyr); dev_free(h->d_blur); dev_free(h->d_nms);
+    dev_free(h->d_cand); dev_free(h->d_sel); dev_free(h->d_cstate); dev_free(h->d_csel);
+    dev_free(h->d_level_total); dev_free(h->d_level_count); dev_free(h->d_status);
+    h->gw = h->gh = 0;
+    h->have_last = false;
+}
+
+template <typename T>
+static int upload(orbx_extractor* h, T*& dptr, const std::vector<T>& v) {
+    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    HIPCHK(h, hipMalloc(&dptr, bytes));
+    if (!v.empty()) HIPCHK(h, hipMemcpy(dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return ORBX_OK;
+}
+
+static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
+    if (h->gw == w && h->gh == hgt) return ORBX_OK;
+    HIPCHK(h, hipDeviceSynchronize());
+    free_geometry(h);
+    HostGeom hg;
+    int rc = build_geometry(h->p, w, hgt, hg, h->err);
+    if (rc != ORBX_OK) return rc;
+    h->hg = hg;
+    const DevGeom& g = h->hg.g;
+    const size_t B = (size_t)h->p.max_batch;
+    HIPCHK(h, hipMalloc(&h->d_g, sizeof(DevGeom)));
+    HIPCHK(h, hipMemcpy(h->d_g, &g, sizeof(DevGeom), hipMemcpyHostToDevice));
+    if ((rc = upload(h, h->d_cells, h->hg.cells)) != ORBX_OK) return rc;
+    if ((rc = upload(h, h->d_tabx, h->hg.tabx)) != ORBX_OK) return rc;
+    if ((rc = upload(h, h->d_taby, h->hg.taby)) != ORBX_OK) return rc;
+    if ((rc = upload(h, h->d_flagx, h->hg.flagx)) != ORBX_OK) return rc;
+    if ((rc = upload(h, h->d_flagy, h->hg.flagy)) != ORBX_OK) return rc;
+    HIPCHK(h, hipMalloc(&h->d_pyr, B * g.frame_plane_bytes));
+    HIPCHK(h, hipMalloc(&h->d_blur, B * g.frame_plane_bytes));
+    HIPCHK(h, hipMalloc(&h->d_nms, B * g.frame_plane_bytes));
+    HIPCHK(h, hipMemset(h->d_nms, 0, B * g.frame_plane_bytes));   // only the scan area is ever rewritten
+    HIPCHK(h, hipMalloc(&h->d_cand, B * std::max(g.frame_cands, 1) * sizeof(Cand)));
+    HIPCHK(h, hipMalloc(&h->d_sel, B * std::max(g.frame_sel, 1) * sizeof(Cand)));
+    HIPCHK(h, hipMalloc(&h->d_cstate, B * g.ncells_total * sizeof(CellState)));
+    HIPCHK(h, hipMalloc(&h->d_csel, B * g.ncells_total * sizeof(CellSel)));
+    HIPCHK(h, hipMalloc(&h->d_level_total, B * MAX_LEVELS * sizeof(int32_t)));
+    HIPCHK(h, hipMalloc(&h->d_level_count, B * MAX_LEVELS * sizeof(int32_t)));
+    HIPCHK(h, hipMemset(h->d_level_total, 0, B * MAX_LEVELS * sizeof(int32_t)));
+    HIPCHK(h, hipMemset(h->d_level_count, 0, B * MAX_LEVELS * sizeof(int32_t)));
+    HIPCHK(h, hipMalloc(&h->d_status, B * sizeof(int32_t)));
+    HIPCHK(h, hipDeviceSynchronize());
+    h->gw = w;
+    h->gh = hgt;
+    return ORBX_OK;
+}
+
+static void fill_batch(orbx_extractor* h, Batch& b) {
+    b.g = h->d_g; b.cells = h->d_cells; b.tabx = h->d_tabx; b.taby = h->d_taby;
+    b.flagx = h->d_flagx; b.flagy = h->d_flagy;
+    b.pyr = h->d_pyr; b.blur = h->d_blur; b.nms = h->d_nms;
+    b.cand = h->d_cand; b.sel = h->d_sel; b.cstate = h->d_cstate; b.csel = h->d_csel;
+    b.level_total = h->d_level_total; b.level_count = h->d_level_count; b.status = h->d_status;
+}
+
+extern "C" {
+
+void orbx_default_params(orbx_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->nfeatures = 1000;       // include/ORBextractor.h:38 defaults
+    p->scale_factor = 1.2f;
+    p->nlevels = 8;
+    p->score_type = ORBX_FAST_SCORE;
+    p->fast_th = 20;
+    p->device = 0;
+    p->max_batch = 1;
+    p->blur_rounding = ORBX_BLUR_X86_SSE2;
+}
+
+int orbx_create(const orbx_params* p, orbx_extractor** out) {
+    if (!p || !out) return ORBX_ERR_ARG;
+    *out = nullptr;
+    if (p->max_batch < 1 || p->nlevels < 1 || p->nlevels > MAX_LEVELS || p->nfeatures < 1) return ORBX_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev) return ORBX_ERR_DEVICE;
+    if (hipSetDevice(p->device) != hipSuccess) return ORBX_ERR_DEVICE;
+    orbx_extractor* h = new orbx_extractor();
+    h->p = *p;
+    *out = h;
+    return ORBX_OK;
+}
+
+void orbx_destroy(orbx_extractor* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->p.device);
+    (void)hipDeviceSynchronize();
+    free_geometry(h);
+    dev_free(h->d_img1); dev_free(h->d_kps1); dev_free(h->d_desc1); dev_free(h->d_n1);
+    delete h;
+}
+
+int orbx_get_levels(const orbx_extractor* h) { return h ? h->p.nlevels : 0; }
+float orbx_get_scale_factor(const orbx_extractor* h) { return h ? (float)(double)h->p.scale_factor : 0.f; }
+const char* orbx_last_error(const orbx_extractor* h) { return h ? h->err.c_str() : "null handle"; }
+
+int orbx_max_keypoints(const orbx_extractor* h) {
+    if (!h) return 0;
+    HostGeom tmp;
+    std::string e;
+    orbx_params p = h->p;
+    // quotas do not depend on the image size; use any valid size
+    if (build_geometry(p, 4096, 4096, tmp, e) != ORBX_OK) return std::max(p.nfeatures, 0) + p.nlevels;
+    return tmp.g.nslots;
+}
+
+int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int nframes, int w, int hgt, ptrdiff_t row_stride,
+                              ptrdiff_t frame_stride, orbx_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, int cap,
+                              int32_t* d_status, void* stream_) {
+    if (!h) return ORBX_ERR_ARG;
+    if (!d_imgs || nframes <= 0 || w <= 0 || hgt <= 0) return ORBX_EMPTY;
+    if (!d_kps || !d_desc || !d_n || cap < 1 || row_stride < w) { h->err = "bad argument"; return ORBX_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->p.device));
+    int rc = ensure_geometry(h, w, hgt);
+    if (rc != ORBX_OK) return rc;
+    if (cap < h->hg.g.nslots) { h->err = "cap < orbx_max_keypoints()"; return ORBX_ERR_CAPACITY; }
+    hipStream_t stream = (hipStream_t)stream_;
+    for (int f0 = 0; f0 < nframes; f0 += h->p.max_batch) {
+        Batch b;
+        memset(&b, 0, sizeof(b));
+        fill_batch(h, b);
+        b.nframes = std::min(h->p.max_batch, nframes - f0);
+        b.img = d_imgs + (ptrdiff_t)f0 * frame_stride;
+        b.img_row_stride = row_stride;
+        b.img_frame_stride = frame_stride;
+        b.out_kps = d_kps + (size_t)f0 * cap;
+        b.out_desc = d_desc + (size_t)f0 * cap * 32;
+        b.out_n = d_n + f0;
+        b.out_status = d_status ? d_status + f0 : nullptr;
+        b.cap = cap;
+        rc = launch_extract(b, h->hg, stream, h->stop_after, &h->timer);
+        if (rc != ORBX_OK) { h->err = "kernel launch failed (no gfx950 code object for this device?)"; return rc; }
+        h->last = b;
+        h->have_last = true;
+    }
+    return ORBX_OK;
+}
+
+int orbx_extract(orbx_extractor* h, const uint8_t* img, int w, int hgt, ptrdiff_t stride, orbx_keypoint* kps, uint8_t* desc, int cap,
+                 int* n_out) {
+    if (!h) return ORBX_ERR_ARG;
+    if (!img || w <= 0 || hgt <= 0) return ORBX_EMPTY;   // reference: silent return, outputs untouched
+    if (!kps || !desc || !n_out || stride < w) { h->err = "bad argument"; return ORBX_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->p.device));
+    int rc = ensure_geometry(h, w, hgt);
+    if (rc != ORBX_OK) return rc;
+    const int need = h->hg.g.nslots;
+    if (cap < need) { h->err = "cap < orbx_max_keypoints()"; return ORBX_ERR_CAPACITY; }
+    const int dstride = (w + 63) / 64 * 64;
+    const size_t bytes = (size_t)dstride * hgt;
+    if (h->img1_bytes < bytes) {
+        dev_free(h->d_img1);
+        HIPCHK(h, hipMalloc(&h->d_img1, bytes));
+        h->img1_bytes = bytes;
+    }
+    if (h->out1_cap < need) {
+        dev_free(h->d_kps1); dev_free(h->d_desc1); dev_free(h->d_n1);
+        HIPCHK(h, hipMalloc(&h->d_kps1, (size_t)need * sizeof(orbx_keypoint)));
+        HIPCHK(h, hipMalloc(&h->d_desc1, (size_t)need * 32));
+        HIPCHK(h, hipMalloc(&h->d_n1, 2 * sizeof(int32_t)));
+        h->out1_cap = need;
+    }
+    HIPCHK(h, hipMemcpy2D(h->d_img1, dstride, img, stride, w, hgt, hipMemcpyHostToDevice));
+    rc = orbx_extract_batch_device(h, h->d_img1, 1, w, hgt, dstride, (ptrdiff_t)bytes, h->d_kps1, h->d_desc1, h->d_n1, need, h->d_n1 + 1, nullptr);
+    if (rc != ORBX_OK) return rc;
+    int32_t res[2] = {0, 0};
+    HIPCHK(h, hipMemcpy(res, h->d_n1, sizeof(res), hipMemcpyDeviceToHost));
+    if (h->stop_after >= 0) { *n_out = 0; return ORBX_OK; }
+    if (res[1] != ORBX_OK) { h->err = "internal list capacity exceeded"; return res[1]; }
+    const int n = res[0];
+    if (n > 0) {
+        HIPCHK(h, hipMemcpy(kps, h->d_kps1, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(desc, h->d_desc1, (size_t)n * 32, hipMemcpyDeviceToHost));
+    }
+    *n_out = n;
+    return ORBX_OK;
+}
+
+// ---- diagnostics ---------------------------------------------------------------------------------
+int orbx_debug_set_stop_after(orbx_extractor* h, int stage) {
+    if (!h) return ORBX_ERR_ARG;
+    h->stop_after = stage;
+    return ORBX_OK;
+}
+
+int orbx_debug_stage_timing(orbx_extractor* h, int enable) {
+    if (!h) return ORBX_ERR_ARG;
+    if (hipSetDevice(h->p.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return ORBX_ERR_DEVICE;
+    stage_timer_collect(h->timer);
+    h->timer.enabled = enable != 0;
+    if (enable == 2) { memset(h->timer.ms, 0, sizeof(h->timer.ms)); memset(h->timer.launches, 0, sizeof(h->timer.launches)); }
+    return ORBX_OK;
+}
+
+int orbx_debug_stage_time(orbx_extractor* h, int stage, double* total_ms, long* launches) {
+    if (!h || stage < 0 || stage >= ST_COUNT) return ORBX_ERR_ARG;
+    if (hipSetDevice(h->p.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return ORBX_ERR_DEVICE;
+    stage_timer_collect(h->timer);
+    *total_ms = h->timer.ms[stage];
+    *launches = h->timer.launches[stage];
+    return ORBX_OK;
+}
+
+int orbx_debug_level_size(const orbx_extractor* h, int level, int* w, int* hgt) {
+    if (!h || h->gw == 0 || level < 0 || level >= h->hg.g.nlevels) return ORBX_ERR_ARG;
+    *w = h->hg.g.lv[level].w;
+    *hgt = h->hg.g.lv[level].h;
+    return ORBX_OK;
+}
+
+long orbx_debug_fetch(orbx_extractor* h, int what, int frame, int level, void* host_out, long cap_bytes) {
+    if (!h || !h->have_last || frame < 0 || frame >= h->last.nframes || level < 0 || level >= h->hg.g.nlevels) return ORBX_ERR_ARG;
+    if (hipSetDevice(h->p.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return ORBX_ERR_DEVICE;
+    const DevGeom& g = h->hg.g;
+    const LevelGeom& L = g.lv[level];
+    const Batch& b = h->last;
+    if (what == ORBX_DBG_PLANE || what == ORBX_DBG_BLUR || what == ORBX_DBG_NMS) {
+        const long need = (long)L.w * L.h;
+        if (cap_bytes < need) return ORBX_ERR_CAPACITY;
+        const uint8_t* src;
+        size_t spitch;
+        if (what == ORBX_DBG_PLANE && level == 0) {
+            src = b.img + (ptrdiff_t)frame * b.img_frame_stride;
+            spitch = (size_t)b.img_row_stride;
+        } else {
+            const uint8_t* base = what == ORBX_DBG_PLANE ? b.pyr : what == ORBX_DBG_BLUR ? b.blur : b.nms;
+            src = base + (size_t)frame * g.frame_plane_bytes + L.plane_off;
+            spitch = (size_t)L.stride;
+        }
+        if (hipMemcpy2D(host_out, L.w, src, spitch, L.w, L.h, hipMemcpyDeviceToHost) != hipSuccess) return ORBX_ERR_DEVICE;
+        return need;
+    }
+    if (what == ORBX_DBG_LEVEL_KPS) {
+        int32_t n = 0;
+        if (hipMemcpy(&n, b.level_count + frame * MAX_LEVELS + level, 4, hipMemcpyDeviceToHost) != hipSuccess) return ORBX_ERR_DEVICE;
+        const long need = (long)n * 12;
+        if (cap_bytes < need) return ORBX_ERR_CAPACITY;
+        std::vector<Cand> tmp(std::max(n, 1));
+        if (n > 0 && hipMemcpy(tmp.data(), b.sel + (size_t)frame * g.frame_sel + L.sel_base, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost) != hipSuccess)
+            return ORBX_ERR_DEVICE;
+        int32_t* o = (int32_t*)host_out;
+        for (int i = 0; i < n; i++) {
+            o[3 * i] = tmp[i].pos & 0xFFFF;
+            o[3 * i + 1] = tmp[i].pos >> 16;
+            memcpy(&o[3 * i + 2], &tmp[i].resp, 4);
+        }
+        return need;
+    }
+    return ORBX_ERR_ARG;
+}
+
+int orbx_debug_eval_math(int kind, const float* in0, const float* in1, float* out0, float* out1, int n, int device) {
+    if (n <= 0) return ORBX_OK;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    float* d = nullptr;
+    const size_t nb = (size_t)n * sizeof(float);
+    if (hipMalloc(&d, 4 * nb) != hipSuccess) return ORBX_ERR_DEVICE;
+    int rc = ORBX_ERR_DEVICE;
+    if (hipMemcpy(d, in0, nb, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(d + n, in1 ? in1 : in0, nb, hipMemcpyHostToDevice) == hipSuccess) {
+        rc = launch_eval_math(kind, d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, n);
+        if (rc == ORBX_OK && hipMemcpy(out0, d + 2 * (size_t)n, nb, hipMemcpyDeviceToHost) != hipSuccess) rc = ORBX_ERR_DEVICE;
+        if (rc == ORBX_OK && out1 && hipMemcpy(out1, d + 3 * (size_t)n, nb, hipMemcpyDeviceToHost) != hipSuccess) rc = ORBX_ERR_DEVICE;
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+}  // extern "C"

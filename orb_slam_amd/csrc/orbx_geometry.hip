@@ -1,0 +1,219 @@
+// Host-side geometry: everything the reference derives from (constructor args, image size) before it
+// touches a pixel, computed once per (w,h) and uploaded to the device as tables.
+//   constructor tables      reference src/ORBextractor.cc:457-511
+//   level sizes             reference src/ORBextractor.cc:783-786 (sizes from the ORIGINAL image)
+//   cell grid               reference src/ORBextractor.cc:527-596
+//   cv::resize coefficients OpenCV 2.4 imgwarp.cpp
+// The float/double mix of every expression is kept exactly as in the reference, since the integer
+// results (level sizes, quotas, grid shape) depend on it.
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+#include "orbx_internal.h"
+
+namespace orbx {
+
+static inline int round_even(double v) { return (int)std::lrint(v); }   // cvRound
+static inline int floor_int(double v) { int i = (int)v; return i - (i > v); }   // cvFloor
+static inline int ceil_int(double v) { int i = (int)v; return i + (i < v); }    // cvCeil
+static inline int16_t sat16(float v) {   // saturate_cast<short>(float)
+    int iv = round_even(v);
+    return (int16_t)(iv < SHRT_MIN ? SHRT_MIN : iv > SHRT_MAX ? SHRT_MAX : iv);
+}
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::string& err) {
+    const int nl = p.nlevels;
+    if (nl < 1 || nl > MAX_LEVELS) { err = "nlevels out of range [1,16]"; return ORBX_ERR_ARG; }
+    if (p.nfeatures < 1) { err = "nfeatures must be >= 1"; return ORBX_ERR_ARG; }
+    if (!(p.scale_factor > 1.0f)) { err = "scale_factor must be > 1"; return ORBX_ERR_ARG; }
+    if (w < 1 || h < 1 || w > 16384 || h > 16384) { err = "image size out of range"; return ORBX_ERR_ARG; }
+    if (p.score_type != ORBX_HARRIS_SCORE && p.score_type != ORBX_FAST_SCORE) { err = "score_type"; return ORBX_ERR_ARG; }
+
+    out = HostGeom();
+    DevGeom& g = out.g;
+    memset(&g, 0, sizeof(g));
+    g.nlevels = nl;
+    g.score_type = p.score_type;
+    g.fast_th = std::min(std::max(p.fast_th, 0), 255);   // cv::FAST clamps its threshold
+    g.tmin = std::min(g.fast_th, 7);                    // one score pass serves fastTh and the fallback 7
+
+    // --- constructor tables (:457-487).  scaleFactor is a double member initialised from a float.
+    const double scaleFactor = (double)p.scale_factor;
+    out.scale.assign(nl, 1.f);
+    out.inv_scale.assign(nl, 1.f);
+    for (int i = 1; i < nl; i++) out.scale[i] = (float)(out.scale[i - 1] * scaleFactor);
+    const float invScaleFactor = (float)(1.0f / scaleFactor);
+    for (int i = 1; i < nl; i++) out.inv_scale[i] = out.inv_scale[i - 1] * invScaleFactor;
+    out.features_per_level.assign(nl, 0);
+    {
+        const float factor = (float)(1.0 / scaleFactor);
+        float per_scale = p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+        int sum = 0;
+        for (int l = 0; l < nl - 1; l++) {
+            out.features_per_level[l] = round_even(per_scale);
+            sum += out.features_per_level[l];
+            per_scale *= factor;
+        }
+        out.features_per_level[nl - 1] = std::max(p.nfeatures - sum, 0);
+    }
+    // circular-patch row extents (:495-510)
+    {
+        int* umax = g.umax;
+        int v, v0;
+        const int vmax = floor_int(HALF_PATCH * std::sqrt(2.f) / 2 + 1);
+        const int vmin = ceil_int(HALF_PATCH * std::sqrt(2.f) / 2);
+        const double hp2 = HALF_PATCH * HALF_PATCH;
+        for (v = 0; v <= vmax; ++v) umax[v] = round_even(std::sqrt(hp2 - v * v));
+        for (v = HALF_PATCH, v0 = 0; v >= vmin; --v) {
+            while (umax[v0] == umax[v0 + 1]) ++v0;
+            umax[v] = v0;
+            ++v0;
+        }
+    }
+
+    // --- per-level geometry
+    const float imageRatio = (float)w / h;   // level 0 cols/rows (:526)
+    int plane_off = 0, cell_base = 0, cand_base = 0, sel_base = 0, slot_base = 0;
+    int tile_base = 0, btile_base = 0, flagx = 0, flagy = 0;
+    for (int l = 0; l < nl; l++) {
+        LevelGeom& L = g.lv[l];
+        const float s = out.inv_scale[l];
+        L.w = round_even((float)w * s);
+        L.h = round_even((float)h * s);
+        if (L.w < 2 * EDGE + 7 || L.h < 2 * EDGE + 7) {
+            // the reference would build cell views with negative extent here (cv::Exception)
+            err = "level " + std::to_string(l) + " too small for the 16-px border + FAST ring";
+            return ORBX_ERR_GEOMETRY;
+        }
+        L.stride = align_up(L.w, 64);
+        L.plane_off = plane_off;
+        plane_off += L.stride * L.h;
+        L.scale = out.scale[l];
+        L.kp_size = (float)(int)(31 * out.scale[l]);
+        L.ndesired = out.features_per_level[l];
+        L.blur_wvec = (p.blur_rounding == ORBX_BLUR_X86_SSE2) ? (L.w & ~3) : 0;
+
+        // grid (:534-547)
+        const int levelCols = (int)std::sqrt((float)L.ndesired / (5 * imageRatio));
+        const int levelRows = (int)(imageRatio * levelCols);
+        if (levelCols < 1 || levelRows < 1) {
+            err = "level " + std::to_string(l) + ": empty cell grid (the reference divides by zero here)";
+            return ORBX_ERR_GEOMETRY;
+        }
+        const int minB = EDGE, maxBX = L.w - EDGE, maxBY = L.h - EDGE;
+        const int W = maxBX - minB, H = maxBY - minB;
+        L.gcols = levelCols;
+        L.grows = levelRows;
+        L.cellW = (int)std::ceil((float)W / levelCols);
+        L.cellH = (int)std::ceil((float)H / levelRows);
+        L.ncells = levelRows * levelCols;
+        L.nfeat_cell = (int)std::ceil((float)L.ndesired / L.ncells);
+        // every cell but the last of a row/column keeps its full cellW+6 view: it must fit the level
+        if ((levelCols - 1) * L.cellW > W || (levelRows - 1) * L.cellH > H) {
+            err = "level " + std::to_string(l) + ": degenerate cell grid (cell views leave the image in the reference)";
+            return ORBX_ERR_GEOMETRY;
+        }
+        L.cell_base = cell_base;
+        L.cand_base = cand_base;
+        int cand_off = 0;
+        for (int i = 0; i < levelRows; i++)
+            for (int j = 0; j < levelCols; j++) {
+                CellGeom c;
+                c.x0 = (int16_t)(minB + j * L.cellW);
+                c.y0 = (int16_t)(minB + i * L.cellH);
+                c.x1 = (int16_t)((j == levelCols - 1) ? maxBX - 1 : c.x0 + L.cellW - 1);
+                c.y1 = (int16_t)((i == levelRows - 1) ? maxBY - 1 : c.y0 + L.cellH - 1);
+                // reference: hX = maxBorderX+3-iniX <= 0  <=>  x0 >= maxBorderX+6  (iniX = x0-3)
+                const bool skipX = (j == levelCols - 1) && (maxBX + 3 - (c.x0 - 3) <= 0);
+                const bool skipY = (i == levelRows - 1) && (maxBY + 3 - (c.y0 - 3) <= 0);
+                c.skipped = (skipX || skipY) ? 1 : 0;
+                const int cw = std::max(0, c.x1 - c.x0 + 1), ch = std::max(0, c.y1 - c.y0 + 1);
+                c.cand_off = cand_off;
+                c.cand_cap = ((cw + 1) / 2) * ((ch + 1) / 2);   // strict 3x3 maxima cannot be adjacent
+                cand_off += c.cand_cap;
+                out.cells.push_back(c);
+            }
+        cell_base += L.ncells;
+        cand_base += cand_off;
+        L.sel_base = sel_base;
+        L.sel_cap = std::min(cand_off, L.ncells * L.nfeat_cell + L.ncells * L.ncells + L.ndesired + 64);
+        sel_base += L.sel_cap;
+        L.slot_base = slot_base;
+        slot_base += L.ndesired;
+
+        // cell-boundary flags for the cell-local NMS (neighbours in another cell count as 0)
+        L.flag_off_x = flagx;
+        L.flag_off_y = flagy;
+        out.flagx.resize(flagx + L.w, 0);
+        out.flagy.resize(flagy + L.h, 0);
+        for (int x = minB; x < maxBX; x++) {
+            int j = std::min((x - minB) / L.cellW, levelCols - 1);
+            int x0 = minB + j * L.cellW, x1 = (j == levelCols - 1) ? maxBX - 1 : x0 + L.cellW - 1;
+            out.flagx[flagx + x] = (uint8_t)((x == x0 ? 1 : 0) | (x == x1 ? 2 : 0) | 4);
+        }
+        for (int y = minB; y < maxBY; y++) {
+            int i = std::min((y - minB) / L.cellH, levelRows - 1);
+            int y0 = minB + i * L.cellH, y1 = (i == levelRows - 1) ? maxBY - 1 : y0 + L.cellH - 1;
+            out.flagy[flagy + y] = (uint8_t)((y == y0 ? 1 : 0) | (y == y1 ? 2 : 0) | 4);
+        }
+        flagx += L.w;
+        flagy += L.h;
+
+        // tilings
+        L.tiles_x = (W + TILE_W - 1) / TILE_W;
+        L.tiles_y = (H + TILE_H - 1) / TILE_H;
+        L.tile_base = tile_base;
+        tile_base += L.tiles_x * L.tiles_y;
+        L.btiles_x = (L.w + TILE_W - 1) / TILE_W;
+        L.btiles_y = (L.h + TILE_H - 1) / TILE_H;
+        L.btile_base = btile_base;
+        btile_base += L.btiles_x * L.btiles_y;
+
+        // cv::resize tables level l-1 -> l
+        if (l > 0) {
+            const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h, dw = L.w, dh = L.h;
+            if (sw > 32767 || sh > 32767) { err = "image too large"; return ORBX_ERR_ARG; }
+            const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+            const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+            L.tabx_off = (int)out.tabx.size();
+            L.taby_off = (int)out.taby.size();
+            for (int dx = 0; dx < dw; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = floor_int(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+                ResizeX e;
+                e.sx = (int16_t)sx;
+                e.sx1 = (int16_t)std::min(sx + 1, sw - 1);
+                e.a0 = sat16((1.f - fx) * 2048);
+                e.a1 = sat16(fx * 2048);
+                out.tabx.push_back(e);
+            }
+            for (int dy = 0; dy < dh; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = floor_int(fy);
+                fy -= sy;
+                ResizeY e;
+                e.sy0 = (int16_t)std::min(std::max(sy, 0), sh - 1);
+                e.sy1 = (int16_t)std::min(std::max(sy + 1, 0), sh - 1);
+                e.b0 = sat16((1.f - fy) * 2048);
+                e.b1 = sat16(fy * 2048);
+                out.taby.push_back(e);
+            }
+        }
+    }
+    g.ncells_total = cell_base;
+    g.ntiles_total = tile_base;
+    g.nbtiles_total = btile_base;
+    g.nslots = slot_base;
+    g.frame_plane_bytes = align_up(plane_off, 256);
+    g.frame_cands = cand_base;
+    g.frame_sel = sel_base;
+    return ORBX_OK;
+}
+
+}  // namespace orbx

@@ -1,0 +1,130 @@
+// Internal data layout shared by the host side (geometry, launches) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "orbx.h"
+
+namespace orbx {
+
+constexpr int MAX_LEVELS = 16;
+constexpr int EDGE = 16;        // EDGE_THRESHOLD, reference src/ORBextractor.cc:77
+constexpr int HALF_PATCH = 15;  // HALF_PATCH_SIZE, :76
+constexpr int TILE_W = 64;      // FAST/NMS and blur tile (pixels)
+constexpr int TILE_H = 32;
+
+// One detected corner that survived NMS.  resp is the float response the reference sorts by
+// (FAST score, or Harris when score_type==HARRIS_SCORE).
+struct Cand {
+    uint32_t pos;   // x | y<<16, level coordinates
+    float resp;
+};
+
+// resize tables (cv::resize INTER_LINEAR 8U; host-computed with the exact float/double sequence)
+struct ResizeX { int16_t sx, sx1, a0, a1; };   // sx1 = min(sx+1, sw-1) (weight a1 is 0 when clamped)
+struct ResizeY { int16_t sy0, sy1, b0, b1; };  // rows already clamped to [0, sh-1]
+
+struct LevelGeom {
+    int w, h;              // level size
+    int stride;            // row stride (bytes) of this level in the pyramid / blur / nms blocks
+    int plane_off;         // byte offset of the level plane inside one frame's block (same for pyr, blur, nms)
+    int gcols, grows;      // cell grid (reference ComputeKeyPoints :534-535)
+    int cellW, cellH;
+    int ncells;
+    int nfeat_cell;        // nfeaturesCell (:547)
+    int ndesired;          // mnFeaturesPerLevel[level]
+    int cell_base;         // first cell index of this level in per-frame cell arrays
+    int cand_base;         // first Cand slot of this level in one frame's candidate block
+    int sel_base, sel_cap; // selected-keypoint list of this level in one frame's sel block
+    int slot_base;         // prefix of ndesired over levels (descriptor-kernel slot -> level map)
+    int tabx_off, taby_off;// offsets into the ResizeX / ResizeY tables (level >= 1)
+    int flag_off_x, flag_off_y;   // offsets into the column / row cell-boundary flag tables
+    int tile_base, tiles_x, tiles_y;   // 64x32 tiling of the scan area [16,w-17]x[16,h-17]
+    int btile_base, btiles_x, btiles_y;// 64x32 tiling of the whole plane (blur)
+    int blur_wvec;         // columns x < blur_wvec round ties-to-even (SSE2 emulation), others half-up
+    float scale;           // mvScaleFactor[level]
+    float kp_size;         // (float)(int)(PATCH_SIZE*mvScaleFactor[level])  (:675,:692)
+};
+
+struct CellGeom {
+    int16_t x0, y0, x1, y1;   // inclusive scan rectangle in level coords; empty when x1<x0 or y1<y0
+    int32_t skipped;          // reference `continue` cells (hX<=0 / hY<=0): never reach the quota else-branch
+    int32_t cand_off;         // first Cand slot relative to the level's cand_base
+    int32_t cand_cap;
+};
+
+struct CellState { int32_t n_all, n_hi, n_lo; };     // survivors total, with score>=fastTh, with score>=7
+struct CellSel { int32_t thr, nkeys, nretain, out_off; };
+
+struct DevGeom {
+    int nlevels;
+    int ncells_total;
+    int ntiles_total, nbtiles_total;
+    int nslots;              // sum of ndesired (max keypoints per frame)
+    int score_type, fast_th, tmin;
+    int frame_plane_bytes;   // bytes of one frame's pyramid block (== blur block == nms block)
+    int frame_cands;         // Cand slots per frame
+    int frame_sel;           // sel slots per frame
+    int umax[HALF_PATCH + 1];
+    LevelGeom lv[MAX_LEVELS];
+};
+
+// Pointers for one batch launch group; passed to kernels by value.
+struct Batch {
+    const DevGeom* g;
+    const CellGeom* cells;
+    const ResizeX* tabx;
+    const ResizeY* taby;
+    const uint8_t* flagx;     // per column: bit0 = first column of its cell, bit1 = last column of its cell
+    const uint8_t* flagy;
+    const uint8_t* img;       // level 0 (caller's frames)
+    long long img_row_stride, img_frame_stride;
+    uint8_t* pyr;             // [frame][frame_plane_bytes]  levels >= 1 (level-0 slot unused)
+    uint8_t* blur;            // [frame][frame_plane_bytes]
+    uint8_t* nms;             // [frame][frame_plane_bytes]
+    Cand* cand;               // [frame][frame_cands]
+    Cand* sel;                // [frame][frame_sel]
+    CellState* cstate;        // [frame][ncells_total]
+    CellSel* csel;            // [frame][ncells_total]
+    int32_t* level_total;     // [frame][MAX_LEVELS]  keypoints gathered from the cells
+    int32_t* level_count;     // [frame][MAX_LEVELS]  after the per-level cap
+    int32_t* status;          // [frame]
+    orbx_keypoint* out_kps;   // [frame][cap]
+    uint8_t* out_desc;        // [frame][cap][32]
+    int32_t* out_n;           // [frame]
+    int32_t* out_status;      // optional [frame]
+    int cap;
+    int nframes;
+};
+
+// Host-side geometry builder result.
+struct HostGeom {
+    DevGeom g;
+    std::vector<CellGeom> cells;
+    std::vector<ResizeX> tabx;
+    std::vector<ResizeY> taby;
+    std::vector<uint8_t> flagx, flagy;
+    std::vector<int> features_per_level;
+    std::vector<float> scale, inv_scale;
+};
+
+// Fills `out` for a w x h input; returns ORBX_OK / ORBX_ERR_GEOMETRY / ORBX_ERR_ARG.
+int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::string& err);
+
+enum Stage { ST_PYRAMID = 0, ST_FAST_NMS, ST_COMPACT, ST_QUOTA, ST_CELL_SELECT, ST_LEVEL_SELECT, ST_BLUR, ST_DESCRIBE, ST_COUNT };
+
+// Optional per-stage timing with HIP events recorded on the launch stream (diagnostics / bench roofline).
+struct StageTimer {
+    bool enabled = false;
+    std::vector<hipEvent_t> pool;      // events of the launch groups not yet folded into `ms`
+    std::vector<int> pool_stage;       // stage id per (start, stop) pair
+    double ms[ST_COUNT] = {0};
+    long launches[ST_COUNT] = {0};
+};
+
+// Launch the whole per-batch kernel sequence on `stream`; stop_after < 0 runs everything.
+int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int stop_after, StageTimer* timer);
+
+}  // namespace orbx

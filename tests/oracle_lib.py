@@ -111,7 +111,7 @@ class OracleExtractor:
     def cells(self):
         res = []
         for i in range(self.L.orc_num_cells(self.h)):
-            info = (c_int * 6)()
+            info = (c_int * 8)()
             n = self.L.orc_cell(self.h, i, info, None, 0)
             out = np.zeros(max(n, 1), dtype=KP_DTYPE)
             self.L.orc_cell(self.h, i, info, out.ctypes.data, max(n, 1))

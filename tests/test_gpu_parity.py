@@ -1,0 +1,165 @@
+"""GPU parity tests proper: every stage of the HIP pipeline and the end-to-end operator() against the
+CPU oracle, through the C ABI (ctypes).  Bit-exact for bytes / ints / float bit patterns."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from orb_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+FAMILIES = [synth.BLOCKS, synth.NOISE, synth.LOWTEX, synth.FLAT]
+FAMNAME = {0: "noise", 1: "blocks", 2: "flat", 3: "lowtex"}
+
+
+def _assert_kps_equal(k_gpu, k_ref):
+    assert len(k_gpu) == len(k_ref), (len(k_gpu), len(k_ref))
+    for f in capi.KP_DTYPE.names:
+        a, b = k_gpu[f], k_ref[f]
+        if a.dtype.kind == "f":
+            a, b = a.view(np.uint32), b.view(np.uint32)
+        bad = np.nonzero(a != b)[0]
+        assert bad.size == 0, "field %s differs at %d of %d entries, first idx %d: gpu=%r ref=%r" % (
+            f, bad.size, len(a), bad[0], k_gpu[bad[0]], k_ref[bad[0]])
+
+
+def test_device_math_matches_host(gpu_extractor_factory):
+    rng = np.random.default_rng(1)
+    n = 1 << 20
+    y = rng.integers(-2900000, 2900000, n).astype(np.float32)   # moment range: |m| <= 749*15*255
+    x = rng.integers(-2900000, 2900000, n).astype(np.float32)
+    y[:1000] = 0; x[500:1500] = 0
+    got, _ = capi.eval_math(0, y, x)
+    L = orc.lib()
+    ref = np.array([L.orc_fastAtan2(float(a), float(b)) for a, b in zip(y[:20000], x[:20000])], dtype=np.float32)
+    assert np.array_equal(got[:20000].view(np.uint32), ref.view(np.uint32))
+    ang = (rng.random(n) * 360.0).astype(np.float32) * np.float32(np.float32(np.pi) / np.float32(180.0))
+    s, c = capi.eval_math(1, ang)
+    import ctypes
+    rs, rc = ctypes.c_float(), ctypes.c_float()
+    for i in range(0, 20000):
+        L.orc_sincosf(float(ang[i]), ctypes.byref(rs), ctypes.byref(rc))
+        assert np.float32(rs.value).view(np.uint32) == s[i].view(np.uint32), (i, ang[i])
+        assert np.float32(rc.value).view(np.uint32) == c[i].view(np.uint32), (i, ang[i])
+
+
+@pytest.mark.parametrize("family", FAMILIES, ids=lambda f: FAMNAME[f])
+def test_stage_parity_vga(gpu_extractor_factory, family):
+    img = synth.frame(640, 480, family, 3)
+    o = orc.OracleExtractor(dumps=True)
+    ok, od = o(img)
+    ex = gpu_extractor_factory()
+    gk, gd = ex(img)
+    nl = 8
+    # pyramid bytes
+    for l in range(nl):
+        assert ex.level_size(l) == o.level_size(l)
+        np.testing.assert_array_equal(ex.fetch_plane(capi.DBG_PLANE, l), o.level_plane(l, 0), err_msg="pyramid level %d" % l)
+    # blur (oracle: blur of the unblurred plane; the pipeline blurs every level)
+    for l in range(nl):
+        np.testing.assert_array_equal(ex.fetch_plane(capi.DBG_BLUR, l), orc.gaussian_blur7(o.level_plane(l, 0)), err_msg="blur level %d" % l)
+    # FAST score + cell-local NMS map at tmin = 7
+    for l in range(nl):
+        plane = o.level_plane(l, 0)
+        ref = np.zeros_like(plane)
+        for info, _ in o.cells():
+            if info[0] != l:
+                continue
+            ix, iy, cw, ch = info[3], info[4], info[6], info[7]
+            kp = orc.fast(plane[iy:iy + ch, ix:ix + cw], 7)
+            ref[iy + kp["y"].astype(int), ix + kp["x"].astype(int)] = kp["response"].astype(np.uint8)
+        got = ex.fetch_plane(capi.DBG_NMS, l)
+        bad = np.argwhere(got != ref)
+        assert bad.size == 0, "nms level %d: %d pixels differ, first %s gpu=%d ref=%d" % (
+            l, len(bad), bad[0], got[tuple(bad[0])], ref[tuple(bad[0])])
+    # per-level selection (order matters)
+    for l in range(nl):
+        xy, resp = ex.fetch_level_keypoints(l)
+        ref = o.level_keypoints(l)
+        assert len(xy) == len(ref), "level %d count %d vs %d" % (l, len(xy), len(ref))
+        np.testing.assert_array_equal(xy[:, 0], ref["x"].astype(np.int32), err_msg="level %d x" % l)
+        np.testing.assert_array_equal(xy[:, 1], ref["y"].astype(np.int32), err_msg="level %d y" % l)
+        np.testing.assert_array_equal(resp.view(np.uint32), ref["response"].view(np.uint32), err_msg="level %d response" % l)
+    _assert_kps_equal(gk, ok)
+    np.testing.assert_array_equal(gd, od)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(w=640, h=480, nfeatures=2000),                       # the reference's init extractor (2x nFeatures)
+    dict(w=752, h=480, nfeatures=1000),                       # EuRoC-size, stride not a multiple of 64
+    dict(w=641, h=479, nfeatures=500, fastTh=12),
+    dict(w=320, h=240, nfeatures=300, nlevels=5),
+    dict(w=1920, h=1080, nfeatures=2000),
+    dict(w=640, h=480, nfeatures=1000, scoreType=capi.HARRIS_SCORE),
+    dict(w=640, h=480, nfeatures=1000, scaleFactor=1.5, nlevels=4),
+    dict(w=640, h=480, nfeatures=1000, fastTh=5),             # fastTh below the fallback threshold 7
+    dict(w=640, h=480, nfeatures=1000, blur_rounding=capi.BLUR_HALF_UP),
+], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+@pytest.mark.parametrize("family", [synth.BLOCKS, synth.NOISE, synth.LOWTEX], ids=lambda f: FAMNAME[f])
+def test_end_to_end_configs(gpu_extractor_factory, cfg, family):
+    cfg = dict(cfg)
+    w, h = cfg.pop("w"), cfg.pop("h")
+    img = synth.frame(w, h, family, 11)
+    okw = dict(cfg)
+    if "blur_rounding" in okw:
+        okw["blur_mode"] = okw.pop("blur_rounding")
+    ok, od = orc.OracleExtractor(**okw)(img)
+    gk, gd = gpu_extractor_factory(**cfg)(img)
+    _assert_kps_equal(gk, ok)
+    np.testing.assert_array_equal(gd, od)
+
+
+def test_strided_input_and_reuse(gpu_extractor_factory):
+    """non-contiguous rows (ROI of a larger buffer) and one handle reused across image sizes"""
+    big = synth.frame(800, 600, synth.BLOCKS, 5)
+    view = big[40:40 + 480, 70:70 + 640]
+    ex = gpu_extractor_factory()
+    o = orc.OracleExtractor()
+    for im in (view, synth.frame(512, 384, synth.NOISE, 2), view):
+        ok, od = o(np.ascontiguousarray(im))
+        gk, gd = ex(im)
+        _assert_kps_equal(gk, ok)
+        np.testing.assert_array_equal(gd, od)
+
+
+def test_empty_and_flat(gpu_extractor_factory):
+    ex = gpu_extractor_factory()
+    assert ex(np.zeros((0, 0), np.uint8)) is None                 # empty image: silent no-op
+    k, d = ex(synth.frame(640, 480, synth.FLAT, 0))               # zero keypoints is a normal outcome
+    assert len(k) == 0 and d.shape == (0, 32)
+
+
+def test_geometry_errors(gpu_extractor_factory):
+    ex = gpu_extractor_factory()
+    with pytest.raises(capi.OrbxError) as e:
+        ex(synth.frame(100, 80, synth.NOISE, 0))                  # level 7 would be < 33 px
+    assert e.value.code == capi.ORBX_ERR_GEOMETRY
+
+
+def test_batch_device_api(gpu_extractor_factory):
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    B, w, h = 12, 640, 480
+    frames = np.concatenate([synth.frames(w, h, synth.BLOCKS, 100, 6), synth.frames(w, h, synth.NOISE, 200, 3),
+                             synth.frames(w, h, synth.LOWTEX, 300, 2), synth.frames(w, h, synth.FLAT, 0, 1)])
+    ex = gpu_extractor_factory(max_batch=5)                       # forces 3 launch groups (5+5+2)
+    cap = ex.max_keypoints
+    d_img = torch.from_numpy(frames).cuda()
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    d_st = torch.full((B,), 99, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+                            d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    n = d_n.cpu().numpy()
+    assert (d_st.cpu().numpy() == 0).all()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+    desc = d_desc.cpu().numpy()
+    o = orc.OracleExtractor()
+    for f in range(B):
+        ok, od = o(frames[f])
+        assert n[f] == len(ok), (f, n[f], len(ok))
+        gk = kps[f, :n[f]].copy().view(capi.KP_DTYPE).reshape(-1)
+        _assert_kps_equal(gk, ok)
+        np.testing.assert_array_equal(desc[f, :n[f]], od)
