@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the ORB front-end hot path on MI355X.
+
+A step = one pass of the hot path over one batch of synthetic frames already resident in HBM:
+  extract (pyramid -> FAST/NMS -> selection -> blur -> orientation + rBRIEF) for `batch` 640x480 frames,
+  then brute-force Hamming top-2 matching of every frame's descriptors against the previous frame's.
+Workload = BASELINE.json `metric` ("frames/s ORB extract+match @640x480, 1000 kp"): configs[1] (single MI355X,
+640x480 stream, 8 levels, nFeatures 1000) plus the frame-to-frame match of the metric.
+
+  python bench.py --gpus N --steps K --warmup W
+For N>1 launch under torch.distributed.run (one rank per GPU); every rank extracts its own stream
+(weak scaling, no data-path collective), RCCL only reduces the timing / counters.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def level_sizes(w, h, nlevels=8, sf=1.2):
+    inv = [np.float32(1.0)]
+    isf = np.float32(1.0 / np.float64(np.float32(sf)))
+    for _ in range(1, nlevels):
+        inv.append(np.float32(inv[-1] * isf))
+    return [(int(np.rint(np.float32(w) * s)), int(np.rint(np.float32(h) * s))) for s in inv]
+
+
+def algorithmic_bytes(w, h, nkp, nlevels=8):
+    """per-frame algorithmic bytes of the whole extraction and of each stage."""
+    sizes = level_sizes(w, h, nlevels)
+    P = [a * b for a, b in sizes]
+    p_total, p0 = sum(P), P[0]
+    per_stage = {
+        "pyramid": sum(P[:-1]) + sum(P[1:]),          # every source level read once, every derived level written once
+        "fast_nms": p_total,                          # every pyramid pixel enters the ring test once
+        "compact": p_total,                           # survivor map walked once
+        "blur": 2 * p_total,                          # read + write of every level
+        "describe": nkp * (749 + 512 + 60),           # patch + BRIEF taps + outputs per keypoint
+    }
+    a_extract = p_total + (p_total - p0) + 60 * nkp
+    a_match = 32 * (nkp + nkp) + 12 * nkp
+    return a_extract, a_match, per_stage
+
+
+def cpu_baseline(w, h, nfeat, seconds=15.0):
+    """Oracle (scalar CPU restatement of the reference algorithm) timed on this host, 1 core, bounded sample.
+    The reference runs its extractor on the single Tracking thread (src/Tracking.cc:199-202), hence cores=1."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    from orb_slam_amd import synth
+    o = orc.OracleExtractor(nfeatures=nfeat)
+    imgs = synth.frames(w, h, synth.BLOCKS, 6000, 32)      # synthesis is outside the timed loop
+    prev = o(imgs[0])[1]                                    # warm-up frame (page faults), not timed
+    done = 0
+    t = time.perf_counter()
+    while time.perf_counter() - t < seconds:
+        _, d = o(imgs[(done + 1) % len(imgs)])
+        if len(d) and len(prev):
+            orc.match_top2(d, prev)
+        prev = d
+        done += 1
+    el = time.perf_counter() - t
+    return {"value": round(done / el, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d S-blocks %dx%d frames, oracle extract (nFeatures %d) + scalar top-2 match vs previous frame, %.1f s"
+                      % (done, w, h, nfeat, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--ring", type=int, default=1024, help="distinct frames resident per GPU (>= 1024 VGA frames exceeds the 256 MiB Infinity Cache)")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--family", type=int, default=1, help="0 noise, 1 blocks (default), 3 lowtex")
+    ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE configs[1] verbatim)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    a = ap.parse_args()
+
+    from orb_slam_amd import dist_util
+    world, rank, local_rank = dist_util.env_ranks()
+    if world == 1:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dist = dist_util.init("nccl", world, rank, local_rank)       # "nccl" is RCCL on ROCm
+    assert a.gpus == world, "--gpus %d but WORLD_SIZE %d (launch with torch.distributed.run for N>1)" % (a.gpus, world)
+    dev = torch.device("cuda", local_rank)
+
+    from orb_slam_amd import capi, synth
+    w, h, B = a.width, a.height, a.batch
+    ring = max(a.ring // B, 1) * B
+    frames = synth.frames(w, h, a.family, dist_util.stream_first_index(rank, ring), ring)          # one independent image stream per rank
+    d_img = torch.from_numpy(frames).to(dev)
+    del frames
+    ex = capi.ORBextractor(nfeatures=a.nfeatures, device=local_rank, max_batch=B)
+    cap = ex.max_keypoints
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)   # slot 0 = last frame of the previous step
+    d_n = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_match = torch.zeros((3, B, cap), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    do_match = not a.no_match
+    match_events = []
+
+    def step(i, timed):
+        f0 = (i * B) % ring
+        ex.extract_batch_device(d_img.data_ptr() + f0 * w * h, B, w, h, w, w * h, d_kps.data_ptr(),
+                                d_desc.data_ptr() + cap * 32, d_n.data_ptr() + 4, cap, d_status.data_ptr(), stream)
+        if do_match:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            capi.match_top2_batch_device(d_desc.data_ptr() + cap * 32, d_n.data_ptr() + 4, d_desc.data_ptr(), d_n.data_ptr(),
+                                         B, cap, d_match[0].data_ptr(), d_match[1].data_ptr(), d_match[2].data_ptr(), stream)
+            if timed:
+                e1.record()
+                match_events.append((e0, e1))
+            d_desc[0].copy_(d_desc[B], non_blocking=True)
+            d_n[0:1].copy_(d_n[B:B + 1], non_blocking=True)
+
+    for i in range(a.warmup):
+        step(i, False)
+    torch.cuda.synchronize(dev)
+    ex.stage_timing(2)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i, True)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+
+    stage = ex.stage_times()
+    ex.stage_timing(0)
+    match_ms = sum(e0.elapsed_time(e1) for e0, e1 in match_events) / max(len(match_events), 1)
+    kp_mean = float(d_n[1:].float().mean().item())
+    bad_status = int((d_status != 0).sum().item())
+    accepted = -1
+    if do_match:
+        best = d_match[1, B - 1, :cap].cpu().numpy()
+        sec = d_match[2, B - 1, :cap].cpu().numpy()
+        nq = int(d_n[B].item())
+        accepted = capi.count_accepted(best[:nq], sec[:nq], 50, 0.6)
+
+    # RCCL: the only collectives of the run (MAX of the timing, all-gather of the counters)
+    tmax, counters, _ = dist_util.reduce_run(dist, elapsed, [a.steps * B, kp_mean * a.steps * B, bad_status], dev)
+    total_frames = float(counters[0])
+
+    if rank == 0:
+        a_extract, a_match, per_stage = algorithmic_bytes(w, h, a.nfeatures)
+        stage_ms = {k: (ms / n if n else 0.0) for k, (ms, n) in stage.items()}
+        if do_match:
+            stage_ms["match"] = match_ms
+        dom = max(stage_ms, key=lambda k: stage_ms[k])
+        dom_bytes = (per_stage.get(dom, a_match if dom == "match" else 0)) * B
+        dom_gbs = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        kernel_ms = sum(stage_ms.values())
+        pipe_bytes = (a_extract + (a_match if do_match else 0)) * B
+        pipe_gbs = pipe_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")      # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if tj.get("workload") == "vga_640x480_nf1000" and tj.get("batch") == B:
+                    traffic = tj.get("per_launch_bytes", {}).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "frames/s ORB extract+match @640x480, 1000 kp" if do_match else "frames/s ORB extract @640x480, 1000 kp",
+            "value": round(total_frames / tmax, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(tmax / a.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "%dx%d grayscale stream, 8 levels, nFeatures %d, %s frames, extract%s" % (
+                           w, h, a.nfeatures, {0: "S-noise", 1: "S-blocks", 3: "S-lowtex"}.get(a.family, str(a.family)),
+                           " + Hamming top-2 match vs previous frame" if do_match else " only"),
+                       "frames_per_step_per_gpu": B, "resident_frames_per_gpu": ring, "parallelism": "one image stream per GPU",
+                       "mean_keypoints_per_frame": round(float(counters[1]) / total_frames, 2),
+                       "frames_with_error_status": int(counters[2]), "accepted_matches_last_frame": accepted},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(dom_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(stage_ms[dom], 4)},
+            "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(pipe_gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": pipe_bytes,
+                                  "kernel_ms_per_step": round(kernel_ms, 4)},
+            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, h, a.nfeatures, a.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

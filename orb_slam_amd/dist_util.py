@@ -1,0 +1,43 @@
+"""Multi-GPU plumbing: one process per GPU, one independent image stream per rank.
+The hot path has NO data-path collective — frames shard embarrassingly — so torch.distributed (RCCL on GPUs,
+gloo in the CPU tests) is used only to agree on the timing (MAX over ranks) and to gather throughput counters."""
+import os
+
+import torch
+
+
+def env_ranks():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend, world, rank, local_rank=0):
+    """Returns the torch.distributed module (initialised) or None for a single process."""
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    kw = {}
+    if backend == "nccl":
+        kw["device_id"] = torch.device("cuda", local_rank)
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+def stream_first_index(rank, ring):
+    """First synthetic-frame index of this rank's stream: ranks never share frames."""
+    return rank * ring
+
+
+def reduce_run(dist, elapsed_s, counters, device):
+    """elapsed_s: this rank's wall time of the timed region; counters: list of per-rank additive counters.
+    Returns (max elapsed over ranks, element-wise sum of counters over ranks, per-rank counter rows)."""
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
+    c = torch.tensor(list(counters), dtype=torch.float64, device=device)
+    if dist is None:
+        return float(t.item()), c.cpu().tolist(), [c.cpu().tolist()]
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    rows = [torch.zeros_like(c) for _ in range(dist.get_world_size())]
+    dist.all_gather(rows, c)
+    total = torch.stack(rows).sum(0)
+    return float(t.item()), total.cpu().tolist(), [r.cpu().tolist() for r in rows]
