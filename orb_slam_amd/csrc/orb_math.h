@@ -158,9 +158,8 @@ ORBX_HD int blur_taps7(int a, int b, int c, int d, int e, int f, int g) {
 // sum has 16 fractional bits.  ties_even = 1 for the columns OpenCV's SSE2 column filter handles
 // (float accumulate + cvtps2dq), 0 for its scalar tail / non-SIMD build (half-up).  SURVEY.md A.5.
 ORBX_HD int blur_round(int sum, int ties_even) {
-    int q = sum >> 16, rem = sum & 0xFFFF;
-    if (ties_even) q += (rem > 0x8000) || (rem == 0x8000 && (q & 1));
-    else q += rem >= 0x8000;
+    // half-up: (sum + 0x8000) >> 16;  ties-to-even: add 0x7FFF plus the parity of the integer part
+    int q = (sum + 0x7FFF + (ties_even ? ((sum >> 16) & 1) : 1)) >> 16;
     return q > 255 ? 255 : q;
 }
 

@@ -1,6 +1,7 @@
 // C ABI of the extractor (include/orbx.h): handle, device memory, launch orchestration.
 // All pixel work happens in orbx_kernels.hip; there is no host fallback.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "orbx_internal.h"
@@ -39,6 +40,7 @@ struct orbx_extractor {
     // diagnostics
     int stop_after = -1;
     StageTimer timer;
+    SideStream side;
     Batch last;
     bool have_last = false;
 };
@@ -95,8 +97,6 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
     if ((rc = upload(h, h->d_flagy, h->hg.flagy)) != ORBX_OK) return rc;
     HIPCHK(h, hipMalloc(&h->d_pyr, B * g.frame_plane_bytes));
     HIPCHK(h, hipMalloc(&h->d_blur, B * g.frame_plane_bytes));
-    HIPCHK(h, hipMalloc(&h->d_nms, B * g.frame_plane_bytes));
-    HIPCHK(h, hipMemset(h->d_nms, 0, B * g.frame_plane_bytes));   // only the scan area is ever rewritten
     HIPCHK(h, hipMalloc(&h->d_cand, B * std::max(g.frame_cands, 1) * sizeof(Cand)));
     HIPCHK(h, hipMalloc(&h->d_sel, B * std::max(g.frame_sel, 1) * sizeof(Cand)));
     HIPCHK(h, hipMalloc(&h->d_cstate, B * g.ncells_total * sizeof(CellState)));
@@ -143,6 +143,17 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
     if (hipSetDevice(p->device) != hipSuccess) return ORBX_ERR_DEVICE;
     orbx_extractor* h = new orbx_extractor();
     h->p = *p;
+    // The blur can run on a side stream next to the FAST/selection chain (ORBX_OVERLAP=1).  Measured on MI355X
+    // it does not pay at batch 256 (both kernels are VALU-bound), so the default is one stream, which also keeps
+    // per-kernel timings (HIP events, rocprofv3) free of cross-kernel contention.
+    const char* ovl = getenv("ORBX_OVERLAP");
+    if (!(ovl && ovl[0] == '1')) { *out = h; return ORBX_OK; }
+    if (hipStreamCreateWithFlags(&h->side.aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->side.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->side.join, hipEventDisableTiming) != hipSuccess) {
+        delete h;
+        return ORBX_ERR_DEVICE;
+    }
     *out = h;
     return ORBX_OK;
 }
@@ -152,6 +163,9 @@ void orbx_destroy(orbx_extractor* h) {
     (void)hipSetDevice(h->p.device);
     (void)hipDeviceSynchronize();
     free_geometry(h);
+    if (h->side.fork) (void)hipEventDestroy(h->side.fork);
+    if (h->side.join) (void)hipEventDestroy(h->side.join);
+    if (h->side.aux) (void)hipStreamDestroy(h->side.aux);
     dev_free(h->d_img1); dev_free(h->d_kps1); dev_free(h->d_desc1); dev_free(h->d_n1);
     delete h;
 }
@@ -194,7 +208,7 @@ int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int nfra
         b.out_n = d_n + f0;
         b.out_status = d_status ? d_status + f0 : nullptr;
         b.cap = cap;
-        rc = launch_extract(b, h->hg, stream, h->stop_after, &h->timer);
+        rc = launch_extract(b, h->hg, stream, h->stop_after, &h->timer, &h->side);
         if (rc != ORBX_OK) { h->err = "kernel launch failed (no gfx950 code object for this device?)"; return rc; }
         h->last = b;
         h->have_last = true;
@@ -280,7 +294,29 @@ long orbx_debug_fetch(orbx_extractor* h, int what, int frame, int level, void* h
     const DevGeom& g = h->hg.g;
     const LevelGeom& L = g.lv[level];
     const Batch& b = h->last;
-    if (what == ORBX_DBG_PLANE || what == ORBX_DBG_BLUR || what == ORBX_DBG_NMS) {
+    if (what == ORBX_DBG_NMS) {
+        // rebuilt on the host from the per-cell survivor lists (valid while they are untouched, i.e. when the
+        // last run stopped after stage 1: the retainBest kernels filter and permute the lists in place)
+        const long need = (long)L.w * L.h;
+        if (cap_bytes < need) return ORBX_ERR_CAPACITY;
+        memset(host_out, 0, need);
+        std::vector<CellState> st(L.ncells);
+        if (hipMemcpy(st.data(), b.cstate + (size_t)frame * g.ncells_total + L.cell_base, L.ncells * sizeof(CellState), hipMemcpyDeviceToHost) != hipSuccess)
+            return ORBX_ERR_DEVICE;
+        std::vector<Cand> tmp;
+        for (int c = 0; c < L.ncells; c++) {
+            const CellGeom& cgm = h->hg.cells[L.cell_base + c];
+            const int n = st[c].n_all;
+            if (n <= 0) continue;
+            if (n > cgm.cand_cap) return ORBX_ERR_CAPACITY;
+            tmp.resize(n);
+            if (hipMemcpy(tmp.data(), b.cand + (size_t)frame * g.frame_cands + L.cand_base + cgm.cand_off, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost) != hipSuccess)
+                return ORBX_ERR_DEVICE;
+            for (int i = 0; i < n; i++) ((uint8_t*)host_out)[(size_t)(tmp[i].pos >> 16) * L.w + (tmp[i].pos & 0xFFFF)] = (uint8_t)tmp[i].resp;
+        }
+        return need;
+    }
+    if (what == ORBX_DBG_PLANE || what == ORBX_DBG_BLUR) {
         const long need = (long)L.w * L.h;
         if (cap_bytes < need) return ORBX_ERR_CAPACITY;
         const uint8_t* src;
@@ -289,7 +325,7 @@ long orbx_debug_fetch(orbx_extractor* h, int what, int frame, int level, void* h
             src = b.img + (ptrdiff_t)frame * b.img_frame_stride;
             spitch = (size_t)b.img_row_stride;
         } else {
-            const uint8_t* base = what == ORBX_DBG_PLANE ? b.pyr : what == ORBX_DBG_BLUR ? b.blur : b.nms;
+            const uint8_t* base = what == ORBX_DBG_PLANE ? b.pyr : b.blur;
             src = base + (size_t)frame * g.frame_plane_bytes + L.plane_off;
             spitch = (size_t)L.stride;
         }

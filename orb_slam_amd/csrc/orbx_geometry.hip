@@ -28,7 +28,7 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
     const int nl = p.nlevels;
     if (nl < 1 || nl > MAX_LEVELS) { err = "nlevels out of range [1,16]"; return ORBX_ERR_ARG; }
     if (p.nfeatures < 1) { err = "nfeatures must be >= 1"; return ORBX_ERR_ARG; }
-    if (!(p.scale_factor > 1.0f)) { err = "scale_factor must be > 1"; return ORBX_ERR_ARG; }
+    if (!(p.scale_factor > 1.0f) || p.scale_factor > 2.5f) { err = "scale_factor must be in (1, 2.5]"; return ORBX_ERR_ARG; }
     if (w < 1 || h < 1 || w > 16384 || h > 16384) { err = "image size out of range"; return ORBX_ERR_ARG; }
     if (p.score_type != ORBX_HARRIS_SCORE && p.score_type != ORBX_FAST_SCORE) { err = "score_type"; return ORBX_ERR_ARG; }
 
@@ -167,8 +167,8 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
         L.tiles_y = (H + TILE_H - 1) / TILE_H;
         L.tile_base = tile_base;
         tile_base += L.tiles_x * L.tiles_y;
-        L.btiles_x = (L.w + TILE_W - 1) / TILE_W;
-        L.btiles_y = (L.h + TILE_H - 1) / TILE_H;
+        L.btiles_x = (L.w + 247) / 248;        // blur: 248-px column strips x 32-row bands, one wave each
+        L.btiles_y = (L.h + 31) / 32;
         L.btile_base = btile_base;
         btile_base += L.btiles_x * L.btiles_y;
 
@@ -205,6 +205,30 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
                 out.taby.push_back(e);
             }
         }
+    }
+    // LDS carve of k_fast_cells, sized by the largest cell
+    {
+        int max_px = 0, max_img = 0;
+        for (const CellGeom& c : out.cells) {
+            const int cw = c.x1 - c.x0 + 1, ch = c.y1 - c.y0 + 1;
+            if (cw <= 0 || ch <= 0) continue;
+            max_px = std::max(max_px, cw * ch);
+            const int nd = (3 + cw + 6 + 3) / 4;
+            max_img = std::max(max_img, nd * 4 * (ch + 6));
+        }
+        if (max_px > 65535) { err = "grid cell larger than 65535 pixels"; return ORBX_ERR_GEOMETRY; }
+        g.fast_max_px = align_up(std::max(max_px, 16), 16);
+        g.fast_max_chunks = align_up((max_px + 63) / 64 + 1, 4);
+        g.fast_lds_bytes = 16 + g.fast_max_chunks * 12 + 1024 * 2 + g.fast_max_px + align_up(max_img, 16) + 16;
+        if (g.fast_lds_bytes > 160 * 1024) { err = "grid cell does not fit the 160 KiB LDS"; return ORBX_ERR_GEOMETRY; }
+    }
+    {
+        int max_cell = 1, max_level = 1;
+        for (const CellGeom& c : out.cells) max_cell = std::max(max_cell, (int)c.cand_cap);
+        for (int l = 0; l < nl; l++) max_level = std::max(max_level, g.lv[l].sel_cap);
+        g.sel_lds_cell = align_up(max_cell * (int)sizeof(Cand), 16);
+        g.sel_lds_level = align_up(max_level * (int)sizeof(Cand), 16);
+        if (g.sel_lds_cell > 160 * 1024 || g.sel_lds_level > 160 * 1024) { err = "keypoint list does not fit the 160 KiB LDS"; return ORBX_ERR_GEOMETRY; }
     }
     g.ncells_total = cell_base;
     g.ntiles_total = tile_base;

@@ -42,7 +42,7 @@ struct LevelGeom {
     int tabx_off, taby_off;// offsets into the ResizeX / ResizeY tables (level >= 1)
     int flag_off_x, flag_off_y;   // offsets into the column / row cell-boundary flag tables
     int tile_base, tiles_x, tiles_y;   // 64x32 tiling of the scan area [16,w-17]x[16,h-17]
-    int btile_base, btiles_x, btiles_y;// 64x32 tiling of the whole plane (blur)
+    int btile_base, btiles_x, btiles_y;// blur wave tasks: 248-px strips x 32-row bands of the whole plane
     int blur_wvec;         // columns x < blur_wvec round ties-to-even (SSE2 emulation), others half-up
     float scale;           // mvScaleFactor[level]
     float kp_size;         // (float)(int)(PATCH_SIZE*mvScaleFactor[level])  (:675,:692)
@@ -67,6 +67,8 @@ struct DevGeom {
     int frame_plane_bytes;   // bytes of one frame's pyramid block (== blur block == nms block)
     int frame_cands;         // Cand slots per frame
     int frame_sel;           // sel slots per frame
+    int sel_lds_cell, sel_lds_level;                    // LDS bytes of k_cell_select / k_level_select (largest list)
+    int fast_max_px, fast_max_chunks, fast_lds_bytes;   // k_fast_cells LDS carve (largest cell of any level)
     int umax[HALF_PATCH + 1];
     LevelGeom lv[MAX_LEVELS];
 };
@@ -125,6 +127,12 @@ struct StageTimer {
 };
 
 // Launch the whole per-batch kernel sequence on `stream`; stop_after < 0 runs everything.
-int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int stop_after, StageTimer* timer);
+// Optional side stream: the blur depends only on the pyramid, so it runs on `aux` concurrently with the
+// FAST -> cell lists -> quotas -> retainBest chain (whose tail kernels are latency-bound and leave the chip idle).
+struct SideStream {
+    hipStream_t aux = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int stop_after, StageTimer* timer, const SideStream* side);
 
 }  // namespace orbx

@@ -4,8 +4,7 @@
 //
 // Stage            reference (under /root/reference/src/ORBextractor.cc)        kernel
 //   pyramid        ComputePyramid :781-822 (cv::resize INTER_LINEAR)             k_resize (per level, 7 launches)
-//   FAST + NMS     cv::FAST(cell, th, true) :607/:613                            k_fast_nms   (dense score, cell-local NMS)
-//   cell lists     raster-ordered keypoints of each cell                         k_compact    (wave ballot/popcount compaction)
+//   FAST + NMS     cv::FAST(cell, th, true) :607/:613 + raster-ordered cell lists  k_fast_cells (one workgroup per grid cell)
 //   quotas         :622-670                                                      k_quota      (sequential, one lane per level)
 //   retainBest     :683-685 (per cell), :697-701 (per level)                     k_cell_select / k_level_select (libstdc++ introselect)
 //   blur           GaussianBlur 7x7 s=2 :760                                     k_blur
@@ -42,29 +41,59 @@ __device__ __forceinline__ int find_level(const DevGeom& g, int idx, T base_of) 
 }
 
 // ------------------------------------------------------------------------------------ pyramid
-// cv::resize INTER_LINEAR 8U, level-1 -> level.  Each lane produces 4 horizontally adjacent output
-// pixels and stores them as one dword (coalesced 256 B per wave); source taps are byte gathers that
-// hit L1/L2 (each source row segment is re-read by the neighbouring output row).
+// cv::resize INTER_LINEAR 8U, level-1 -> level.  A workgroup produces a 256x4 output tile: the source
+// rectangle it needs (<= 7 rows x ~310 px) is staged in LDS with coalesced dword loads, each lane then
+// reads its 16 taps as LDS bytes, produces 4 horizontally adjacent output pixels and stores one dword.
+// (Byte gathers straight from global memory made this kernel texture-addresser bound.)
+constexpr int RZ_ROWS = 4;
+constexpr int RZ_SRC_ROWS = 12;    // >= RZ_ROWS * max scale + 2 (scale_factor <= 2.5 is checked on the host)
+constexpr int RZ_SRC_W = 704;      // >= 256 * max scale + 8, multiple of 4
+
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[RZ_SRC_ROWS * RZ_SRC_W];
     const DevGeom& g = *b.g;
     const LevelGeom& L = g.lv[level];
     const LevelGeom& P = g.lv[level - 1];
     const int frame = blockIdx.z;
-    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (dy >= L.h || dx0 >= L.w) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bx0 = blockIdx.x * 256, by0 = blockIdx.y * RZ_ROWS;
+    const int bx1 = min(bx0 + 255, L.w - 1), by1 = min(by0 + RZ_ROWS - 1, L.h - 1);
     long long sstride;
     const uint8_t* src = plain_plane(b, P, level - 1, frame, sstride);
-    const ResizeY ry = b.taby[L.taby_off + dy];
-    const uint8_t* r0 = src + ry.sy0 * sstride;
-    const uint8_t* r1 = src + ry.sy1 * sstride;
+    const ResizeX* tx = b.tabx + L.tabx_off;
+    const ResizeY* ty = b.taby + L.taby_off;
+    // source rectangle of this tile (tables are monotone)
+    const int r0 = ty[by0].sy0, r1 = ty[by1].sy1;
+    const int c0 = tx[bx0].sx & ~3, c1 = tx[bx1].sx1;
+    const int nd = ((c1 - c0) >> 2) + 1, nr = r1 - r0 + 1;
+    for (int r = wave; r < nr; r += 4) {
+        const uint8_t* row = src + (long long)(r0 + r) * sstride + c0;
+        for (int d = lane; d < nd; d += 64) {
+            uint32_t v4;
+            if (ALIGNED) v4 = *reinterpret_cast<const uint32_t*>(row + 4 * d);
+            else {
+                const int xm = P.w - 1 - c0;
+                v4 = (uint32_t)row[min(4 * d, xm)] | (uint32_t)row[min(4 * d + 1, xm)] << 8 | (uint32_t)row[min(4 * d + 2, xm)] << 16 |
+                     (uint32_t)row[min(4 * d + 3, xm)] << 24;
+            }
+            *reinterpret_cast<uint32_t*>(s_src + r * RZ_SRC_W + 4 * d) = v4;
+        }
+    }
+    __syncthreads();
+    const int dx0 = bx0 + lane * 4;
+    const int dy = by0 + wave;
+    if (dy >= L.h || dx0 >= L.w) return;
+    const ResizeY ry = ty[dy];
+    const uint8_t* q0 = s_src + (ry.sy0 - r0) * RZ_SRC_W - c0;
+    const uint8_t* q1 = s_src + (ry.sy1 - r0) * RZ_SRC_W - c0;
     uint32_t packed = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int dx = dx0 + k;
         if (dx < L.w) {
-            const ResizeX rx = b.tabx[L.tabx_off + dx];
-            const int px = resize_px(r0[rx.sx], r0[rx.sx1], r1[rx.sx], r1[rx.sx1], rx.a0, rx.a1, ry.b0, ry.b1);
+            const ResizeX rx = tx[dx];
+            const int px = resize_px(q0[rx.sx], q0[rx.sx1], q1[rx.sx], q1[rx.sx1], rx.a0, rx.a1, ry.b0, ry.b1);
             packed |= (uint32_t)(px & 255) << (8 * k);
         }
     }
@@ -72,136 +101,235 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
     *reinterpret_cast<uint32_t*>(dst + dx0) = packed;   // stride is a multiple of 64: in-bounds and aligned
 }
 
-// ------------------------------------------------------------------------------------ FAST + NMS
-// One workgroup = one 64x32 tile of a level's scan area.  The image tile (+4 halo) is staged in LDS,
-// every pixel of the tile +1 halo gets its exact FAST-9 score (fast9_score: two rounds of 3-input
-// min/max give the 9-arc extrema), then the 3x3 strict NMS runs from LDS.  Neighbours that belong to
-// a different grid cell count as 0, exactly as when cv::FAST is called per cell view.
-constexpr int FI_W = TILE_W + 8, FI_H = TILE_H + 8;   // image tile
-constexpr int FS_W = TILE_W + 2, FS_H = TILE_H + 2;   // score tile
-constexpr int FI_S = FI_W;                            // LDS row stride of the image tile (72 B)
-constexpr int FS_S = FS_W + 2;                        // 68 B
+// ------------------------------------------------------------------------------------ FAST + NMS + cell lists
+// One workgroup = one grid cell of one level of one frame — the unit the reference calls cv::FAST on
+// (src/ORBextractor.cc:599-614).  Because the NMS of cv::FAST never looks outside the cell view, a
+// cell-native workgroup needs no score halo, no survivor plane in HBM and no separate compaction pass:
+//   1. stage the cell's pixels (+3 halo) in LDS with dword loads;
+//   2. per 1024-pixel round, every lane runs a cheap exact-necessary test on 4 pixels (each opposite ring
+//      pair {k,k+8} must contain a pixel beyond the threshold) and the survivors are queued in LDS by
+//      __ballot/popcount; the full FAST-9 score (9-arc extrema of the RAW ring bytes by two rounds of
+//      v_min3/v_max3: dark = v - min_arcs(max9), bright = max_arcs(min9) - v) then runs on the dense queue;
+//   3. 3x3 strict NMS from the LDS score array, one 64-pixel raster chunk per wave step; the survivor
+//      ballots are kept, a wave-level scan turns their popcounts into list offsets, and the cell's keypoint
+//      list comes out in cv::FAST's raster order together with its counts at fastTh and at 7.
+struct FastLds {
+    int qn[2], n_hi, n_lo;   // qn: queue fill of the even / odd round (double-buffered so one barrier per phase suffices)
+};
 
-__global__ __launch_bounds__(256) void k_fast_nms(Batch b) {
-    __shared__ uint8_t s_img[FI_H * FI_S];
-    __shared__ uint8_t s_sc[FS_H * FS_S];
-    const DevGeom& g = *b.g;
-    const int frame = blockIdx.x / g.ntiles_total;
-    const int t = blockIdx.x - frame * g.ntiles_total;
-    const int level = find_level(g, t, [](const LevelGeom& l) { return l.tile_base; });
-    const LevelGeom& L = g.lv[level];
-    const int tl = t - L.tile_base;
-    const int ty = tl / L.tiles_x, tx = tl - ty * L.tiles_x;
-    const int x0 = EDGE + tx * TILE_W, y0 = EDGE + ty * TILE_H;
-    const int tid = threadIdx.x;
-    long long stride;
-    const uint8_t* src = plain_plane(b, L, level, frame, stride);
-
-    for (int i = tid; i < FI_H * FI_W; i += 256) {
-        const int ly = i / FI_W, lx = i - ly * FI_W;
-        const int gx = min(x0 - 4 + lx, L.w - 1), gy = min(y0 - 4 + ly, L.h - 1);
-        s_img[ly * FI_S + lx] = src[gy * stride + gx];
-    }
-    __syncthreads();
-
-    const int tmin = g.tmin;
-    for (int p = tid; p < FS_H * FS_W; p += 256) {
-        const int sy = p / FS_W, sx = p - sy * FS_W;
-        const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-        const bool in_scan = gx >= EDGE && gx < L.w - EDGE && gy >= EDGE && gy < L.h - EDGE;
-        const uint8_t* c = &s_img[(sy + 3) * FI_S + sx + 3];
-        const int v = c[0];
-        int d[16];
-        d[0] = v - c[3 * FI_S + 0];   d[1] = v - c[3 * FI_S + 1];   d[2] = v - c[2 * FI_S + 2];   d[3] = v - c[1 * FI_S + 3];
-        d[4] = v - c[3];              d[5] = v - c[-1 * FI_S + 3];  d[6] = v - c[-2 * FI_S + 2];  d[7] = v - c[-3 * FI_S + 1];
-        d[8] = v - c[-3 * FI_S + 0];  d[9] = v - c[-3 * FI_S - 1];  d[10] = v - c[-2 * FI_S - 2]; d[11] = v - c[-1 * FI_S - 3];
-        d[12] = v - c[-3];            d[13] = v - c[1 * FI_S - 3];  d[14] = v - c[2 * FI_S - 2];  d[15] = v - c[3 * FI_S - 1];
-        // cheap necessary condition, wave-uniform skip over flat regions
-        int mx = imax3(d[0], d[1], d[2]), mn = imin3(d[0], d[1], d[2]);
-#pragma unroll
-        for (int k = 3; k < 15; k += 2) { mx = imax3(mx, d[k], d[k + 1]); mn = imin3(mn, d[k], d[k + 1]); }
-        mx = imax(mx, d[15]); mn = imin(mn, d[15]);
-        const bool maybe = in_scan && (mx > tmin || mn < -tmin);
-        int score = 0;
-        if (__any(maybe)) score = maybe ? fast9_score(d, tmin) : 0;
-        s_sc[sy * FS_S + sx] = (uint8_t)score;
-    }
-    __syncthreads();
-
-    uint8_t* nms = b.nms + (long long)frame * g.frame_plane_bytes + L.plane_off;
-    const uint8_t* fxs = b.flagx + L.flag_off_x;
-    const uint8_t* fys = b.flagy + L.flag_off_y;
-    const int lx = tid & 63;
-    const int gx = x0 + lx;
-    if (gx >= L.w - EDGE) return;
-    const int fx = fxs[gx];
-#pragma unroll
-    for (int k = 0; k < TILE_H / 4; k++) {
-        const int ly = (tid >> 6) + 4 * k;
-        const int gy = y0 + ly;
-        if (gy >= L.h - EDGE) break;
-        const uint8_t* sc = &s_sc[(ly + 1) * FS_S + lx + 1];
-        const int s = sc[0];
-        int keep = 0;
-        if (s) {
-            const int fy = fys[gy];
-            const bool hasL = !(fx & 1), hasR = !(fx & 2), hasU = !(fy & 1), hasD = !(fy & 2);
-            int m = 0;   // max over valid neighbours
-            if (hasL) m = imax(m, sc[-1]);
-            if (hasR) m = imax(m, sc[1]);
-            if (hasU) {
-                m = imax(m, sc[-FS_S]);
-                if (hasL) m = imax(m, sc[-FS_S - 1]);
-                if (hasR) m = imax(m, sc[-FS_S + 1]);
-            }
-            if (hasD) {
-                m = imax(m, sc[FS_S]);
-                if (hasL) m = imax(m, sc[FS_S - 1]);
-                if (hasR) m = imax(m, sc[FS_S + 1]);
-            }
-            keep = s > m ? s : 0;
-        }
-        nms[(long long)gy * L.stride + gx] = (uint8_t)keep;
-    }
+__device__ __forceinline__ int fast_pair_test(const uint8_t* c, int S, int v, int t) {
+    // ring offsets k=0..15 (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+    const int x0 = c[3 * S], x1 = c[3 * S + 1], x2 = c[2 * S + 2], x3 = c[S + 3], x4 = c[3], x5 = c[-S + 3], x6 = c[-2 * S + 2], x7 = c[-3 * S + 1];
+    const int x8 = c[-3 * S], x9 = c[-3 * S - 1], x10 = c[-2 * S - 2], x11 = c[-S - 3], x12 = c[-3], x13 = c[S - 3], x14 = c[2 * S - 2], x15 = c[3 * S - 1];
+    // a dark 9-arc contains one pixel of every opposite pair, so max_k min(pair) < v - t is necessary (bright: mirrored)
+    const int a = imax3(imax3(imin(x0, x8), imin(x1, x9), imin(x2, x10)), imax3(imin(x3, x11), imin(x4, x12), imin(x5, x13)), imax(imin(x6, x14), imin(x7, x15)));
+    const int bq = imin3(imin3(imax(x0, x8), imax(x1, x9), imax(x2, x10)), imin3(imax(x3, x11), imax(x4, x12), imax(x5, x13)), imin(imax(x6, x14), imax(x7, x15)));
+    return (v - a > t) | (bq - v > t);
 }
 
-// ------------------------------------------------------------------------------------ cell lists
-// One wave per (frame, cell): walk the cell's scan rectangle in raster order, 64 pixels per step;
-// __ballot + popcount give each survivor its rank, so the list comes out in cv::FAST's raster order.
-__global__ __launch_bounds__(64) void k_compact(Batch b) {
+__device__ __forceinline__ int fast_score_raw(const uint8_t* c, int S, int v, int tmin) {
+    int x[16];
+    x[0] = c[3 * S]; x[1] = c[3 * S + 1]; x[2] = c[2 * S + 2]; x[3] = c[S + 3]; x[4] = c[3]; x[5] = c[-S + 3]; x[6] = c[-2 * S + 2]; x[7] = c[-3 * S + 1];
+    x[8] = c[-3 * S]; x[9] = c[-3 * S - 1]; x[10] = c[-2 * S - 2]; x[11] = c[-S - 3]; x[12] = c[-3]; x[13] = c[S - 3]; x[14] = c[2 * S - 2]; x[15] = c[3 * S - 1];
+    int hi3[16], lo3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        hi3[k] = imax3(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+        lo3[k] = imin3(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+    }
+    int min_hi9 = 255, max_lo9 = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        min_hi9 = imin(min_hi9, imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
+        max_lo9 = imax(max_lo9, imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
+    }
+    const int s = imax(v - min_hi9, max_lo9 - v) - 1;   // == OpenCV cornerScore for every corner
+    return s >= tmin ? s : 0;
+}
+
+constexpr int FAST_ROUND = 1024;   // pixels per filter/score round (4 per lane)
+
+// p -> (p / cw, p % cw) for p < 65536, cw <= 4096 with full-rate VALU ops only (v_mul_lo/hi_u32 are
+// quarter rate): q = trunc((p + 0.5) * (1/cw)).  (p+0.5)/cw is at least 0.5/cw away from any integer, the
+// float product is off by < q * 2^-22 <= 2^-6 * ... far below that margin for every cell size the LDS holds.
+__device__ __forceinline__ void split_px(int p, int cw, float inv_cw, int& y, int& x) {
+    y = (int)(((float)p + 0.5f) * inv_cw);
+    x = p - (int)__umul24((unsigned)y, (unsigned)cw);
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const DevGeom& g = *b.g;
     const int frame = blockIdx.x / g.ncells_total;
     const int cell = blockIdx.x - frame * g.ncells_total;
     const int level = find_level(g, cell, [](const LevelGeom& l) { return l.cell_base; });
     const LevelGeom& L = g.lv[level];
-    const CellGeom c = b.cells[cell];
-    const int lane = threadIdx.x;
-    Cand* out = b.cand + (long long)frame * g.frame_cands + L.cand_base + c.cand_off;
-    const uint8_t* nms = b.nms + (long long)frame * g.frame_plane_bytes + L.plane_off;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int n = 0, nhi = 0, nlo = 0;
-    for (int y = c.y0; y <= c.y1; y++) {
-        const uint8_t* row = nms + (long long)y * L.stride;
-        for (int xb = c.x0; xb <= c.x1; xb += 64) {
-            const int x = xb + lane;
-            const int s = (x <= c.x1) ? row[x] : 0;
-            const unsigned long long m = __ballot(s != 0);
-            if (m == 0) continue;
-            if (s) {
-                Cand e;
-                e.pos = (uint32_t)x | ((uint32_t)y << 16);
-                e.resp = (float)s;
-                out[n + __popcll(m & lt)] = e;
+    const CellGeom cg = b.cells[cell];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cw = cg.x1 - cg.x0 + 1, ch = cg.y1 - cg.y0 + 1;
+    CellState* cst = b.cstate + (long long)frame * g.ncells_total + cell;
+    if (cw <= 0 || ch <= 0) {
+        if (tid == 0) { CellState st; st.n_all = 0; st.n_hi = 0; st.n_lo = 0; *cst = st; }
+        return;
+    }
+    const int npx = cw * ch;
+    const int nchunks = (npx + 63) >> 6;
+    // LDS carve (all offsets multiples of 16): header | chunk masks | chunk offsets | queue | scores | image
+    FastLds* hdr = reinterpret_cast<FastLds*>(smem);
+    unsigned long long* cmask = reinterpret_cast<unsigned long long*>(smem + 16);
+    int* coffs = reinterpret_cast<int*>(smem + 16 + g.fast_max_chunks * 8);
+    uint16_t* queue = reinterpret_cast<uint16_t*>(smem + 16 + g.fast_max_chunks * 12);
+    uint8_t* s_sc = smem + 16 + g.fast_max_chunks * 12 + FAST_ROUND * 2;
+    uint8_t* s_img = s_sc + g.fast_max_px;
+    // image region: rows y0-3..y1+3, columns from the dword-aligned start at or left of x0-3
+    const int gxb = (cg.x0 - 3) & ~3;
+    const int xoff = (cg.x0 - 3) - gxb;
+    const int nd = (xoff + cw + 6 + 3) >> 2;
+    const int S = nd * 4;
+    long long stride;
+    const uint8_t* src = plain_plane(b, L, level, frame, stride);
+    for (int r = wave; r < ch + 6; r += 4) {
+        const uint8_t* row = src + (long long)(cg.y0 - 3 + r) * stride + gxb;
+        for (int d = lane; d < nd; d += 64) {
+            uint32_t v4;
+            if (ALIGNED) v4 = *reinterpret_cast<const uint32_t*>(row + 4 * d);
+            else {
+                const int xm = L.w - 1 - gxb;   // never read past the row end on the unaligned path
+                v4 = (uint32_t)row[imin(4 * d, xm)] | (uint32_t)row[imin(4 * d + 1, xm)] << 8 | (uint32_t)row[imin(4 * d + 2, xm)] << 16 |
+                     (uint32_t)row[imin(4 * d + 3, xm)] << 24;
             }
-            n += __popcll(m);
-            nhi += __popcll(__ballot(s >= g.fast_th && s != 0));
-            nlo += __popcll(__ballot(s >= 7));
+            *reinterpret_cast<uint32_t*>(s_img + r * S + 4 * d) = v4;
         }
     }
-    if (lane == 0) {
+    if (tid == 0) { hdr->qn[0] = 0; hdr->qn[1] = 0; hdr->n_hi = 0; hdr->n_lo = 0; }
+    __syncthreads();
+
+    const float inv_cw = 1.0f / (float)cw;
+    const int tmin = g.tmin;
+    const uint8_t* img0 = s_img + 3 * S + xoff + 3;         // pixel (0,0) of the cell
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = 0, rnd = 0; base < npx; base += FAST_ROUND, rnd ^= 1) {
+        int pass[FAST_ROUND / 256];
+        unsigned long long pm[FAST_ROUND / 256];
+#pragma unroll
+        for (int k = 0; k < FAST_ROUND / 256; k++) {
+            const int p = base + k * 256 + tid;
+            pass[k] = 0;
+            const uint8_t* c = img0;
+            int v = 0, maybe = 0;
+            if (p < npx) {
+                int y, x;
+                split_px(p, cw, inv_cw, y, x);
+                c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
+                v = c[0];
+                // a 9-arc covers at least 2 of the 4 compass pixels: one of them must be beyond the threshold
+                const int x0 = c[3 * S], x4 = c[3], x8 = c[-3 * S], x12 = c[-3];
+                maybe = (int)(v - imin(imin(x0, x4), imin(x8, x12)) > tmin) | (int)(imax(imax(x0, x4), imax(x8, x12)) - v > tmin);
+                s_sc[p] = 0;
+            }
+            if (__any(maybe)) pass[k] = maybe ? fast_pair_test(c, S, v, tmin) : 0;   // wave-uniform skip over flat regions
+            pm[k] = __ballot(pass[k]);
+        }
+        {
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < FAST_ROUND / 256; k++) cnt += __popcll(pm[k]);
+            if (cnt) {
+                int qb = 0;
+                if (lane == 0) qb = atomicAdd(&hdr->qn[rnd], cnt);
+                qb = __shfl(qb, 0, 64);
+#pragma unroll
+                for (int k = 0; k < FAST_ROUND / 256; k++) {
+                    if (pass[k]) queue[qb + __popcll(pm[k] & lt)] = (uint16_t)(base + k * 256 + tid);
+                    qb += __popcll(pm[k]);
+                }
+            }
+        }
+        __syncthreads();
+        const int qn = hdr->qn[rnd];
+        if (tid == 0) hdr->qn[rnd ^ 1] = 0;   // next round's counter; nobody touches it before the barrier below
+        for (int i = tid; i < qn; i += 256) {
+            const int p = queue[i];
+            int y, x;
+            split_px(p, cw, inv_cw, y, x);
+            const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
+            s_sc[p] = (uint8_t)fast_score_raw(c, S, c[0], tmin);
+        }
+        __syncthreads();
+    }
+
+    // NMS per 64-pixel raster chunk; neighbours outside the cell count as 0
+    int nhi = 0, nlo = 0;
+    for (int ci = wave; ci < nchunks; ci += 4) {
+        const int p = ci * 64 + lane;
+        int s = 0, keep = 0;
+        if (p < npx) s = s_sc[p];
+        if (!__any(s)) {   // no corner in this chunk
+            if (lane == 0) { cmask[ci] = 0ull; coffs[ci] = 0; }
+            continue;
+        }
+        if (s) {
+            int y, x;
+            split_px(p, cw, inv_cw, y, x);
+            const uint8_t* q = s_sc + p;
+            const bool hasL = x > 0, hasR = x < cw - 1, hasU = y > 0, hasD = y < ch - 1;
+            int mx = 0;
+            if (hasL) mx = imax(mx, q[-1]);
+            if (hasR) mx = imax(mx, q[1]);
+            if (hasU) {
+                mx = imax(mx, q[-cw]);
+                if (hasL) mx = imax(mx, q[-cw - 1]);
+                if (hasR) mx = imax(mx, q[-cw + 1]);
+            }
+            if (hasD) {
+                mx = imax(mx, q[cw]);
+                if (hasL) mx = imax(mx, q[cw - 1]);
+                if (hasR) mx = imax(mx, q[cw + 1]);
+            }
+            keep = s > mx;
+        }
+        const unsigned long long m = __ballot(keep);
+        nhi += __popcll(__ballot(keep && s >= g.fast_th));
+        nlo += __popcll(__ballot(keep && s >= 7));
+        if (lane == 0) { cmask[ci] = m; coffs[ci] = __popcll(m); }
+    }
+    if (lane == 0) { atomicAdd(&hdr->n_hi, nhi); atomicAdd(&hdr->n_lo, nlo); }
+    __syncthreads();
+    // exclusive scan of the chunk counts (wave 0): lane-local run, wave scan, lane-local fix-up
+    if (wave == 0) {
+        const int per = (nchunks + 63) >> 6;
+        const int c0 = lane * per, c1 = imin(c0 + per, nchunks);
+        int sum = 0;
+        for (int ci = c0; ci < c1; ci++) sum += coffs[ci];
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        int run = incl - sum;
+        for (int ci = c0; ci < c1; ci++) { const int cnt = coffs[ci]; coffs[ci] = run; run += cnt; }
+        if (lane == 63) hdr->qn[0] = incl;   // total survivors (the round counters are free now)
+    }
+    __syncthreads();
+    Cand* out = b.cand + (long long)frame * g.frame_cands + L.cand_base + cg.cand_off;
+    for (int ci = wave; ci < nchunks; ci += 4) {
+        const unsigned long long m = cmask[ci];
+        if ((m >> lane) & 1ull) {
+            const int p = ci * 64 + lane;
+            int y, x;
+            split_px(p, cw, inv_cw, y, x);
+            Cand e;
+            e.pos = (uint32_t)(cg.x0 + x) | ((uint32_t)(cg.y0 + y) << 16);
+            e.resp = (float)s_sc[p];
+            out[coffs[ci] + __popcll(m & lt)] = e;
+        }
+    }
+    if (tid == 0) {
         CellState st;
-        st.n_all = n; st.n_hi = nhi; st.n_lo = nlo;
-        b.cstate[(long long)frame * g.ncells_total + cell] = st;
+        st.n_all = hdr->qn[0]; st.n_hi = hdr->n_hi; st.n_lo = hdr->n_lo;
+        *cst = st;
     }
 }
 
@@ -281,99 +409,148 @@ __device__ float harris_response(const uint8_t* img, long long step, int x, int 
 // that std::nth_element leaves in front (the std::partition of boundary ties is truncated away again by
 // the resize).  Which tied keypoints survive, and their ORDER, is libstdc++'s introselect;
 // std::nth_element is constexpr in C++20, so the very same library code is compiled for the device.
+// The algorithm is sequential, so one lane runs it — but on a copy of the list staged in LDS (latency
+// ~100 cycles instead of ~1-2k for global memory); the wave does the staging, the threshold filter
+// (ordered __ballot compaction) and, for HARRIS_SCORE, the per-keypoint responses in parallel.
 __global__ __launch_bounds__(64) void k_cell_select(Batch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Cand* lst = reinterpret_cast<Cand*>(smem);
     const DevGeom& g = *b.g;
-    const int idx = blockIdx.x * 64 + threadIdx.x;
-    if (idx >= b.nframes * g.ncells_total) return;
-    const int frame = idx / g.ncells_total, cell = idx - frame * g.ncells_total;
+    const int frame = blockIdx.x / g.ncells_total, cell = blockIdx.x - frame * g.ncells_total;
     const int level = find_level(g, cell, [](const LevelGeom& l) { return l.cell_base; });
     const LevelGeom& L = g.lv[level];
     const CellGeom cgeo = b.cells[cell];
     const CellSel s = b.csel[(long long)frame * g.ncells_total + cell];
     if (s.nretain <= 0) return;
+    const int lane = threadIdx.x;
     const int n_all = b.cstate[(long long)frame * g.ncells_total + cell].n_all;
-    Cand* c = b.cand + (long long)frame * g.frame_cands + L.cand_base + cgeo.cand_off;
-    int m = 0;
+    const Cand* c = b.cand + (long long)frame * g.frame_cands + L.cand_base + cgeo.cand_off;
     const float thr = (float)s.thr;
-    for (int i = 0; i < n_all; i++) {
-        const Cand e = c[i];
-        if (e.resp >= thr) c[m++] = e;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int m = 0;
+    for (int base = 0; base < n_all; base += 64) {
+        const int i = base + lane;
+        Cand e;
+        e.pos = 0; e.resp = -1.f;
+        if (i < n_all) e = c[i];
+        const bool pass = i < n_all && e.resp >= thr;
+        const unsigned long long mk = __ballot(pass);
+        if (pass) lst[m + __popcll(mk & lt)] = e;
+        m += __popcll(mk);
     }
+    __syncthreads();
     if (g.score_type == ORBX_HARRIS_SCORE) {
         long long stride;
         const uint8_t* img = plain_plane(b, L, level, frame, stride);
-        for (int i = 0; i < m; i++) c[i].resp = harris_response(img, stride, c[i].pos & 0xFFFF, c[i].pos >> 16);
+        for (int i = lane; i < m; i += 64) lst[i].resp = harris_response(img, stride, lst[i].pos & 0xFFFF, lst[i].pos >> 16);
+        __syncthreads();
     }
-    if (m > s.nretain) std::nth_element(c, c + s.nretain, c + m, RespGreater());
+    if (m > s.nretain && lane == 0) std::nth_element(lst, lst + s.nretain, lst + m, RespGreater());
+    __syncthreads();
     Cand* out = b.sel + (long long)frame * g.frame_sel + L.sel_base + s.out_off;
     const int keep = min(m, s.nretain);
-    for (int i = 0; i < keep; i++) out[i] = c[i];
+    for (int i = lane; i < keep; i += 64) out[i] = lst[i];
 }
 
-// reference :697-701 (per-level cap)
+// reference :697-701 (per-level cap), same LDS staging
 __global__ __launch_bounds__(64) void k_level_select(Batch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Cand* lst = reinterpret_cast<Cand*>(smem);
     const DevGeom& g = *b.g;
-    const int idx = blockIdx.x * 64 + threadIdx.x;
-    if (idx >= b.nframes * g.nlevels) return;
-    const int frame = idx / g.nlevels, level = idx - frame * g.nlevels;
+    const int frame = blockIdx.x / g.nlevels, level = blockIdx.x - frame * g.nlevels;
     const LevelGeom& L = g.lv[level];
+    const int lane = threadIdx.x;
     const int total = b.level_total[frame * MAX_LEVELS + level];
     int n = total;
     if (total > L.ndesired) {
         n = L.ndesired;
         if (n > 0) {
             Cand* v = b.sel + (long long)frame * g.frame_sel + L.sel_base;
-            std::nth_element(v, v + n, v + total, RespGreater());
+            for (int i = lane; i < total; i += 64) lst[i] = v[i];
+            __syncthreads();
+            if (lane == 0) std::nth_element(lst, lst + n, lst + total, RespGreater());
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) v[i] = lst[i];
         }
     }
-    b.level_count[frame * MAX_LEVELS + level] = n;
+    if (lane == 0) b.level_count[frame * MAX_LEVELS + level] = n;
 }
 
 // ------------------------------------------------------------------------------------ blur
 // GaussianBlur 7x7 sigma 2 (8U fixed point, taps [18,34,49,55,49,34,18]/256 twice, 16 fractional bits).
-// Separable inside one workgroup: image tile (+3 halo, reflect-101 at the image edge) -> LDS, row sums
-// -> LDS, column pass -> global.  Reads the UNBLURRED plane, writes a separate blurred plane, which is
-// what the reference's in-place filter computes (its border taps read the unblurred reflect border).
-constexpr int BI_W = TILE_W + 6, BI_H = TILE_H + 6;
-constexpr int BI_S = TILE_W + 8;   // 72
+// Register-resident separable filter, no LDS: one wave owns a 248-px wide column strip and streams down
+// BLUR_ROWS output rows.  Lane j holds one dword (4 pixels) of the current row; the neighbouring dwords
+// come from lanes j-1 / j+1 by DPP wave shifts, v_alignbyte_b32 cuts the 4-byte tap windows and two
+// v_dot4_u32_u8 give a pixel's 7-tap row sum.  The last 7 row sums live in registers (loop fully unrolled),
+// so the column pass is 7 multiply-adds per pixel; each lane stores its 4 output pixels as one dword.
+// Reads the UNBLURRED plane and writes a separate blurred plane, which is what the reference's in-place
+// filter computes (its border taps read the unblurred reflect-101 border; here: reflect-101 index math).
+constexpr int BLUR_ROWS = 32;
+constexpr int BLUR_STRIP_DW = 62;   // useful dwords per wave (lanes 1..62; lanes 0 and 63 are halo)
 
+__device__ __forceinline__ uint32_t load_px4_reflect(const uint8_t* row, int x, int w) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v |= (uint32_t)row[reflect101(x + i, w)] << (8 * i);
+    return v;
+}
+
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_blur(Batch b) {
-    __shared__ uint8_t s_in[BI_H * BI_S];
-    __shared__ uint32_t s_row[BI_H * TILE_W];
     const DevGeom& g = *b.g;
-    const int frame = blockIdx.x / g.nbtiles_total;
-    const int t = blockIdx.x - frame * g.nbtiles_total;
+    const int task_all = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int frame = task_all / g.nbtiles_total;
+    if (frame >= b.nframes) return;
+    const int t = task_all - frame * g.nbtiles_total;
     const int level = find_level(g, t, [](const LevelGeom& l) { return l.btile_base; });
     const LevelGeom& L = g.lv[level];
     const int tl = t - L.btile_base;
-    const int ty = tl / L.btiles_x, tx = tl - ty * L.btiles_x;
-    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
-    const int tid = threadIdx.x;
+    const int band = tl / L.btiles_x, strip = tl - band * L.btiles_x;
+    const int lane = threadIdx.x & 63;
+    const int x = (strip * BLUR_STRIP_DW + lane - 1) * 4;      // first pixel of this lane's dword (may be < 0)
+    const int y0 = band * BLUR_ROWS;
+    const int w = L.w, h = L.h;
     long long stride;
     const uint8_t* src = plain_plane(b, L, level, frame, stride);
-    for (int i = tid; i < BI_H * BI_W; i += 256) {
-        const int ly = i / BI_W, lx = i - ly * BI_W;
-        const int gx = reflect101(x0 - 3 + lx, L.w), gy = reflect101(y0 - 3 + ly, L.h);
-        s_in[ly * BI_S + lx] = src[gy * stride + gx];
-    }
-    __syncthreads();
-    for (int p = tid; p < BI_H * TILE_W; p += 256) {
-        const int r = p >> 6, x = p & 63;
-        const uint8_t* q = &s_in[r * BI_S + x];
-        s_row[p] = (uint32_t)blur_taps7(q[0], q[1], q[2], q[3], q[4], q[5], q[6]);
-    }
-    __syncthreads();
-    const int lx = tid & 63, gx = x0 + lx;
-    if (gx >= L.w) return;
     uint8_t* dst = b.blur + (long long)frame * g.frame_plane_bytes + L.plane_off;
-    const int te = gx < L.blur_wvec;
+    const bool interior = x >= 0 && x + 3 < w;
+    const bool fetch = x >= -4 && x < w + 4;                   // halo lanes beyond that are never consumed
+    const bool writer = lane >= 1 && lane <= BLUR_STRIP_DW && x < w;
+    const int te = x < L.blur_wvec;                            // blur_wvec is a multiple of 4
+    const uint32_t WA = 0x37312212u;                           // taps 18,34,49,55 (little-endian bytes)
+    const uint32_t WB = 0x00122231u;                           // taps 49,34,18,0
+    uint32_t rs[7][4];
 #pragma unroll
-    for (int k = 0; k < TILE_H / 4; k++) {
-        const int ly = (tid >> 6) + 4 * k, gy = y0 + ly;
-        if (gy >= L.h) break;
-        const uint32_t* q = &s_row[ly * TILE_W + lx];
-        const int sum = blur_taps7(q[0], q[TILE_W], q[2 * TILE_W], q[3 * TILE_W], q[4 * TILE_W], q[5 * TILE_W], q[6 * TILE_W]);
-        dst[(long long)gy * L.stride + gx] = (uint8_t)blur_round(sum, te);
+    for (int r = 0; r < BLUR_ROWS + 6; r++) {
+        const int yy = reflect101(y0 + r - 3, h);
+        const uint8_t* row = src + (long long)yy * stride;
+        uint32_t C = 0;
+        if (fetch) {
+            if (ALIGNED && interior) C = *reinterpret_cast<const uint32_t*>(row + x);
+            else C = load_px4_reflect(row, x, w);
+        }
+        const uint32_t Lw = __builtin_amdgcn_update_dpp(0u, C, 0x138, 0xf, 0xf, false);   // wave_shr:1  <- lane-1
+        const uint32_t R = __builtin_amdgcn_update_dpp(0u, C, 0x130, 0xf, 0xf, false);    // wave_shl:1  <- lane+1
+        const uint32_t wa0 = __builtin_amdgcn_alignbyte(C, Lw, 1), wa1 = __builtin_amdgcn_alignbyte(C, Lw, 2),
+                       wa2 = __builtin_amdgcn_alignbyte(C, Lw, 3), wa3 = C;
+        const uint32_t wb0 = __builtin_amdgcn_alignbyte(R, C, 1), wb1 = __builtin_amdgcn_alignbyte(R, C, 2),
+                       wb2 = __builtin_amdgcn_alignbyte(R, C, 3), wb3 = R;
+        uint32_t* cur = rs[r % 7];
+        cur[0] = __builtin_amdgcn_udot4(wa0, WA, __builtin_amdgcn_udot4(wb0, WB, 0u, false), false);
+        cur[1] = __builtin_amdgcn_udot4(wa1, WA, __builtin_amdgcn_udot4(wb1, WB, 0u, false), false);
+        cur[2] = __builtin_amdgcn_udot4(wa2, WA, __builtin_amdgcn_udot4(wb2, WB, 0u, false), false);
+        cur[3] = __builtin_amdgcn_udot4(wa3, WA, __builtin_amdgcn_udot4(wb3, WB, 0u, false), false);
+        if (r >= 6) {
+            const int oy = y0 + r - 6;
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int sum = blur_taps7((int)rs[(r - 6) % 7][i], (int)rs[(r - 5) % 7][i], (int)rs[(r - 4) % 7][i], (int)rs[(r - 3) % 7][i],
+                                           (int)rs[(r - 2) % 7][i], (int)rs[(r - 1) % 7][i], (int)rs[r % 7][i]);
+                packed |= (uint32_t)blur_round(sum, te) << (8 * i);
+            }
+            if (writer && oy < h) *reinterpret_cast<uint32_t*>(dst + (long long)oy * L.stride + x) = packed;
+        }
     }
 }
 
@@ -420,7 +597,7 @@ __global__ __launch_bounds__(256) void k_describe(Batch b) {
     {
         const int u = (lane & 31) - HALF_PATCH;
         const int au = u < 0 ? -u : u;
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < 16; it++) {
             const int r = it * 2 + (lane >> 5);
             const int v = r - HALF_PATCH;
@@ -496,7 +673,7 @@ struct StageScope {   // records (start, stop) events around one stage when timi
     }
 };
 
-int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int stop_after, StageTimer* timer) {
+int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int stop_after, StageTimer* timer, const SideStream* side) {
     const DevGeom& g = hg.g;
     const int F = b.nframes;
     if (F <= 0) return ORBX_OK;
@@ -505,23 +682,42 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         StageScope sc(timer, stream, ST_PYRAMID);
         for (int l = 1; l < g.nlevels; l++) {
             const LevelGeom& L = g.lv[l];
-            dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, F);
-            hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, stream, b, l);
+            dim3 grid((L.w + 255) / 256, (L.h + RZ_ROWS - 1) / RZ_ROWS, F);
+            const bool al = l > 1 || (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
+            if (al) hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), 0, stream, b, l);
+            else hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), 0, stream, b, l);
             ORBX_LAUNCH_CHECK();
         }
     }
     if (stop_after == ST_PYRAMID) return ORBX_OK;
+    auto launch_blur = [&](hipStream_t st) -> int {
+        StageScope sc(timer, st, ST_BLUR);
+        const bool aligned = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
+        const int nblk = (F * g.nbtiles_total + 3) / 4;
+        if (aligned) hipLaunchKernelGGL(k_blur<true>, dim3(nblk), dim3(256), 0, st, b);
+        else hipLaunchKernelGGL(k_blur<false>, dim3(nblk), dim3(256), 0, st, b);
+        ORBX_LAUNCH_CHECK();
+        return ORBX_OK;
+    };
+    const bool overlap = side && side->aux && stop_after < 0;
+    if (overlap) {
+        if (hipEventRecord(side->fork, stream) != hipSuccess || hipStreamWaitEvent(side->aux, side->fork, 0) != hipSuccess) return ORBX_ERR_DEVICE;
+        if (launch_blur(side->aux) != ORBX_OK) return ORBX_ERR_DEVICE;
+        if (hipEventRecord(side->join, side->aux) != hipSuccess) return ORBX_ERR_DEVICE;
+    }
     {
         StageScope sc(timer, stream, ST_FAST_NMS);
-        hipLaunchKernelGGL(k_fast_nms, dim3(F * g.ntiles_total), dim3(256), 0, stream, b);
+        const bool aligned = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
+        const size_t lds = (size_t)g.fast_lds_bytes;
+        if (lds > 64 * 1024) {   // opt in to > 64 KiB dynamic LDS (big cells, e.g. 1080p)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+        if (aligned) hipLaunchKernelGGL(k_fast_cells<true>, dim3(F * g.ncells_total), dim3(256), lds, stream, b);
+        else hipLaunchKernelGGL(k_fast_cells<false>, dim3(F * g.ncells_total), dim3(256), lds, stream, b);
         ORBX_LAUNCH_CHECK();
     }
     if (stop_after == ST_FAST_NMS) return ORBX_OK;
-    {
-        StageScope sc(timer, stream, ST_COMPACT);
-        hipLaunchKernelGGL(k_compact, dim3(F * g.ncells_total), dim3(64), 0, stream, b);
-        ORBX_LAUNCH_CHECK();
-    }
     if (stop_after == ST_COMPACT) return ORBX_OK;
     {
         StageScope sc(timer, stream, ST_QUOTA);
@@ -531,21 +727,23 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     if (stop_after == ST_QUOTA) return ORBX_OK;
     {
         StageScope sc(timer, stream, ST_CELL_SELECT);
-        hipLaunchKernelGGL(k_cell_select, dim3((F * g.ncells_total + 63) / 64), dim3(64), 0, stream, b);
+        const size_t lds = (size_t)g.sel_lds_cell;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cell_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_cell_select, dim3(F * g.ncells_total), dim3(64), lds, stream, b);
         ORBX_LAUNCH_CHECK();
     }
     if (stop_after == ST_CELL_SELECT) return ORBX_OK;
     {
         StageScope sc(timer, stream, ST_LEVEL_SELECT);
-        hipLaunchKernelGGL(k_level_select, dim3((F * g.nlevels + 63) / 64), dim3(64), 0, stream, b);
+        const size_t lds = (size_t)g.sel_lds_level;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_level_select, dim3(F * g.nlevels), dim3(64), lds, stream, b);
         ORBX_LAUNCH_CHECK();
     }
     if (stop_after == ST_LEVEL_SELECT) return ORBX_OK;
-    {
-        StageScope sc(timer, stream, ST_BLUR);
-        hipLaunchKernelGGL(k_blur, dim3(F * g.nbtiles_total), dim3(256), 0, stream, b);
-        ORBX_LAUNCH_CHECK();
-    }
+    if (overlap) {
+        if (hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) return ORBX_ERR_DEVICE;
+    } else if (launch_blur(stream) != ORBX_OK) return ORBX_ERR_DEVICE;
     if (stop_after == ST_BLUR) return ORBX_OK;
     {
         StageScope sc(timer, stream, ST_DESCRIBE);

@@ -58,7 +58,12 @@ def test_stage_parity_vga(gpu_extractor_factory, family):
     # blur (oracle: blur of the unblurred plane; the pipeline blurs every level)
     for l in range(nl):
         np.testing.assert_array_equal(ex.fetch_plane(capi.DBG_BLUR, l), orc.gaussian_blur7(o.level_plane(l, 0)), err_msg="blur level %d" % l)
-    # FAST score + cell-local NMS map at tmin = 7
+    # FAST score + cell-local NMS map at tmin = 7 (survivor lists are permuted by the later stages: stop after FAST)
+    ex.set_stop_after(capi.ST_FAST_NMS)
+    ex(img)
+    nms_planes = [ex.fetch_plane(capi.DBG_NMS, l) for l in range(nl)]
+    ex.set_stop_after(-1)
+    gk, gd = ex(img)
     for l in range(nl):
         plane = o.level_plane(l, 0)
         ref = np.zeros_like(plane)
@@ -68,7 +73,7 @@ def test_stage_parity_vga(gpu_extractor_factory, family):
             ix, iy, cw, ch = info[3], info[4], info[6], info[7]
             kp = orc.fast(plane[iy:iy + ch, ix:ix + cw], 7)
             ref[iy + kp["y"].astype(int), ix + kp["x"].astype(int)] = kp["response"].astype(np.uint8)
-        got = ex.fetch_plane(capi.DBG_NMS, l)
+        got = nms_planes[l]
         bad = np.argwhere(got != ref)
         assert bad.size == 0, "nms level %d: %d pixels differ, first %s gpu=%d ref=%d" % (
             l, len(bad), bad[0], got[tuple(bad[0])], ref[tuple(bad[0])])
