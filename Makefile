@@ -8,7 +8,7 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -ffp-contract=off -Wal
 ORBX_SRCS  := $(wildcard orb_slam_amd/csrc/*.hip)
 ORBX_HDRS  := $(wildcard orb_slam_amd/csrc/*.h orb_slam_amd/csrc/*.inc include/*.h)
 
-all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
+all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so orb_slam_amd/cpp/example_frame
 
 orb_slam_amd/liborbx.so: $(ORBX_SRCS) $(ORBX_HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared $(ORBX_SRCS) -o $@
@@ -20,7 +20,11 @@ orb_slam_amd/libsynthframes.so: orb_slam_amd/csrc/synth_frames.c
 oracle/liborb_oracle.so: oracle/orb_oracle.cpp oracle/orb_pattern_points.inc
 	$(CXX) -O3 -march=native -ffp-contract=off -std=c++17 -fPIC -shared $< -o $@
 
+# C++ shim demo: the reference's Frame-side call sequence against the drop-in classes (host C++, links the C ABI)
+orb_slam_amd/cpp/example_frame: orb_slam_amd/cpp/example_frame.cpp orb_slam_amd/cpp/ORBextractor.h orb_slam_amd/cpp/ORBmatcher.h orb_slam_amd/cpp/cvcompat.h include/orbx.h orb_slam_amd/liborbx.so
+	$(CXX) -O2 -std=c++14 -Iinclude -Iorb_slam_amd/cpp $< -o $@ -Lorb_slam_amd -lorbx -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
+
 clean:
-	rm -f orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
+	rm -f orb_slam_amd/cpp/example_frame orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
 
 .PHONY: all clean

@@ -1,0 +1,40 @@
+// What Frame::Frame does at the drop-in boundary (reference src/Frame.cc:56-65), against the shim classes.
+// usage: example_frame <w> <h> <raw 8-bit image file> <out file>   — writes N, keypoints (28 B each), descriptors
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+
+int main(int argc, char** argv) {
+    if (argc < 5) { std::fprintf(stderr, "usage: %s w h image.raw out.bin\n", argv[0]); return 2; }
+    const int w = std::atoi(argv[1]), h = std::atoi(argv[2]);
+    std::vector<unsigned char> buf((size_t)w * h);
+    FILE* f = std::fopen(argv[3], "rb");
+    if (!f || std::fread(buf.data(), 1, buf.size(), f) != buf.size()) { std::fprintf(stderr, "cannot read image\n"); return 2; }
+    std::fclose(f);
+    cv::Mat im(h, w, CV_8UC1, buf.data());
+
+    ORB_SLAM::ORBextractor* mpORBextractor = new ORB_SLAM::ORBextractor(1000, 1.2f, 8, ORB_SLAM::ORBextractor::FAST_SCORE, 20);
+    std::vector<cv::KeyPoint> mvKeys;
+    cv::Mat mDescriptors;
+    (*mpORBextractor)(im, cv::Mat(), mvKeys, mDescriptors);        // the reference call, verbatim
+    const int N = (int)mvKeys.size();
+
+    ORB_SLAM::ORBmatcher matcher(0.6, true);
+    std::vector<int> idx, best, second;
+    matcher.MatchTop2(mDescriptors, mDescriptors, idx, best, second);
+    int self = 0;
+    for (int i = 0; i < N; i++) self += (best[i] == 0);
+    const int d01 = N >= 2 ? ORB_SLAM::ORBmatcher::DescriptorDistance(mDescriptors.row(0), mDescriptors.row(1)) : -1;
+
+    FILE* o = std::fopen(argv[4], "wb");
+    std::fwrite(&N, 4, 1, o);
+    std::fwrite(mvKeys.data(), sizeof(cv::KeyPoint), N, o);
+    for (int i = 0; i < N; i++) std::fwrite(mDescriptors.ptr(i), 1, 32, o);
+    std::fclose(o);
+    std::printf("N=%d levels=%d scale=%.3f self_matches=%d d01=%d\n", N, mpORBextractor->GetLevels(), mpORBextractor->GetScaleFactor(), self, d01);
+    delete mpORBextractor;
+    return 0;
+}

@@ -168,3 +168,24 @@ def test_batch_device_api(gpu_extractor_factory):
         gk = kps[f, :n[f]].copy().view(capi.KP_DTYPE).reshape(-1)
         _assert_kps_equal(gk, ok)
         np.testing.assert_array_equal(desc[f, :n[f]], od)
+
+
+def test_cpp_shim_reference_call_sequence(tmp_path):
+    """the C++ drop-in classes (ORB_SLAM::ORBextractor / ORBmatcher over the C ABI), driven exactly like Frame.cc:60"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "orb_slam_amd", "cpp", "example_frame")
+    assert os.path.exists(exe), "run make"
+    img = synth.frame(640, 480, synth.BLOCKS, 21)
+    raw, out = tmp_path / "im.raw", tmp_path / "out.bin"
+    raw.write_bytes(img.tobytes())
+    res = subprocess.run([exe, "640", "480", str(raw), str(out)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    blob = out.read_bytes()
+    n = int(np.frombuffer(blob[:4], np.int32)[0])
+    k = np.frombuffer(blob[4:4 + 28 * n], capi.KP_DTYPE)
+    d = np.frombuffer(blob[4 + 28 * n:], np.uint8).reshape(n, 32)
+    ok, od = orc.OracleExtractor()(img)
+    _assert_kps_equal(k, ok)
+    np.testing.assert_array_equal(d, od)
+    assert "N=%d " % n in res.stdout and "levels=8" in res.stdout
