@@ -18,7 +18,6 @@ struct orbx_extractor {
     // geometry for the current image size
     int gw = 0, gh = 0;
     HostGeom hg;
-    DevGeom* d_g = nullptr;
     CellGeom* d_cells = nullptr;
     ResizeX* d_tabx = nullptr;
     ResizeY* d_taby = nullptr;
@@ -61,7 +60,7 @@ static void dev_free(T*& p) {
 }
 
 static void free_geometry(orbx_extractor* h) {
-    dev_free(h->d_g); dev_free(h->d_cells); dev_free(h->d_tabx); dev_free(h->d_taby);
+    dev_free(h->d_cells); dev_free(h->d_tabx); dev_free(h->d_taby);
     dev_free(h->d_flagx); dev_free(h->d_flagy);
     dev_free(h->d_pyr); dev_free(h->d_blur); dev_free(h->d_nms);
     dev_free(h->d_cand); dev_free(h->d_sel); dev_free(h->d_cstate); dev_free(h->d_csel);
@@ -88,8 +87,6 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
     h->hg = hg;
     const DevGeom& g = h->hg.g;
     const size_t B = (size_t)h->p.max_batch;
-    HIPCHK(h, hipMalloc(&h->d_g, sizeof(DevGeom)));
-    HIPCHK(h, hipMemcpy(h->d_g, &g, sizeof(DevGeom), hipMemcpyHostToDevice));
     if ((rc = upload(h, h->d_cells, h->hg.cells)) != ORBX_OK) return rc;
     if ((rc = upload(h, h->d_tabx, h->hg.tabx)) != ORBX_OK) return rc;
     if ((rc = upload(h, h->d_taby, h->hg.taby)) != ORBX_OK) return rc;
@@ -113,7 +110,7 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
 }
 
 static void fill_batch(orbx_extractor* h, Batch& b) {
-    b.g = h->d_g; b.cells = h->d_cells; b.tabx = h->d_tabx; b.taby = h->d_taby;
+    b.g = h->hg.g; b.cells = h->d_cells; b.tabx = h->d_tabx; b.taby = h->d_taby;
     b.flagx = h->d_flagx; b.flagy = h->d_flagy;
     b.pyr = h->d_pyr; b.blur = h->d_blur; b.nms = h->d_nms;
     b.cand = h->d_cand; b.sel = h->d_sel; b.cstate = h->d_cstate; b.csel = h->d_csel;

@@ -72,6 +72,10 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
             umax[v] = v0;
             ++v0;
         }
+        // the describe kernel carries this table as a packed constant
+        const unsigned long long nib = 0x3689ABCDDEEEFFFFull;
+        for (v = 0; v <= HALF_PATCH; ++v)
+            if (umax[v] != (int)((nib >> (4 * v)) & 15ull)) { err = "umax table mismatch"; return ORBX_ERR_ARG; }
     }
 
     // --- per-level geometry
@@ -213,13 +217,14 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
             const int cw = c.x1 - c.x0 + 1, ch = c.y1 - c.y0 + 1;
             if (cw <= 0 || ch <= 0) continue;
             max_px = std::max(max_px, cw * ch);
+            if (cw > 1000) { err = "grid cell wider than 1000 pixels"; return ORBX_ERR_GEOMETRY; }   // k_fast_cells: a round must span > 1 row
             const int nd = (3 + cw + 6 + 3) / 4;
             max_img = std::max(max_img, nd * 4 * (ch + 6));
         }
         if (max_px > 65535) { err = "grid cell larger than 65535 pixels"; return ORBX_ERR_GEOMETRY; }
         g.fast_max_px = align_up(std::max(max_px, 16), 16);
         g.fast_max_chunks = align_up((max_px + 63) / 64 + 1, 4);
-        g.fast_lds_bytes = 16 + g.fast_max_chunks * 12 + 1024 * 2 + g.fast_max_px + align_up(max_img, 16) + 16;
+        g.fast_lds_bytes = 528 /*sizeof(FastLds)*/ + g.fast_max_chunks * 12 + 3 * 1024 * 2 + g.fast_max_px + align_up(max_img, 16) + 16;
         if (g.fast_lds_bytes > 160 * 1024) { err = "grid cell does not fit the 160 KiB LDS"; return ORBX_ERR_GEOMETRY; }
     }
     {

@@ -73,9 +73,11 @@ struct DevGeom {
     LevelGeom lv[MAX_LEVELS];
 };
 
-// Pointers for one batch launch group; passed to kernels by value.
+// Arguments of one batch launch group; passed to kernels BY VALUE so that the geometry lives in the kernarg
+// segment: every LevelGeom field is then fetched with scalar loads (wave-uniform, no vector-memory round trip).
+// (A pointer to the same struct in global memory makes the compiler issue per-lane global loads for each field.)
 struct Batch {
-    const DevGeom* g;
+    DevGeom g;
     const CellGeom* cells;
     const ResizeX* tabx;
     const ResizeY* taby;

@@ -30,8 +30,12 @@ __device__ __forceinline__ const uint8_t* plain_plane(const Batch& b, const Leve
         return b.img + (long long)frame * b.img_frame_stride;
     }
     stride = L.stride;
-    return b.pyr + (long long)frame * b.g->frame_plane_bytes + L.plane_off;
+    return b.pyr + (long long)frame * b.g.frame_plane_bytes + L.plane_off;
 }
+
+// threadIdx.x >> 6 is wave-uniform but the compiler cannot know it: pin it in an SGPR so that everything derived
+// from it (task -> level -> LevelGeom fields) is fetched with scalar loads instead of per-lane vector loads.
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 template <typename T>
 __device__ __forceinline__ int find_level(const DevGeom& g, int idx, T base_of) {
@@ -40,29 +44,43 @@ __device__ __forceinline__ int find_level(const DevGeom& g, int idx, T base_of) 
     return level;
 }
 
+constexpr unsigned long long UMAX_NIBBLES = 0x3689ABCDDEEEFFFFull;   // umax[v] for v = 0..15 (15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3)
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+
 // ------------------------------------------------------------------------------------ pyramid
 // cv::resize INTER_LINEAR 8U, level-1 -> level.  A workgroup produces a 256x4 output tile: the source
 // rectangle it needs (<= 7 rows x ~310 px) is staged in LDS with coalesced dword loads, each lane then
 // reads its 16 taps as LDS bytes, produces 4 horizontally adjacent output pixels and stores one dword.
 // (Byte gathers straight from global memory made this kernel texture-addresser bound.)
-constexpr int RZ_ROWS = 4;
-constexpr int RZ_SRC_ROWS = 12;    // >= RZ_ROWS * max scale + 2 (scale_factor <= 2.5 is checked on the host)
+constexpr int RZ_ROWS = 16;        // output rows per workgroup (4 per wave): a tall tile amortises the table -> source -> LDS latency chain
+constexpr int RZ_SRC_ROWS = 44;    // >= RZ_ROWS * max scale + 2 (scale_factor <= 2.5 is checked on the host)
 constexpr int RZ_SRC_W = 704;      // >= 256 * max scale + 8, multiple of 4
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
     __shared__ __attribute__((aligned(16))) uint8_t s_src[RZ_SRC_ROWS * RZ_SRC_W];
-    const DevGeom& g = *b.g;
+    const DevGeom& g = b.g;
     const LevelGeom& L = g.lv[level];
     const LevelGeom& P = g.lv[level - 1];
     const int frame = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int bx0 = blockIdx.x * 256, by0 = blockIdx.y * RZ_ROWS;
     const int bx1 = min(bx0 + 255, L.w - 1), by1 = min(by0 + RZ_ROWS - 1, L.h - 1);
     long long sstride;
     const uint8_t* src = plain_plane(b, P, level - 1, frame, sstride);
     const ResizeX* tx = b.tabx + L.tabx_off;
     const ResizeY* ty = b.taby + L.taby_off;
+    // this lane's 4 output columns (independent of the staging below: issued first)
+    const int dx0 = bx0 + lane * 4;
+    ResizeX rx[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) rx[k] = tx[min(dx0 + k, L.w - 1)];
     // source rectangle of this tile (tables are monotone)
     const int r0 = ty[by0].sy0, r1 = ty[by1].sy1;
     const int c0 = tx[bx0].sx & ~3, c1 = tx[bx1].sx1;
@@ -81,24 +99,24 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
         }
     }
     __syncthreads();
-    const int dx0 = bx0 + lane * 4;
-    const int dy = by0 + wave;
-    if (dy >= L.h || dx0 >= L.w) return;
-    const ResizeY ry = ty[dy];
-    const uint8_t* q0 = s_src + (ry.sy0 - r0) * RZ_SRC_W - c0;
-    const uint8_t* q1 = s_src + (ry.sy1 - r0) * RZ_SRC_W - c0;
-    uint32_t packed = 0;
+    if (dx0 >= L.w) return;
+    uint8_t* dplane = b.pyr + (long long)frame * g.frame_plane_bytes + L.plane_off;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int dx = dx0 + k;
-        if (dx < L.w) {
-            const ResizeX rx = tx[dx];
-            const int px = resize_px(q0[rx.sx], q0[rx.sx1], q1[rx.sx], q1[rx.sx1], rx.a0, rx.a1, ry.b0, ry.b1);
+    for (int j = 0; j < RZ_ROWS / 4; j++) {
+        const int dy = by0 + wave + 4 * j;
+        if (dy >= L.h) break;
+        const ResizeY ry = ty[dy];
+        const uint8_t* q0 = s_src + (ry.sy0 - r0) * RZ_SRC_W - c0;
+        const uint8_t* q1 = s_src + (ry.sy1 - r0) * RZ_SRC_W - c0;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int px = resize_px(q0[rx[k].sx], q0[rx[k].sx1], q1[rx[k].sx], q1[rx[k].sx1], rx[k].a0, rx[k].a1, ry.b0, ry.b1);
             packed |= (uint32_t)(px & 255) << (8 * k);
         }
+        // columns past L.w (dx0+k clamped above) land in the row padding: stride is a multiple of 64
+        *reinterpret_cast<uint32_t*>(dplane + (long long)dy * L.stride + dx0) = packed;
     }
-    uint8_t* dst = b.pyr + (long long)frame * g.frame_plane_bytes + L.plane_off + (long long)dy * L.stride;
-    *reinterpret_cast<uint32_t*>(dst + dx0) = packed;   // stride is a multiple of 64: in-bounds and aligned
 }
 
 // ------------------------------------------------------------------------------------ FAST + NMS + cell lists
@@ -113,8 +131,13 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
 //   3. 3x3 strict NMS from the LDS score array, one 64-pixel raster chunk per wave step; the survivor
 //      ballots are kept, a wave-level scan turns their popcounts into list offsets, and the cell's keypoint
 //      list comes out in cv::FAST's raster order together with its counts at fastTh and at 7.
+constexpr int FAST_ROUND = 1024;      // pixels per round (4 per lane)
+constexpr int FAST_MAX_ROUNDS = 64;   // cells hold < 65536 pixels (checked on the host)
+
 struct FastLds {
-    int qn[2], n_hi, n_lo;   // qn: queue fill of the even / odd round (double-buffered so one barrier per phase suffices)
+    int n1[FAST_MAX_ROUNDS];   // per round: pixels that passed the compass test
+    int n2[FAST_MAX_ROUNDS];   // per round: pixels that passed the opposite-pair test (get an exact score)
+    int n_hi, n_lo, n_all, pad;
 };
 
 __device__ __forceinline__ int fast_pair_test(const uint8_t* c, int S, int v, int t) {
@@ -124,7 +147,7 @@ __device__ __forceinline__ int fast_pair_test(const uint8_t* c, int S, int v, in
     // a dark 9-arc contains one pixel of every opposite pair, so max_k min(pair) < v - t is necessary (bright: mirrored)
     const int a = imax3(imax3(imin(x0, x8), imin(x1, x9), imin(x2, x10)), imax3(imin(x3, x11), imin(x4, x12), imin(x5, x13)), imax(imin(x6, x14), imin(x7, x15)));
     const int bq = imin3(imin3(imax(x0, x8), imax(x1, x9), imax(x2, x10)), imin3(imax(x3, x11), imax(x4, x12), imax(x5, x13)), imin(imax(x6, x14), imax(x7, x15)));
-    return (v - a > t) | (bq - v > t);
+    return (int)(v - a > t) | (int)(bq - v > t);
 }
 
 __device__ __forceinline__ int fast_score_raw(const uint8_t* c, int S, int v, int tmin) {
@@ -147,26 +170,34 @@ __device__ __forceinline__ int fast_score_raw(const uint8_t* c, int S, int v, in
     return s >= tmin ? s : 0;
 }
 
-constexpr int FAST_ROUND = 1024;   // pixels per filter/score round (4 per lane)
-
-// p -> (p / cw, p % cw) for p < 65536, cw <= 4096 with full-rate VALU ops only (v_mul_lo/hi_u32 are
-// quarter rate): q = trunc((p + 0.5) * (1/cw)).  (p+0.5)/cw is at least 0.5/cw away from any integer, the
-// float product is off by < q * 2^-22 <= 2^-6 * ... far below that margin for every cell size the LDS holds.
+// p -> (p / cw, p % cw) for p < 65536, cw <= 2048 with full-rate VALU ops only (v_mul_lo/hi_u32 are quarter
+// rate): q = trunc((p + 0.5) * (1/cw)), exact for every (p, cw) in that range (exhaustively checked offline).
 __device__ __forceinline__ void split_px(int p, int cw, float inv_cw, int& y, int& x) {
     y = (int)(((float)p + 0.5f) * inv_cw);
     x = p - (int)__umul24((unsigned)y, (unsigned)cw);
 }
 
+// wave-aggregated append of the lanes with `pass` to an LDS queue; returns nothing, order inside the queue is irrelevant
+__device__ __forceinline__ void queue_push(uint16_t* q, int* counter, int pass, int value, int lane, unsigned long long lt) {
+    const unsigned long long m = __ballot(pass);
+    if (m) {
+        int qb = 0;
+        if (lane == 0) qb = atomicAdd(counter, __popcll(m));
+        qb = __shfl(qb, 0, 64);
+        if (pass) q[qb + __popcll(m & lt)] = (uint16_t)value;
+    }
+}
+
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const DevGeom& g = *b.g;
+    const DevGeom& g = b.g;
     const int frame = blockIdx.x / g.ncells_total;
     const int cell = blockIdx.x - frame * g.ncells_total;
     const int level = find_level(g, cell, [](const LevelGeom& l) { return l.cell_base; });
     const LevelGeom& L = g.lv[level];
     const CellGeom cg = b.cells[cell];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int cw = cg.x1 - cg.x0 + 1, ch = cg.y1 - cg.y0 + 1;
     CellState* cst = b.cstate + (long long)frame * g.ncells_total + cell;
     if (cw <= 0 || ch <= 0) {
@@ -175,12 +206,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
     }
     const int npx = cw * ch;
     const int nchunks = (npx + 63) >> 6;
-    // LDS carve (all offsets multiples of 16): header | chunk masks | chunk offsets | queue | scores | image
+    // LDS carve (all offsets multiples of 16): header | survivor bit masks | chunk offsets | queues | scores | image
     FastLds* hdr = reinterpret_cast<FastLds*>(smem);
-    unsigned long long* cmask = reinterpret_cast<unsigned long long*>(smem + 16);
-    int* coffs = reinterpret_cast<int*>(smem + 16 + g.fast_max_chunks * 8);
-    uint16_t* queue = reinterpret_cast<uint16_t*>(smem + 16 + g.fast_max_chunks * 12);
-    uint8_t* s_sc = smem + 16 + g.fast_max_chunks * 12 + FAST_ROUND * 2;
+    unsigned long long* cmask = reinterpret_cast<unsigned long long*>(smem + sizeof(FastLds));
+    int* coffs = reinterpret_cast<int*>(smem + sizeof(FastLds) + g.fast_max_chunks * 8);
+    uint16_t* q1 = reinterpret_cast<uint16_t*>(smem + sizeof(FastLds) + g.fast_max_chunks * 12);
+    uint16_t* q2 = q1 + FAST_ROUND;                 // two buffers: the NMS of round i-1 runs while round i is being scored
+    uint8_t* s_sc = reinterpret_cast<uint8_t*>(q2 + 2 * FAST_ROUND);
     uint8_t* s_img = s_sc + g.fast_max_px;
     // image region: rows y0-3..y1+3, columns from the dword-aligned start at or left of x0-3
     const int gxb = (cg.x0 - 3) & ~3;
@@ -202,106 +234,126 @@ __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
             *reinterpret_cast<uint32_t*>(s_img + r * S + 4 * d) = v4;
         }
     }
-    if (tid == 0) { hdr->qn[0] = 0; hdr->qn[1] = 0; hdr->n_hi = 0; hdr->n_lo = 0; }
+    for (int i = tid; i < (int)(sizeof(FastLds) / 4); i += 256) reinterpret_cast<int*>(hdr)[i] = 0;
+    for (int i = tid; i < nchunks; i += 256) cmask[i] = 0ull;
     __syncthreads();
 
     const float inv_cw = 1.0f / (float)cw;
     const int tmin = g.tmin;
     const uint8_t* img0 = s_img + 3 * S + xoff + 3;         // pixel (0,0) of the cell
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int base = 0, rnd = 0; base < npx; base += FAST_ROUND, rnd ^= 1) {
-        int pass[FAST_ROUND / 256];
-        unsigned long long pm[FAST_ROUND / 256];
-#pragma unroll
-        for (int k = 0; k < FAST_ROUND / 256; k++) {
-            const int p = base + k * 256 + tid;
-            pass[k] = 0;
-            const uint8_t* c = img0;
-            int v = 0, maybe = 0;
-            if (p < npx) {
+    int nhi = 0, nlo = 0;
+
+    // 3x3 strict NMS of the scored pixels of one finished round (dense over its queue); survivors set their bit
+    auto nms_round = [&](const uint16_t* q, int n) {
+        for (int i = tid; i < n; i += 256) {
+            const int p = q[i];
+            const int s = s_sc[p];
+            if (s) {
                 int y, x;
                 split_px(p, cw, inv_cw, y, x);
-                c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
-                v = c[0];
-                // a 9-arc covers at least 2 of the 4 compass pixels: one of them must be beyond the threshold
-                const int x0 = c[3 * S], x4 = c[3], x8 = c[-3 * S], x12 = c[-3];
-                maybe = (int)(v - imin(imin(x0, x4), imin(x8, x12)) > tmin) | (int)(imax(imax(x0, x4), imax(x8, x12)) - v > tmin);
-                s_sc[p] = 0;
+                const uint8_t* sp = s_sc + p;
+                const bool hasL = x > 0, hasR = x < cw - 1, hasU = y > 0, hasD = y < ch - 1;
+                int mx = 0;   // neighbours outside the cell count as 0 (cv::FAST on the cell view)
+                if (hasL) mx = imax(mx, sp[-1]);
+                if (hasR) mx = imax(mx, sp[1]);
+                if (hasU) {
+                    mx = imax(mx, sp[-cw]);
+                    if (hasL) mx = imax(mx, sp[-cw - 1]);
+                    if (hasR) mx = imax(mx, sp[-cw + 1]);
+                }
+                if (hasD) {
+                    mx = imax(mx, sp[cw]);
+                    if (hasL) mx = imax(mx, sp[cw - 1]);
+                    if (hasR) mx = imax(mx, sp[cw + 1]);
+                }
+                if (s > mx) {
+                    atomicOr(&cmask[p >> 6], 1ull << (p & 63));
+                    nhi += s >= g.fast_th;
+                    nlo += s >= 7;
+                }
             }
-            if (__any(maybe)) pass[k] = maybe ? fast_pair_test(c, S, v, tmin) : 0;   // wave-uniform skip over flat regions
-            pm[k] = __ballot(pass[k]);
         }
+    };
+
+    int rnd = 0;
+    for (int base = 0; base < npx; base += FAST_ROUND, rnd++) {
+        uint16_t* q2cur = q2 + (rnd & 1) * FAST_ROUND;
+        // A1: compass test on every pixel (a 9-arc covers >= 2 of the 4 compass pixels)
         {
+            int pass[FAST_ROUND / 256];
+            unsigned long long pm[FAST_ROUND / 256];
             int cnt = 0;
 #pragma unroll
-            for (int k = 0; k < FAST_ROUND / 256; k++) cnt += __popcll(pm[k]);
+            for (int k = 0; k < FAST_ROUND / 256; k++) {
+                const int p = base + k * 256 + tid;
+                pass[k] = 0;
+                if (p < npx) {
+                    int y, x;
+                    split_px(p, cw, inv_cw, y, x);
+                    const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
+                    const int v = c[0], x0 = c[3 * S], x4 = c[3], x8 = c[-3 * S], x12 = c[-3];
+                    pass[k] = (int)(v - imin(imin(x0, x4), imin(x8, x12)) > tmin) | (int)(imax(imax(x0, x4), imax(x8, x12)) - v > tmin);
+                    s_sc[p] = 0;
+                }
+                pm[k] = __ballot(pass[k]);
+                cnt += __popcll(pm[k]);
+            }
             if (cnt) {
                 int qb = 0;
-                if (lane == 0) qb = atomicAdd(&hdr->qn[rnd], cnt);
+                if (lane == 0) qb = atomicAdd(&hdr->n1[rnd], cnt);
                 qb = __shfl(qb, 0, 64);
 #pragma unroll
                 for (int k = 0; k < FAST_ROUND / 256; k++) {
-                    if (pass[k]) queue[qb + __popcll(pm[k] & lt)] = (uint16_t)(base + k * 256 + tid);
+                    if (pass[k]) q1[qb + __popcll(pm[k] & lt)] = (uint16_t)(base + k * 256 + tid);
                     qb += __popcll(pm[k]);
                 }
             }
         }
         __syncthreads();
-        const int qn = hdr->qn[rnd];
-        if (tid == 0) hdr->qn[rnd ^ 1] = 0;   // next round's counter; nobody touches it before the barrier below
-        for (int i = tid; i < qn; i += 256) {
-            const int p = queue[i];
-            int y, x;
-            split_px(p, cw, inv_cw, y, x);
-            const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
-            s_sc[p] = (uint8_t)fast_score_raw(c, S, c[0], tmin);
+        // A2: opposite-pair test, dense over the compass survivors
+        {
+            const int n1 = hdr->n1[rnd];
+            for (int i0 = 0; i0 < n1; i0 += 256) {
+                const int i = i0 + tid;
+                int pass = 0, p = 0;
+                if (i < n1) {
+                    p = q1[i];
+                    int y, x;
+                    split_px(p, cw, inv_cw, y, x);
+                    const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
+                    pass = fast_pair_test(c, S, c[0], tmin);
+                }
+                queue_push(q2cur, &hdr->n2[rnd], pass, p, lane, lt);
+            }
         }
         __syncthreads();
-    }
-
-    // NMS per 64-pixel raster chunk; neighbours outside the cell count as 0
-    int nhi = 0, nlo = 0;
-    for (int ci = wave; ci < nchunks; ci += 4) {
-        const int p = ci * 64 + lane;
-        int s = 0, keep = 0;
-        if (p < npx) s = s_sc[p];
-        if (!__any(s)) {   // no corner in this chunk
-            if (lane == 0) { cmask[ci] = 0ull; coffs[ci] = 0; }
-            continue;
-        }
-        if (s) {
-            int y, x;
-            split_px(p, cw, inv_cw, y, x);
-            const uint8_t* q = s_sc + p;
-            const bool hasL = x > 0, hasR = x < cw - 1, hasU = y > 0, hasD = y < ch - 1;
-            int mx = 0;
-            if (hasL) mx = imax(mx, q[-1]);
-            if (hasR) mx = imax(mx, q[1]);
-            if (hasU) {
-                mx = imax(mx, q[-cw]);
-                if (hasL) mx = imax(mx, q[-cw - 1]);
-                if (hasR) mx = imax(mx, q[-cw + 1]);
+        // B: exact FAST score, dense over the pair-test survivors
+        {
+            const int n2 = hdr->n2[rnd];
+            for (int i = tid; i < n2; i += 256) {
+                const int p = q2cur[i];
+                int y, x;
+                split_px(p, cw, inv_cw, y, x);
+                const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
+                s_sc[p] = (uint8_t)fast_score_raw(c, S, c[0], tmin);
             }
-            if (hasD) {
-                mx = imax(mx, q[cw]);
-                if (hasL) mx = imax(mx, q[cw - 1]);
-                if (hasR) mx = imax(mx, q[cw + 1]);
-            }
-            keep = s > mx;
         }
-        const unsigned long long m = __ballot(keep);
-        nhi += __popcll(__ballot(keep && s >= g.fast_th));
-        nlo += __popcll(__ballot(keep && s >= 7));
-        if (lane == 0) { cmask[ci] = m; coffs[ci] = __popcll(m); }
+        __syncthreads();
+        // N: every neighbour of the previous round's pixels is scored now
+        if (rnd > 0) nms_round(q2 + ((rnd - 1) & 1) * FAST_ROUND, hdr->n2[rnd - 1]);
     }
+    nms_round(q2 + ((rnd - 1) & 1) * FAST_ROUND, hdr->n2[rnd - 1]);
+    nhi = wave_sum(nhi);
+    nlo = wave_sum(nlo);
     if (lane == 0) { atomicAdd(&hdr->n_hi, nhi); atomicAdd(&hdr->n_lo, nlo); }
     __syncthreads();
-    // exclusive scan of the chunk counts (wave 0): lane-local run, wave scan, lane-local fix-up
+    // exclusive scan of the per-chunk survivor counts (wave 0): lane-local run, wave scan, lane-local fix-up
     if (wave == 0) {
         const int per = (nchunks + 63) >> 6;
         const int c0 = lane * per, c1 = imin(c0 + per, nchunks);
         int sum = 0;
-        for (int ci = c0; ci < c1; ci++) sum += coffs[ci];
+        for (int ci = c0; ci < c1; ci++) sum += __popcll(cmask[ci]);
         int incl = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -309,10 +361,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
             if (lane >= off) incl += t;
         }
         int run = incl - sum;
-        for (int ci = c0; ci < c1; ci++) { const int cnt = coffs[ci]; coffs[ci] = run; run += cnt; }
-        if (lane == 63) hdr->qn[0] = incl;   // total survivors (the round counters are free now)
+        for (int ci = c0; ci < c1; ci++) { coffs[ci] = run; run += __popcll(cmask[ci]); }
+        if (lane == 63) hdr->n_all = incl;
     }
     __syncthreads();
+    // the cell's keypoint list in raster order (cv::FAST's order)
     Cand* out = b.cand + (long long)frame * g.frame_cands + L.cand_base + cg.cand_off;
     for (int ci = wave; ci < nchunks; ci += 4) {
         const unsigned long long m = cmask[ci];
@@ -328,7 +381,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
     }
     if (tid == 0) {
         CellState st;
-        st.n_all = hdr->qn[0]; st.n_hi = hdr->n_hi; st.n_lo = hdr->n_lo;
+        st.n_all = hdr->n_all; st.n_hi = hdr->n_hi; st.n_lo = hdr->n_lo;
         *cst = st;
     }
 }
@@ -336,7 +389,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
 // ------------------------------------------------------------------------------------ quotas
 // reference :609-670, one lane per (frame, level); sequential by definition.
 __global__ __launch_bounds__(64) void k_quota(Batch b) {
-    const DevGeom& g = *b.g;
+    const DevGeom& g = b.g;
     const int idx = blockIdx.x * 64 + threadIdx.x;
     if (idx >= b.nframes * g.nlevels) return;
     const int frame = idx / g.nlevels, level = idx - frame * g.nlevels;
@@ -415,7 +468,7 @@ __device__ float harris_response(const uint8_t* img, long long step, int x, int 
 __global__ __launch_bounds__(64) void k_cell_select(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Cand* lst = reinterpret_cast<Cand*>(smem);
-    const DevGeom& g = *b.g;
+    const DevGeom& g = b.g;
     const int frame = blockIdx.x / g.ncells_total, cell = blockIdx.x - frame * g.ncells_total;
     const int level = find_level(g, cell, [](const LevelGeom& l) { return l.cell_base; });
     const LevelGeom& L = g.lv[level];
@@ -456,7 +509,7 @@ __global__ __launch_bounds__(64) void k_cell_select(Batch b) {
 __global__ __launch_bounds__(64) void k_level_select(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Cand* lst = reinterpret_cast<Cand*>(smem);
-    const DevGeom& g = *b.g;
+    const DevGeom& g = b.g;
     const int frame = blockIdx.x / g.nlevels, level = blockIdx.x - frame * g.nlevels;
     const LevelGeom& L = g.lv[level];
     const int lane = threadIdx.x;
@@ -497,8 +550,8 @@ __device__ __forceinline__ uint32_t load_px4_reflect(const uint8_t* row, int x, 
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_blur(Batch b) {
-    const DevGeom& g = *b.g;
-    const int task_all = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const DevGeom& g = b.g;
+    const int task_all = blockIdx.x * 4 + wave_id();
     const int frame = task_all / g.nbtiles_total;
     if (frame >= b.nframes) return;
     const int t = task_all - frame * g.nbtiles_total;
@@ -558,16 +611,10 @@ __global__ __launch_bounds__(256) void k_blur(Batch b) {
 // One wave per output keypoint.  IC_Angle: 2 patch rows per step, lanes over u; wave reduction of the
 // integer moments.  Descriptor: lane i evaluates tests i, i+64, i+128, i+192; each __ballot is 8
 // descriptor bytes (test t is bit t%8 of byte t/8, LSB first — the reference's packing).
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 __global__ __launch_bounds__(256) void k_describe(Batch b) {
-    const DevGeom& g = *b.g;
+    const DevGeom& g = b.g;
     const int frame = blockIdx.y;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slot = blockIdx.x * 4 + wave_id();
     const int lane = threadIdx.x & 63;
     const int32_t* counts = b.level_count + frame * MAX_LEVELS;
     if (slot == 0 && lane == 0) {
@@ -589,10 +636,17 @@ __global__ __launch_bounds__(256) void k_describe(Batch b) {
 
     const Cand kp = b.sel[(long long)frame * g.frame_sel + L.sel_base + k];
     const int x = kp.pos & 0xFFFF, y = kp.pos >> 16;
-    long long pstride;
-    const uint8_t* plain = plain_plane(b, L, level, frame, pstride);
+    long long pstride64;
+    const uint8_t* plain = plain_plane(b, L, level, frame, pstride64);
+    const unsigned pstride = (unsigned)pstride64;   // rows < 2^24 bytes, planes < 2^31 bytes (host-checked): 24-bit multiplies
 
-    // IC_Angle on the unblurred level (:705-706 run before the blur)
+    // the 4 BRIEF tests of this lane (independent of everything below: issue the loads now)
+    uint32_t pat[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) pat[r] = c_pattern[r * 64 + lane];
+
+    // IC_Angle on the unblurred level (:705-706 run before the blur).  umax[] (reference :495-510) depends only on
+    // HALF_PATCH_SIZE = 15, so it is a constant: nibble v of UMAX_NIBBLES (the host checks it against the computed table).
     int m10 = 0, m01 = 0;
     {
         const int u = (lane & 31) - HALF_PATCH;
@@ -602,8 +656,9 @@ __global__ __launch_bounds__(256) void k_describe(Batch b) {
             const int r = it * 2 + (lane >> 5);
             const int v = r - HALF_PATCH;
             const int av = v < 0 ? -v : v;
-            if (r <= 2 * HALF_PATCH && au <= HALF_PATCH && au <= g.umax[av]) {
-                const int I = plain[(long long)(y + v) * pstride + x + u];
+            const int um = (int)((UMAX_NIBBLES >> (4 * (av & 15))) & 15ull);
+            if (r <= 2 * HALF_PATCH && au <= um) {
+                const int I = plain[__umul24((unsigned)(y + v), pstride) + (unsigned)(x + u)];
                 m10 += u * I;
                 m01 += v * I;
             }
@@ -621,19 +676,23 @@ __global__ __launch_bounds__(256) void k_describe(Batch b) {
     unsigned long long words[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const uint32_t pat = c_pattern[r * 64 + lane];
         int val[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-            const float px = (float)(int)(int8_t)(pat >> (16 * e));
-            const float py = (float)(int)(int8_t)(pat >> (16 * e + 8));
+            const float px = (float)(int)(int8_t)(pat[r] >> (16 * e));
+            const float py = (float)(int)(int8_t)(pat[r] >> (16 * e + 8));
             const int iy = cv_round_f(px * sn + py * cs);
             const int ix = cv_round_f(px * cs - py * sn);
-            const int X = x + ix, Y = y + iy;
-            if ((unsigned)X < (unsigned)L.w && (unsigned)Y < (unsigned)L.h)
-                val[e] = blur[(long long)Y * L.stride + X];
-            else   // the reference reads the level's unblurred reflect-101 border here
-                val[e] = plain[(long long)reflect101(Y, L.h) * pstride + reflect101(X, L.w)];
+            int X = x + ix, Y = y + iy;
+            // inside the level: blurred pixel.  Outside (<= 2 px, only for keypoints 16..17 px from the edge): the
+            // reference reads the level's UNBLURRED reflect-101 border; |offset| <= 18 < size, so one
+            // reflection suffices.
+            const bool inside = (unsigned)X < (unsigned)L.w && (unsigned)Y < (unsigned)L.h;
+            X = X < 0 ? -X : (X >= L.w ? 2 * L.w - 2 - X : X);
+            Y = Y < 0 ? -Y : (Y >= L.h ? 2 * L.h - 2 - Y : Y);
+            const uint8_t* base = inside ? blur : plain;
+            const unsigned st = inside ? (unsigned)L.stride : pstride;
+            val[e] = base[__umul24((unsigned)Y, st) + (unsigned)X];
         }
         words[r] = __ballot(val[0] < val[1]);
     }
