@@ -22,35 +22,59 @@ namespace orbx {
 
 constexpr int KEY_SHIFT = 22;                       // index bits; distance (<=256) sits above
 constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
-constexpr int QPL = 2;                              // queries per lane
 constexpr int MATCH_BLOCK = 256;
-constexpr int Q_PER_BLOCK = MATCH_BLOCK * QPL;
 
+// k1 <= k2 are the two smallest keys so far: the new second-smallest is the median of (k1, k2, key)
 __device__ __forceinline__ void top2_update(uint32_t& k1, uint32_t& k2, uint32_t key) {
-    k2 = min(k2, max(k1, key));
+    uint32_t m;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(k1), "v"(k2), "v"(key));
+    k2 = m;
     k1 = min(k1, key);
 }
 
+// popcount(x) + acc in ONE VALU op (v_bcnt_u32_b32 accumulates); the compiler otherwise builds an add tree
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 // Scan train descriptors [t0, t1) for the block's queries.  T must be wave-uniform readable.
-template <bool GUARD>
+template <int QPL>
 __device__ __forceinline__ void scan_range(const uint32_t* __restrict__ T, int t0, int t1, const uint32_t (&q)[QPL][8],
                                            uint32_t (&k1)[QPL], uint32_t (&k2)[QPL]) {
-#pragma unroll 4
-    for (int t = t0; t < t1; t++) {
-        const uint32_t* tp = T + (long long)t * 8;
-        uint32_t tw[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) tw[i] = tp[i];   // uniform address -> s_load
+    auto one = [&](const uint32_t (&tw)[8], int t) {
 #pragma unroll
         for (int j = 0; j < QPL; j++) {
             uint32_t d = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) d += __popc(q[j][i] ^ tw[i]);
+            for (int i = 0; i < 8; i++) d = bcnt_acc(q[j][i] ^ tw[i], d);
             top2_update(k1[j], k2[j], (d << KEY_SHIFT) | (uint32_t)t);
         }
+    };
+    int t = t0;
+    // 4 train descriptors per trip: their scalar loads are issued together, so the s_load latency is paid once per 4
+    for (; t + 4 <= t1; t += 4) {
+        uint32_t tw[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t* tp = T + (long long)(t + u) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) tw[u][i] = tp[i];   // uniform address -> s_load_dwordx8
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) one(tw[u], t + u);
+    }
+    for (; t < t1; t++) {
+        const uint32_t* tp = T + (long long)t * 8;
+        uint32_t tw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) tw[i] = tp[i];
+        one(tw, t);
     }
 }
 
+template <int QPL>
 __device__ __forceinline__ void load_queries(const uint32_t* __restrict__ Q, int nq, int qbase, uint32_t (&q)[QPL][8]) {
 #pragma unroll
     for (int j = 0; j < QPL; j++) {
@@ -74,15 +98,16 @@ __device__ __forceinline__ void write_result(uint32_t k1, uint32_t k2, int32_t* 
 }
 
 // Large single problem: grid = (query blocks, train splits); partial (k1,k2) per (split, query).
+template <int QPL>
 __global__ __launch_bounds__(MATCH_BLOCK) void k_match_split(const uint32_t* __restrict__ Q, int nq, const uint32_t* __restrict__ T, int nt,
                                                              int chunk, uint32_t* __restrict__ pk1, uint32_t* __restrict__ pk2) {
-    const int qbase = blockIdx.x * Q_PER_BLOCK + threadIdx.x;
+    const int qbase = blockIdx.x * (MATCH_BLOCK * QPL) + threadIdx.x;
     const int t0 = blockIdx.y * chunk, t1 = min(nt, t0 + chunk);
     uint32_t q[QPL][8], k1[QPL], k2[QPL];
-    load_queries(Q, nq, qbase, q);
+    load_queries<QPL>(Q, nq, qbase, q);
 #pragma unroll
     for (int j = 0; j < QPL; j++) { k1[j] = KEY_NONE; k2[j] = KEY_NONE; }
-    scan_range<false>(T, t0, t1, q, k1, k2);
+    scan_range<QPL>(T, t0, t1, q, k1, k2);
 #pragma unroll
     for (int j = 0; j < QPL; j++) {
         const int qi = qbase + j * MATCH_BLOCK;
@@ -106,20 +131,21 @@ __global__ __launch_bounds__(256) void k_match_merge(const uint32_t* __restrict_
 }
 
 // Many small problems (frame-to-frame matching): blockIdx.y = problem, sizes read on the device.
+template <int QPL>
 __global__ __launch_bounds__(MATCH_BLOCK) void k_match_batch(const uint32_t* __restrict__ Q, const int32_t* __restrict__ nqs,
                                                              const uint32_t* __restrict__ T, const int32_t* __restrict__ nts, int cap,
                                                              int32_t* __restrict__ idx, int32_t* __restrict__ best, int32_t* __restrict__ second) {
     const int prob = blockIdx.y;
     const int nq = min(nqs[prob], cap), nt = min(nts[prob], cap);
-    const int qbase = blockIdx.x * Q_PER_BLOCK + threadIdx.x;
-    if (blockIdx.x * Q_PER_BLOCK >= nq) return;
+    const int qbase = blockIdx.x * (MATCH_BLOCK * QPL) + threadIdx.x;
+    if (blockIdx.x * (MATCH_BLOCK * QPL) >= nq) return;
     const uint32_t* Qp = Q + (long long)prob * cap * 8;
     const uint32_t* Tp = T + (long long)prob * cap * 8;
     uint32_t q[QPL][8], k1[QPL], k2[QPL];
-    load_queries(Qp, nq, qbase, q);
+    load_queries<QPL>(Qp, nq, qbase, q);
 #pragma unroll
     for (int j = 0; j < QPL; j++) { k1[j] = KEY_NONE; k2[j] = KEY_NONE; }
-    scan_range<false>(Tp, 0, nt, q, k1, k2);
+    scan_range<QPL>(Tp, 0, nt, q, k1, k2);
 #pragma unroll
     for (int j = 0; j < QPL; j++) {
         const int qi = qbase + j * MATCH_BLOCK;
@@ -175,6 +201,7 @@ int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
     if (nq < 0 || nt < 0 || nt >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
     if (nq == 0) return ORBX_OK;
     if (((uintptr_t)dQ & 15) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
+    constexpr int QPL = 2, Q_PER_BLOCK = MATCH_BLOCK * QPL;   // big problems: 2 queries per lane halve the scalar T traffic
     const int qblocks = (nq + Q_PER_BLOCK - 1) / Q_PER_BLOCK;
     // enough workgroups to fill 256 CUs several times over, but chunks of >= 256 train descriptors
     int nsplit = std::max(1, std::min((nt + 255) / 256, (4096 + qblocks - 1) / qblocks));
@@ -184,7 +211,7 @@ int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
     if (ensure_scratch(need) != ORBX_OK) return ORBX_ERR_DEVICE;
     uint32_t* pk1 = t_scratch.buf;
     uint32_t* pk2 = pk1 + (size_t)nsplit * nq;
-    hipLaunchKernelGGL(k_match_split, dim3(qblocks, nsplit), dim3(MATCH_BLOCK), 0, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt,
+    hipLaunchKernelGGL(k_match_split<QPL>, dim3(qblocks, nsplit), dim3(MATCH_BLOCK), 0, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt,
                        chunk, pk1, pk2);
     if (hipGetLastError() != hipSuccess) return ORBX_ERR_DEVICE;
     hipLaunchKernelGGL(k_match_merge, dim3((nq + 255) / 256), dim3(256), 0, stream, pk1, pk2, nq, nsplit, d_best_idx, d_best, d_second);
@@ -198,7 +225,8 @@ int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const u
     if (nbatch < 0 || cap < 1 || cap >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
     if (nbatch == 0) return ORBX_OK;
     if (((uintptr_t)dQ & 15) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
-    hipLaunchKernelGGL(k_match_batch, dim3((cap + Q_PER_BLOCK - 1) / Q_PER_BLOCK, nbatch), dim3(MATCH_BLOCK), 0, stream, (const uint32_t*)dQ,
+    // frame-sized problems (~1000 x 1000): 1 query per lane so that a batch of 256 still fills the chip (4 waves per SIMD)
+    hipLaunchKernelGGL(k_match_batch<1>, dim3((cap + MATCH_BLOCK - 1) / MATCH_BLOCK, nbatch), dim3(MATCH_BLOCK), 0, stream, (const uint32_t*)dQ,
                        d_nq, (const uint32_t*)dT, d_nt, cap, d_best_idx, d_best, d_second);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }

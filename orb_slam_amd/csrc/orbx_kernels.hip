@@ -131,8 +131,10 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
 //   3. 3x3 strict NMS from the LDS score array, one 64-pixel raster chunk per wave step; the survivor
 //      ballots are kept, a wave-level scan turns their popcounts into list offsets, and the cell's keypoint
 //      list comes out in cv::FAST's raster order together with its counts at fastTh and at 7.
-constexpr int FAST_ROUND = 1024;      // pixels per round (4 per lane)
-constexpr int FAST_MAX_ROUNDS = 64;   // cells hold < 65536 pixels (checked on the host)
+constexpr int FAST_THREADS = 512;     // 8 waves per cell: more work between barriers, full CU occupancy at ~35 KB LDS per cell
+constexpr int FAST_PPT = 4;           // pixels per lane per round
+constexpr int FAST_ROUND = FAST_THREADS * FAST_PPT;   // pixels per round
+constexpr int FAST_MAX_ROUNDS = 32;   // cells hold < 65536 pixels (checked on the host)
 
 struct FastLds {
     int n1[FAST_MAX_ROUNDS];   // per round: pixels that passed the compass test
@@ -189,7 +191,7 @@ __device__ __forceinline__ void queue_push(uint16_t* q, int* counter, int pass, 
 }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
+__global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const DevGeom& g = b.g;
     const int frame = blockIdx.x / g.ncells_total;
@@ -221,21 +223,36 @@ __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
     const int S = nd * 4;
     long long stride;
     const uint8_t* src = plain_plane(b, L, level, frame, stride);
-    for (int r = wave; r < ch + 6; r += 4) {
-        const uint8_t* row = src + (long long)(cg.y0 - 3 + r) * stride + gxb;
-        for (int d = lane; d < nd; d += 64) {
-            uint32_t v4;
-            if (ALIGNED) v4 = *reinterpret_cast<const uint32_t*>(row + 4 * d);
-            else {
-                const int xm = L.w - 1 - gxb;   // never read past the row end on the unaligned path
-                v4 = (uint32_t)row[imin(4 * d, xm)] | (uint32_t)row[imin(4 * d + 1, xm)] << 8 | (uint32_t)row[imin(4 * d + 2, xm)] << 16 |
-                     (uint32_t)row[imin(4 * d + 3, xm)] << 24;
+    {
+        const int total = (ch + 6) * nd;
+        const float inv_nd = 1.0f / (float)nd;
+        const uint8_t* src0 = src + (long long)(cg.y0 - 3) * stride + gxb;
+        const int xm = L.w - 1 - gxb;   // unaligned path: never read past the row end
+        for (int i0 = 0; i0 < total; i0 += FAST_THREADS * 8) {
+            uint32_t v4[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {   // 8 independent loads in flight per lane
+                const int i = i0 + k * FAST_THREADS + tid;
+                v4[k] = 0;
+                if (i < total) {
+                    int r, d;
+                    split_px(i, nd, inv_nd, r, d);
+                    const uint8_t* row = src0 + (long long)r * stride;
+                    if (ALIGNED) v4[k] = *reinterpret_cast<const uint32_t*>(row + 4 * d);
+                    else v4[k] = (uint32_t)row[imin(4 * d, xm)] | (uint32_t)row[imin(4 * d + 1, xm)] << 8 | (uint32_t)row[imin(4 * d + 2, xm)] << 16 |
+                                 (uint32_t)row[imin(4 * d + 3, xm)] << 24;
+                }
             }
-            *reinterpret_cast<uint32_t*>(s_img + r * S + 4 * d) = v4;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + k * FAST_THREADS + tid;
+                if (i < total) reinterpret_cast<uint32_t*>(s_img)[i] = v4[k];   // row r, dword d  ==  r*nd + d  (S = 4*nd)
+            }
         }
     }
-    for (int i = tid; i < (int)(sizeof(FastLds) / 4); i += 256) reinterpret_cast<int*>(hdr)[i] = 0;
-    for (int i = tid; i < nchunks; i += 256) cmask[i] = 0ull;
+    for (int i = tid; i < (g.fast_max_px >> 4); i += FAST_THREADS) reinterpret_cast<uint4*>(s_sc)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < (int)(sizeof(FastLds) / 4); i += FAST_THREADS) reinterpret_cast<int*>(hdr)[i] = 0;
+    for (int i = tid; i < nchunks; i += FAST_THREADS) cmask[i] = 0ull;
     __syncthreads();
 
     const float inv_cw = 1.0f / (float)cw;
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
 
     // 3x3 strict NMS of the scored pixels of one finished round (dense over its queue); survivors set their bit
     auto nms_round = [&](const uint16_t* q, int n) {
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += FAST_THREADS) {
             const int p = q[i];
             const int s = s_sc[p];
             if (s) {
@@ -281,12 +298,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
         uint16_t* q2cur = q2 + (rnd & 1) * FAST_ROUND;
         // A1: compass test on every pixel (a 9-arc covers >= 2 of the 4 compass pixels)
         {
-            int pass[FAST_ROUND / 256];
-            unsigned long long pm[FAST_ROUND / 256];
+            int pass[FAST_PPT];
+            unsigned long long pm[FAST_PPT];
             int cnt = 0;
 #pragma unroll
-            for (int k = 0; k < FAST_ROUND / 256; k++) {
-                const int p = base + k * 256 + tid;
+            for (int k = 0; k < FAST_PPT; k++) {
+                const int p = base + k * FAST_THREADS + tid;
                 pass[k] = 0;
                 if (p < npx) {
                     int y, x;
@@ -294,7 +311,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
                     const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
                     const int v = c[0], x0 = c[3 * S], x4 = c[3], x8 = c[-3 * S], x12 = c[-3];
                     pass[k] = (int)(v - imin(imin(x0, x4), imin(x8, x12)) > tmin) | (int)(imax(imax(x0, x4), imax(x8, x12)) - v > tmin);
-                    s_sc[p] = 0;
                 }
                 pm[k] = __ballot(pass[k]);
                 cnt += __popcll(pm[k]);
@@ -304,17 +320,18 @@ __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
                 if (lane == 0) qb = atomicAdd(&hdr->n1[rnd], cnt);
                 qb = __shfl(qb, 0, 64);
 #pragma unroll
-                for (int k = 0; k < FAST_ROUND / 256; k++) {
-                    if (pass[k]) q1[qb + __popcll(pm[k] & lt)] = (uint16_t)(base + k * 256 + tid);
+                for (int k = 0; k < FAST_PPT; k++) {
+                    if (pass[k]) q1[qb + __popcll(pm[k] & lt)] = (uint16_t)(base + k * FAST_THREADS + tid);
                     qb += __popcll(pm[k]);
                 }
             }
         }
         __syncthreads();
-        // A2: opposite-pair test, dense over the compass survivors
-        {
-            const int n1 = hdr->n1[rnd];
-            for (int i0 = 0; i0 < n1; i0 += 256) {
+        // A2: opposite-pair test, dense over the compass survivors.  n1 / n2 are block-uniform after the barriers, so
+        // rounds without candidates (flat image regions) skip the remaining phases and their barriers altogether.
+        const int n1 = hdr->n1[rnd];
+        if (n1 > 0) {
+            for (int i0 = 0; i0 < n1; i0 += FAST_THREADS) {
                 const int i = i0 + tid;
                 int pass = 0, p = 0;
                 if (i < n1) {
@@ -326,20 +343,20 @@ __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
                 }
                 queue_push(q2cur, &hdr->n2[rnd], pass, p, lane, lt);
             }
-        }
-        __syncthreads();
-        // B: exact FAST score, dense over the pair-test survivors
-        {
+            __syncthreads();
+            // B: exact FAST score, dense over the pair-test survivors
             const int n2 = hdr->n2[rnd];
-            for (int i = tid; i < n2; i += 256) {
-                const int p = q2cur[i];
-                int y, x;
-                split_px(p, cw, inv_cw, y, x);
-                const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
-                s_sc[p] = (uint8_t)fast_score_raw(c, S, c[0], tmin);
+            if (n2 > 0) {
+                for (int i = tid; i < n2; i += FAST_THREADS) {
+                    const int p = q2cur[i];
+                    int y, x;
+                    split_px(p, cw, inv_cw, y, x);
+                    const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
+                    s_sc[p] = (uint8_t)fast_score_raw(c, S, c[0], tmin);
+                }
+                __syncthreads();
             }
         }
-        __syncthreads();
         // N: every neighbour of the previous round's pixels is scored now
         if (rnd > 0) nms_round(q2 + ((rnd - 1) & 1) * FAST_ROUND, hdr->n2[rnd - 1]);
     }
@@ -367,7 +384,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Batch b) {
     __syncthreads();
     // the cell's keypoint list in raster order (cv::FAST's order)
     Cand* out = b.cand + (long long)frame * g.frame_cands + L.cand_base + cg.cand_off;
-    for (int ci = wave; ci < nchunks; ci += 4) {
+    for (int ci = wave; ci < nchunks; ci += FAST_THREADS / 64) {
         const unsigned long long m = cmask[ci];
         if ((m >> lane) & 1ull) {
             const int p = ci * 64 + lane;
@@ -772,8 +789,8 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
-        if (aligned) hipLaunchKernelGGL(k_fast_cells<true>, dim3(F * g.ncells_total), dim3(256), lds, stream, b);
-        else hipLaunchKernelGGL(k_fast_cells<false>, dim3(F * g.ncells_total), dim3(256), lds, stream, b);
+        if (aligned) hipLaunchKernelGGL(k_fast_cells<true>, dim3(F * g.ncells_total), dim3(FAST_THREADS), lds, stream, b);
+        else hipLaunchKernelGGL(k_fast_cells<false>, dim3(F * g.ncells_total), dim3(FAST_THREADS), lds, stream, b);
         ORBX_LAUNCH_CHECK();
     }
     if (stop_after == ST_FAST_NMS) return ORBX_OK;
