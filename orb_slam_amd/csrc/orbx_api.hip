@@ -140,11 +140,10 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
     if (hipSetDevice(p->device) != hipSuccess) return ORBX_ERR_DEVICE;
     orbx_extractor* h = new orbx_extractor();
     h->p = *p;
-    // The blur can run on a side stream next to the FAST/selection chain (ORBX_OVERLAP=1).  Measured on MI355X
-    // it does not pay at batch 256 (both kernels are VALU-bound), so the default is one stream, which also keeps
-    // per-kernel timings (HIP events, rocprofv3) free of cross-kernel contention.
+    // The blur runs on a side stream next to the latency-bound selection kernels (see launch_extract);
+    // ORBX_OVERLAP=0 keeps everything on one stream (cleaner per-kernel timings when profiling).
     const char* ovl = getenv("ORBX_OVERLAP");
-    if (!(ovl && ovl[0] == '1')) { *out = h; return ORBX_OK; }
+    if (ovl && ovl[0] == '0') { *out = h; return ORBX_OK; }
     if (hipStreamCreateWithFlags(&h->side.aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->side.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->side.join, hipEventDisableTiming) != hipSuccess) {

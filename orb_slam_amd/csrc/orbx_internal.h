@@ -129,8 +129,8 @@ struct StageTimer {
 };
 
 // Launch the whole per-batch kernel sequence on `stream`; stop_after < 0 runs everything.
-// Optional side stream: the blur depends only on the pyramid, so it runs on `aux` concurrently with the
-// FAST -> cell lists -> quotas -> retainBest chain (whose tail kernels are latency-bound and leave the chip idle).
+// Side stream: the blur depends only on the pyramid.  It is forked after the (VALU-bound) FAST kernel so that it
+// runs concurrently with the quota / retainBest kernels, which are latency-bound and leave the chip mostly idle.
 struct SideStream {
     hipStream_t aux = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;

@@ -776,11 +776,6 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         return ORBX_OK;
     };
     const bool overlap = side && side->aux && stop_after < 0;
-    if (overlap) {
-        if (hipEventRecord(side->fork, stream) != hipSuccess || hipStreamWaitEvent(side->aux, side->fork, 0) != hipSuccess) return ORBX_ERR_DEVICE;
-        if (launch_blur(side->aux) != ORBX_OK) return ORBX_ERR_DEVICE;
-        if (hipEventRecord(side->join, side->aux) != hipSuccess) return ORBX_ERR_DEVICE;
-    }
     {
         StageScope sc(timer, stream, ST_FAST_NMS);
         const bool aligned = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
@@ -794,6 +789,12 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         ORBX_LAUNCH_CHECK();
     }
     if (stop_after == ST_FAST_NMS) return ORBX_OK;
+    if (overlap) {
+        // fork: the VALU-bound blur runs on the side stream next to the latency-bound quota / retainBest kernels
+        if (hipEventRecord(side->fork, stream) != hipSuccess || hipStreamWaitEvent(side->aux, side->fork, 0) != hipSuccess) return ORBX_ERR_DEVICE;
+        if (launch_blur(side->aux) != ORBX_OK) return ORBX_ERR_DEVICE;
+        if (hipEventRecord(side->join, side->aux) != hipSuccess) return ORBX_ERR_DEVICE;
+    }
     if (stop_after == ST_COMPACT) return ORBX_OK;
     {
         StageScope sc(timer, stream, ST_QUOTA);
