@@ -76,6 +76,10 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
         const unsigned long long nib = 0x3689ABCDDEEEFFFFull;
         for (v = 0; v <= HALF_PATCH; ++v)
             if (umax[v] != (int)((nib >> (4 * v)) & 15ull)) { err = "umax table mismatch"; return ORBX_ERR_ARG; }
+        // ... and relies on the patch being symmetric: |u| <= umax[|v|]  <=>  |v| <= umax[|u|]
+        for (int a = 0; a <= HALF_PATCH; ++a)
+            for (int c = 0; c <= HALF_PATCH; ++c)
+                if ((a <= umax[c]) != (c <= umax[a])) { err = "circular patch not symmetric"; return ORBX_ERR_ARG; }
     }
 
     // --- per-level geometry
@@ -218,6 +222,7 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
             if (cw <= 0 || ch <= 0) continue;
             max_px = std::max(max_px, cw * ch);
             if (cw > 1000) { err = "grid cell wider than 1000 pixels"; return ORBX_ERR_GEOMETRY; }   // k_fast_cells: a round must span > 1 row
+            if (((cw / 4 + 2) * ch + 511) / 512 > 32) { err = "grid cell needs more than 32 k_fast_cells rounds"; return ORBX_ERR_GEOMETRY; }
             const int nd = (3 + cw + 6 + 3) / 4;
             max_img = std::max(max_img, nd * 4 * (ch + 6));
         }

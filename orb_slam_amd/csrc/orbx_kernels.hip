@@ -53,6 +53,13 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 
 
+// p -> (p / cw, p % cw) for p < 65536, cw <= 2048 with full-rate VALU ops only (v_mul_lo/hi_u32 are quarter
+// rate): q = trunc((p + 0.5) * (1/cw)), exact for every (p, cw) in that range (exhaustively checked offline).
+__device__ __forceinline__ void split_px(int p, int cw, float inv_cw, int& y, int& x) {
+    y = (int)(((float)p + 0.5f) * inv_cw);
+    x = p - (int)__umul24((unsigned)y, (unsigned)cw);
+}
+
 // ------------------------------------------------------------------------------------ pyramid
 // cv::resize INTER_LINEAR 8U, level-1 -> level.  A workgroup produces a 256x4 output tile: the source
 // rectangle it needs (<= 7 rows x ~310 px) is staged in LDS with coalesced dword loads, each lane then
@@ -85,17 +92,34 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
     const int r0 = ty[by0].sy0, r1 = ty[by1].sy1;
     const int c0 = tx[bx0].sx & ~3, c1 = tx[bx1].sx1;
     const int nd = ((c1 - c0) >> 2) + 1, nr = r1 - r0 + 1;
-    for (int r = wave; r < nr; r += 4) {
-        const uint8_t* row = src + (long long)(r0 + r) * sstride + c0;
-        for (int d = lane; d < nd; d += 64) {
-            uint32_t v4;
-            if (ALIGNED) v4 = *reinterpret_cast<const uint32_t*>(row + 4 * d);
-            else {
-                const int xm = P.w - 1 - c0;
-                v4 = (uint32_t)row[min(4 * d, xm)] | (uint32_t)row[min(4 * d + 1, xm)] << 8 | (uint32_t)row[min(4 * d + 2, xm)] << 16 |
-                     (uint32_t)row[min(4 * d + 3, xm)] << 24;
+    {
+        // flattened (row, dword) items, 8 independent loads in flight per lane (a row-per-iteration loop serialises
+        // ~6 dependent global-load round trips per workgroup and made this kernel latency-bound)
+        const int total = nr * nd;
+        const float inv_nd = 1.0f / (float)nd;
+        const uint8_t* base = src + (long long)r0 * sstride + c0;
+        const int xm = P.w - 1 - c0;
+        for (int i0 = 0; i0 < total; i0 += 256 * 8) {
+            uint32_t v4[8];
+            int off[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + k * 256 + tid;
+                v4[k] = 0;
+                off[k] = -1;
+                if (i < total) {
+                    int r, d;
+                    split_px(i, nd, inv_nd, r, d);
+                    const uint8_t* row = base + (long long)r * sstride;
+                    off[k] = r * RZ_SRC_W + 4 * d;
+                    if (ALIGNED) v4[k] = *reinterpret_cast<const uint32_t*>(row + 4 * d);
+                    else v4[k] = (uint32_t)row[min(4 * d, xm)] | (uint32_t)row[min(4 * d + 1, xm)] << 8 | (uint32_t)row[min(4 * d + 2, xm)] << 16 |
+                                 (uint32_t)row[min(4 * d + 3, xm)] << 24;
+                }
             }
-            *reinterpret_cast<uint32_t*>(s_src + r * RZ_SRC_W + 4 * d) = v4;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (off[k] >= 0) *reinterpret_cast<uint32_t*>(s_src + off[k]) = v4[k];
         }
     }
     __syncthreads();
@@ -172,13 +196,6 @@ __device__ __forceinline__ int fast_score_raw(const uint8_t* c, int S, int v, in
     return s >= tmin ? s : 0;
 }
 
-// p -> (p / cw, p % cw) for p < 65536, cw <= 2048 with full-rate VALU ops only (v_mul_lo/hi_u32 are quarter
-// rate): q = trunc((p + 0.5) * (1/cw)), exact for every (p, cw) in that range (exhaustively checked offline).
-__device__ __forceinline__ void split_px(int p, int cw, float inv_cw, int& y, int& x) {
-    y = (int)(((float)p + 0.5f) * inv_cw);
-    x = p - (int)__umul24((unsigned)y, (unsigned)cw);
-}
-
 // wave-aggregated append of the lanes with `pass` to an LDS queue; returns nothing, order inside the queue is irrelevant
 __device__ __forceinline__ void queue_push(uint16_t* q, int* counter, int pass, int value, int lane, unsigned long long lt) {
     const unsigned long long m = __ballot(pass);
@@ -224,6 +241,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(Batch b) {
     long long stride;
     const uint8_t* src = plain_plane(b, L, level, frame, stride);
     {
+        // flattened (row, dword) items, 8 independent loads in flight per lane
         const int total = (ch + 6) * nd;
         const float inv_nd = 1.0f / (float)nd;
         const uint8_t* src0 = src + (long long)(cg.y0 - 3) * stride + gxb;
@@ -231,7 +249,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(Batch b) {
         for (int i0 = 0; i0 < total; i0 += FAST_THREADS * 8) {
             uint32_t v4[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {   // 8 independent loads in flight per lane
+            for (int k = 0; k < 8; k++) {
                 const int i = i0 + k * FAST_THREADS + tid;
                 v4[k] = 0;
                 if (i < total) {
@@ -385,7 +403,11 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(Batch b) {
     // the cell's keypoint list in raster order (cv::FAST's order)
     Cand* out = b.cand + (long long)frame * g.frame_cands + L.cand_base + cg.cand_off;
     for (int ci = wave; ci < nchunks; ci += FAST_THREADS / 64) {
-        const unsigned long long m = cmask[ci];
+        // the mask word is the same for the whole wave: keep it in SGPRs so that empty chunks cost a scalar branch
+        const uint32_t* mw = reinterpret_cast<const uint32_t*>(cmask + ci);
+        const uint32_t mlo = __builtin_amdgcn_readfirstlane(mw[0]), mhi = __builtin_amdgcn_readfirstlane(mw[1]);
+        if ((mlo | mhi) == 0) continue;
+        const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
         if ((m >> lane) & 1ull) {
             const int p = ci * 64 + lane;
             int y, x;
@@ -666,16 +688,18 @@ __global__ __launch_bounds__(256) void k_describe(Batch b) {
     // HALF_PATCH_SIZE = 15, so it is a constant: nibble v of UMAX_NIBBLES (the host checks it against the computed table).
     int m10 = 0, m01 = 0;
     {
+        // the circular patch is symmetric under (u,v) -> (v,u) (the reference builds umax[] that way, :503-510; the host
+        // re-checks it), so "|u| <= umax[|v|]" is the same as "|v| <= umax[|u|]": one per-lane constant, one compare per row
         const int u = (lane & 31) - HALF_PATCH;
         const int au = u < 0 ? -u : u;
+        const int vm = au <= HALF_PATCH ? (int)((UMAX_NIBBLES >> (4 * (au & 15))) & 15ull) : -1;
+        const uint8_t* col = plain + (unsigned)(x + u) + __umul24((unsigned)(y - HALF_PATCH + (int)(lane >> 5)), pstride);
 #pragma unroll
         for (int it = 0; it < 16; it++) {
-            const int r = it * 2 + (lane >> 5);
-            const int v = r - HALF_PATCH;
+            const int v = it * 2 + (int)(lane >> 5) - HALF_PATCH;
             const int av = v < 0 ? -v : v;
-            const int um = (int)((UMAX_NIBBLES >> (4 * (av & 15))) & 15ull);
-            if (r <= 2 * HALF_PATCH && au <= um) {
-                const int I = plain[__umul24((unsigned)(y + v), pstride) + (unsigned)(x + u)];
+            if (av <= vm) {
+                const int I = col[__umul24((unsigned)(2 * it), pstride)];
                 m10 += u * I;
                 m01 += v * I;
             }
@@ -691,27 +715,46 @@ __global__ __launch_bounds__(256) void k_describe(Batch b) {
     sincosf_orb(angle * factorPI, &sn, &cs);
     const uint8_t* blur = b.blur + (long long)frame * g.frame_plane_bytes + L.plane_off;
     unsigned long long words[4];
+    // rounded pattern offsets never exceed 18 px (|(-13,-13)| = 18.4): keypoints at least 19 px from every edge — all
+    // but the outermost ring of candidates — take a branch-free path; the test is wave-uniform (scalar branch)
+    const bool interior = x >= 19 && y >= 19 && x < L.w - 19 && y < L.h - 19;
+    if (interior) {
+        const uint8_t* ctr = blur + __umul24((unsigned)y, (unsigned)L.stride) + (unsigned)x;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        int val[2];
+        for (int r = 0; r < 4; r++) {
+            int val[2];
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const float px = (float)(int)(int8_t)(pat[r] >> (16 * e));
-            const float py = (float)(int)(int8_t)(pat[r] >> (16 * e + 8));
-            const int iy = cv_round_f(px * sn + py * cs);
-            const int ix = cv_round_f(px * cs - py * sn);
-            int X = x + ix, Y = y + iy;
-            // inside the level: blurred pixel.  Outside (<= 2 px, only for keypoints 16..17 px from the edge): the
-            // reference reads the level's UNBLURRED reflect-101 border; |offset| <= 18 < size, so one
-            // reflection suffices.
-            const bool inside = (unsigned)X < (unsigned)L.w && (unsigned)Y < (unsigned)L.h;
-            X = X < 0 ? -X : (X >= L.w ? 2 * L.w - 2 - X : X);
-            Y = Y < 0 ? -Y : (Y >= L.h ? 2 * L.h - 2 - Y : Y);
-            const uint8_t* base = inside ? blur : plain;
-            const unsigned st = inside ? (unsigned)L.stride : pstride;
-            val[e] = base[__umul24((unsigned)Y, st) + (unsigned)X];
+            for (int e = 0; e < 2; e++) {
+                const float px = (float)(int)(int8_t)(pat[r] >> (16 * e));
+                const float py = (float)(int)(int8_t)(pat[r] >> (16 * e + 8));
+                const int iy = cv_round_f(px * sn + py * cs);
+                const int ix = cv_round_f(px * cs - py * sn);
+                val[e] = ctr[__mul24(iy, L.stride) + ix];
+            }
+            words[r] = __ballot(val[0] < val[1]);
         }
-        words[r] = __ballot(val[0] < val[1]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int val[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float px = (float)(int)(int8_t)(pat[r] >> (16 * e));
+                const float py = (float)(int)(int8_t)(pat[r] >> (16 * e + 8));
+                const int iy = cv_round_f(px * sn + py * cs);
+                const int ix = cv_round_f(px * cs - py * sn);
+                int X = x + ix, Y = y + iy;
+                // inside the level: blurred pixel.  Outside (<= 2 px, only for keypoints 16..17 px from the edge): the
+                // reference reads the level's UNBLURRED reflect-101 border; one reflection suffices.
+                const bool inside = (unsigned)X < (unsigned)L.w && (unsigned)Y < (unsigned)L.h;
+                X = X < 0 ? -X : (X >= L.w ? 2 * L.w - 2 - X : X);
+                Y = Y < 0 ? -Y : (Y >= L.h ? 2 * L.h - 2 - Y : Y);
+                const uint8_t* base = inside ? blur : plain;
+                const unsigned st = inside ? (unsigned)L.stride : pstride;
+                val[e] = base[__umul24((unsigned)Y, st) + (unsigned)X];
+            }
+            words[r] = __ballot(val[0] < val[1]);
+        }
     }
     if (lane < 4) {
         unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
