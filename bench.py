@@ -89,14 +89,16 @@ def main():
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE configs[1] verbatim)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo")
+    ap.add_argument("--share-device", action="store_true", help="functional smoke of the N>1 path on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     a = ap.parse_args()
 
     from orb_slam_amd import dist_util
     world, rank, local_rank = dist_util.env_ranks()
-    if world == 1:
+    if world == 1 or a.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = dist_util.init("nccl", world, rank, local_rank)       # "nccl" is RCCL on ROCm
+    dist = dist_util.init(a.backend, world, rank, local_rank)    # "nccl" is RCCL on ROCm
     assert a.gpus == world, "--gpus %d but WORLD_SIZE %d (launch with torch.distributed.run for N>1)" % (a.gpus, world)
     dev = torch.device("cuda", local_rank)
 
@@ -162,7 +164,8 @@ def main():
         accepted = capi.count_accepted(best[:nq], sec[:nq], 50, 0.6)
 
     # RCCL: the only collectives of the run (MAX of the timing, all-gather of the counters)
-    tmax, counters, _ = dist_util.reduce_run(dist, elapsed, [a.steps * B, kp_mean * a.steps * B, bad_status], dev)
+    tmax, counters, _ = dist_util.reduce_run(dist, elapsed, [a.steps * B, kp_mean * a.steps * B, bad_status],
+                                             dev if a.backend == "nccl" else torch.device("cpu"))
     total_frames = float(counters[0])
 
     if rank == 0:

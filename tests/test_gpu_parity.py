@@ -189,3 +189,47 @@ def test_cpp_shim_reference_call_sequence(tmp_path):
     _assert_kps_equal(k, ok)
     np.testing.assert_array_equal(d, od)
     assert "N=%d " % n in res.stdout and "levels=8" in res.stdout
+
+
+def test_batch_device_unaligned_frames(gpu_extractor_factory):
+    """device frames whose base / strides are not multiples of 4 take the byte-load kernel variants"""
+    torch = pytest.importorskip("torch")
+    B, w, h = 3, 641, 479
+    frames = np.stack([synth.frame(w, h, fam, 40 + i) for i, fam in enumerate((synth.BLOCKS, synth.NOISE, synth.LOWTEX))])
+    row_stride, pad = w + 3, 1                                   # odd row stride, base pointer offset by 1 byte
+    frame_stride = row_stride * h + 5
+    buf = np.zeros(pad + B * frame_stride + 8, np.uint8)
+    for f in range(B):
+        v = buf[pad + f * frame_stride: pad + f * frame_stride + row_stride * h].reshape(h, row_stride)
+        v[:, :w] = frames[f]
+    ex = gpu_extractor_factory(nfeatures=700, max_batch=2)
+    cap = ex.max_keypoints
+    d_buf = torch.from_numpy(buf).cuda()
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d_buf.data_ptr() + pad, B, w, h, row_stride, frame_stride, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+                            0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+    desc = d_desc.cpu().numpy()
+    o = orc.OracleExtractor(nfeatures=700)
+    for f in range(B):
+        ok, od = o(frames[f])
+        assert n[f] == len(ok)
+        _assert_kps_equal(kps[f, :n[f]].copy().view(capi.KP_DTYPE).reshape(-1), ok)
+        np.testing.assert_array_equal(desc[f, :n[f]], od)
+
+
+def test_capacity_and_argument_errors(gpu_extractor_factory):
+    torch = pytest.importorskip("torch")
+    ex = gpu_extractor_factory()
+    img = torch.zeros((480, 640), dtype=torch.uint8, device="cuda")
+    out = torch.zeros(16, dtype=torch.int32, device="cuda")
+    with pytest.raises(capi.OrbxError) as e:     # cap below orbx_max_keypoints()
+        ex.extract_batch_device(img.data_ptr(), 1, 640, 480, 640, 640 * 480, out.data_ptr(), out.data_ptr(), out.data_ptr(), 10)
+    assert e.value.code == capi.ORBX_ERR_CAPACITY
+    with pytest.raises(capi.OrbxError) as e:     # row stride smaller than the width
+        ex.extract_batch_device(img.data_ptr(), 1, 640, 480, 600, 640 * 480, out.data_ptr(), out.data_ptr(), out.data_ptr(), 1000)
+    assert e.value.code == capi.ORBX_ERR_ARG
