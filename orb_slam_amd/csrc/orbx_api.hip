@@ -204,6 +204,7 @@ int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int nfra
         b.out_n = d_n + f0;
         b.out_status = d_status ? d_status + f0 : nullptr;
         b.cap = cap;
+        { const char* d = getenv("ORBX_DBG"); b.dbg = d ? atoi(d) : 0; }
         rc = launch_extract(b, h->hg, stream, h->stop_after, &h->timer, &h->side);
         if (rc != ORBX_OK) { h->err = "kernel launch failed (no gfx950 code object for this device?)"; return rc; }
         h->last = b;

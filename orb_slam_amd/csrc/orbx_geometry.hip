@@ -144,6 +144,22 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
                 cand_off += c.cand_cap;
                 out.cells.push_back(c);
             }
+        // closed form of cand_off used by k_fast_cells (checked against the table)
+        {
+            auto capf = [&](int i, int j) { return (int)out.cells[cell_base + i * levelCols + j].cand_cap; };
+            L.cap_a = capf(0, 0);
+            L.cap_c = capf(levelRows - 1, 0);
+            L.cap_row = 0;
+            for (int j = 0; j < levelCols; j++) L.cap_row += capf(0, j);
+            if (levelRows == 1) { L.cap_a = L.cap_c; }
+            for (int i = 0; i < levelRows; i++)
+                for (int j = 0; j < levelCols; j++) {
+                    const int want = out.cells[cell_base + i * levelCols + j].cand_off;
+                    const int got = (i == levelRows - 1) ? (levelRows - 1) * L.cap_row + j * L.cap_c : i * L.cap_row + j * L.cap_a;
+                    // the last column of a row may differ, but it is the last term of the prefix: offsets still agree
+                    if (want != got) { err = "internal: closed-form list offsets disagree with the table"; return ORBX_ERR_GEOMETRY; }
+                }
+        }
         cell_base += L.ncells;
         cand_base += cand_off;
         L.sel_base = sel_base;
@@ -239,6 +255,12 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
         g.sel_lds_cell = align_up(max_cell * (int)sizeof(Cand), 16);
         g.sel_lds_level = align_up(max_level * (int)sizeof(Cand), 16);
         if (g.sel_lds_cell > 160 * 1024 || g.sel_lds_level > 160 * 1024) { err = "keypoint list does not fit the 160 KiB LDS"; return ORBX_ERR_GEOMETRY; }
+    }
+    for (int l = 0; l < MAX_LEVELS; l++) {
+        const bool live = l < nl;
+        g.cell_bases[l] = live ? g.lv[l].cell_base : INT_MAX;
+        g.slot_bases[l] = live ? g.lv[l].slot_base : INT_MAX;
+        g.btile_bases[l] = live ? g.lv[l].btile_base : INT_MAX;
     }
     g.ncells_total = cell_base;
     g.ntiles_total = tile_base;

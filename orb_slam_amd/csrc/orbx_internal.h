@@ -37,6 +37,7 @@ struct LevelGeom {
     int ndesired;          // mnFeaturesPerLevel[level]
     int cell_base;         // first cell index of this level in per-frame cell arrays
     int cand_base;         // first Cand slot of this level in one frame's candidate block
+    int cap_a, cap_c, cap_row;   // list capacity of a regular cell / a last-row cell, and of one full regular row (closed-form cand_off)
     int sel_base, sel_cap; // selected-keypoint list of this level in one frame's sel block
     int slot_base;         // prefix of ndesired over levels (descriptor-kernel slot -> level map)
     int tabx_off, taby_off;// offsets into the ResizeX / ResizeY tables (level >= 1)
@@ -70,6 +71,9 @@ struct DevGeom {
     int sel_lds_cell, sel_lds_level;                    // LDS bytes of k_cell_select / k_level_select (largest list)
     int fast_max_px, fast_max_chunks, fast_lds_bytes;   // k_fast_cells LDS carve (largest cell of any level)
     int umax[HALF_PATCH + 1];
+    // per-level bases as compact arrays: one scalar load each, so a wave finds its level in a single round trip
+    // (walking lv[l].xxx_base level by level was a chain of up to nlevels dependent scalar loads, ~1.5 us per wave)
+    int cell_bases[MAX_LEVELS], slot_bases[MAX_LEVELS], btile_bases[MAX_LEVELS];
     LevelGeom lv[MAX_LEVELS];
 };
 
@@ -101,6 +105,7 @@ struct Batch {
     int32_t* out_status;      // optional [frame]
     int cap;
     int nframes;
+    int dbg;                  // ablation switches for kernel tuning (ORBX_DBG env; 0 in production)
 };
 
 // Host-side geometry builder result.
