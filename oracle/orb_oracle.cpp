@@ -765,6 +765,13 @@ int orc_retain_best(const float* responses, int count, int n, int* out_idx) {
     for (size_t i = 0; i < v.size(); i++) out_idx[i] = v[i].class_id;
     return (int)v.size();
 }
+// std::nth_element(v, v+nth, v+count, response greater): the full resulting permutation (original indices)
+void orc_nth_element_perm(const float* responses, int count, int nth, int* out_perm) {
+    std::vector<KeyPoint> v(count);
+    for (int i = 0; i < count; i++) { v[i] = KeyPoint{0, 0, 0, 0, responses[i], 0, i}; }
+    std::nth_element(v.begin(), v.begin() + nth, v.end(), ResponseGreater());
+    for (int i = 0; i < count; i++) out_perm[i] = v[i].class_id;
+}
 void orc_sincosf(float a, float* s, float* c) { *s = sinf(a); *c = cosf(a); }
 
 // matcher (M1, M2)

@@ -27,7 +27,7 @@ EXPORTS = [
     "orbx_max_keypoints", "orbx_last_error", "orbx_extract", "orbx_extract_batch_device",
     "orbm_hamming256", "orbm_match_top2", "orbm_match_top2_device", "orbm_match_top2_batch_device",
     "orbm_count_accepted", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
-    "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time",
+    "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element",
 ]
 
 
@@ -84,6 +84,7 @@ def lib():
         L.orbx_debug_fetch.argtypes = [vp, ci, ci, ci, vp, cl]
         L.orbx_debug_fetch.restype = cl
         L.orbx_debug_eval_math.argtypes = [ci, vp, vp, vp, vp, ci, ci]
+        L.orbx_debug_nth_element.argtypes = [vp, ci, ci, vp, ci]
         L.orbx_debug_stage_timing.argtypes = [vp, ci]
         L.orbx_debug_stage_time.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(cl)]
         _LIB = L
@@ -233,6 +234,16 @@ def count_accepted(best, second, th=50, ratio=0.6):
     best = np.ascontiguousarray(best, dtype=np.int32)
     second = np.ascontiguousarray(second, dtype=np.int32)
     return lib().orbm_count_accepted(best.ctypes.data, second.ctypes.data, len(best), th, ratio)
+
+
+def nth_element_perm(resp, nth, device=0):
+    """permutation produced by the device's wave-parallel std::nth_element(greater by response)"""
+    r = np.ascontiguousarray(resp, dtype=np.float32)
+    out = np.empty(len(r), np.int32)
+    rc = lib().orbx_debug_nth_element(r.ctypes.data, len(r), nth, out.ctypes.data, device)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbx_debug_nth_element")
+    return out
 
 
 def eval_math(kind, in0, in1=None, device=0):

@@ -9,6 +9,7 @@
 namespace orbx {
 int launch_eval_math(int kind, const float* in0, const float* in1, float* out0, float* out1, int n);
 void stage_timer_collect(StageTimer& t);
+int launch_debug_nth(const float* d_resp, int n, int nth, int* d_out);
 }
 using namespace orbx;
 
@@ -346,6 +347,22 @@ long orbx_debug_fetch(orbx_extractor* h, int what, int frame, int level, void* h
         return need;
     }
     return ORBX_ERR_ARG;
+}
+
+int orbx_debug_nth_element(const float* resp, int n, int nth, int32_t* out_perm, int device) {
+    if (!resp || !out_perm || n < 1 || nth < 0 || nth > n || n > 13000) return ORBX_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    float* d_r = nullptr;
+    int* d_o = nullptr;
+    int rc = ORBX_ERR_DEVICE;
+    if (hipMalloc(&d_r, (size_t)n * 4) == hipSuccess && hipMalloc(&d_o, (size_t)n * 4) == hipSuccess &&
+        hipMemcpy(d_r, resp, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess) {
+        rc = launch_debug_nth(d_r, n, nth, d_o);
+        if (rc == ORBX_OK && hipMemcpy(out_perm, d_o, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = ORBX_ERR_DEVICE;
+    }
+    if (d_r) (void)hipFree(d_r);
+    if (d_o) (void)hipFree(d_o);
+    return rc;
 }
 
 int orbx_debug_eval_math(int kind, const float* in0, const float* in1, float* out0, float* out1, int n, int device) {

@@ -252,8 +252,11 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
         int max_cell = 1, max_level = 1;
         for (const CellGeom& c : out.cells) max_cell = std::max(max_cell, (int)c.cand_cap);
         for (int l = 0; l < nl; l++) max_level = std::max(max_level, g.lv[l].sel_cap);
-        g.sel_lds_cell = align_up(max_cell * (int)sizeof(Cand), 16);
-        g.sel_lds_level = align_up(max_level * (int)sizeof(Cand), 16);
+        // lists are staged in LDS up to 2048 entries (8 B + two uint16 scratch words each); longer ones (possible only in
+        // pathological images) take a sequential global-memory path
+        g.sel_lds_entries = std::min(std::max(max_cell, max_level), 2048);
+        g.sel_lds_cell = align_up(g.sel_lds_entries * ((int)sizeof(Cand) + 4), 16);
+        g.sel_lds_level = g.sel_lds_cell;
         if (g.sel_lds_cell > 160 * 1024 || g.sel_lds_level > 160 * 1024) { err = "keypoint list does not fit the 160 KiB LDS"; return ORBX_ERR_GEOMETRY; }
     }
     for (int l = 0; l < MAX_LEVELS; l++) {

@@ -68,7 +68,7 @@ struct DevGeom {
     int frame_plane_bytes;   // bytes of one frame's pyramid block (== blur block == nms block)
     int frame_cands;         // Cand slots per frame
     int frame_sel;           // sel slots per frame
-    int sel_lds_cell, sel_lds_level;                    // LDS bytes of k_cell_select / k_level_select (largest list)
+    int sel_lds_cell, sel_lds_level, sel_lds_entries;   // LDS bytes of k_cell_select / k_level_select and the list entries they stage
     int fast_max_px, fast_max_chunks, fast_lds_bytes;   // k_fast_cells LDS carve (largest cell of any level)
     int umax[HALF_PATCH + 1];
     // per-level bases as compact arrays: one scalar load each, so a wave finds its level in a single round trip

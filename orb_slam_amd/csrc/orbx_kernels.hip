@@ -490,9 +490,93 @@ __global__ __launch_bounds__(64) void k_quota(Batch b) {
     b.level_total[frame * MAX_LEVELS + level] = off;
 }
 
+// ------------------------------------------------------------------------------------ retainBest per cell
+// KeyPointsFilter::retainBest(keysCell, n) followed by resize(n) keeps exactly the first n elements
+// that std::nth_element leaves in front (the std::partition of boundary ties is truncated away again by
+// the resize).  Which tied keypoints survive, and their ORDER, is libstdc++'s introselect.
+//
+// wave_nth_element reproduces libstdc++'s std::nth_element(first, nth, last, greater-by-response) — the exact
+// permutation, not just the set — with the wave working in parallel on the Hoare partition passes:
+//   __introselect:   while (last-first > 3) { depth check; cut = __unguarded_partition_pivot; narrow } + insertion sort
+//   pivot:           __move_median_to_first(first, first+1, mid, last-1)            (lane 0, 3 compares)
+//   partition:       i scans right over elements > pivot, j scans left over elements < pivot, swap, repeat.
+// Within one pass the scans only ever stop at "left stoppers" (value <= pivot) resp. "right stoppers" (value >= pivot)
+// of the ORIGINAL array — elements between the pointers are untouched — so swap k exchanges the k-th left stopper
+// L[k] with the k-th right stopper from the top R[k] while L[k] < R[k]; after S swaps the left scan stops at
+// min(L[S], R[S-1]) (R[S-1] now holds a value <= pivot), which is the returned cut.  L and R are built with ordered
+// __ballot compaction, the swaps are disjoint and run in parallel.  The depth-limit fallback (heap select) and the
+// final <= 3-element insertion sort call libstdc++'s own constexpr internals on lane 0.
+// The list `a` and the scratch `lpos`/`rpos` (n uint16 each) live in LDS.
 struct RespGreater {   // KeypointResponseGreater (OpenCV keypoint.cpp)
-    __host__ __device__ constexpr bool operator()(const Cand& a, const Cand& b) const { return a.resp > b.resp; }
+    __host__ __device__ constexpr bool operator()(const Cand& x, const Cand& y) const { return x.resp > y.resp; }
 };
+
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+__device__ void wave_nth_element(Cand* a, int first, int nth, int last, uint16_t* lpos, uint16_t* rpos, int lane) {
+    if (first == last || nth == last) return;
+    int depth = 2 * (31 - __clz(last - first));   // std::__lg(n) * 2
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    while (last - first > 3) {
+        if (depth == 0) {
+            if (lane == 0) std::__introselect(a + first, a + nth, a + last, 0, __gnu_cxx::__ops::__iter_comp_iter(RespGreater()));
+            wave_lds_fence();
+            return;
+        }
+        --depth;
+        const int mid = first + (last - first) / 2;
+        if (lane == 0) std::__move_median_to_first(a + first, a + first + 1, a + mid, a + last - 1, __gnu_cxx::__ops::__iter_comp_iter(RespGreater()));
+        wave_lds_fence();
+        const float P = a[first].resp;
+        const int f = first + 1, l = last;
+        // left stoppers (ascending positions): !(value > P)
+        int nL = 0;
+        for (int base = f; base < l; base += 64) {
+            const int p = base + lane;
+            const bool st = p < l && !(a[p].resp > P);
+            const unsigned long long m = __ballot(st);
+            if (st) lpos[nL + __popcll(m & lt)] = (uint16_t)p;
+            nL += __popcll(m);
+        }
+        // right stoppers (descending positions): !(P > value)
+        int nR = 0;
+        for (int top = l; top > f; top -= 64) {
+            const int p = top - 1 - lane;
+            const bool st = p >= f && !(P > a[p].resp);
+            const unsigned long long m = __ballot(st);
+            if (st) rpos[nR + __popcll(m & lt)] = (uint16_t)p;
+            nR += __popcll(m);
+        }
+        wave_lds_fence();
+        // S = number of leading k with L[k] < R[k]  (L ascending, R descending: a prefix)
+        const int nmin = nL < nR ? nL : nR;
+        int S = 0;
+        for (int kb = 0; kb < nmin; kb += 64) {
+            const int k = kb + lane;
+            const bool ok = k < nmin && lpos[k] < rpos[k];
+            const unsigned long long m = __ballot(ok);
+            const int c = __popcll(m);
+            S += c;
+            if (c < 64) break;
+        }
+        for (int kb = 0; kb < S; kb += 64) {
+            const int k = kb + lane;
+            if (k < S) {
+                const int pl = lpos[k], pr = rpos[k];
+                const Cand t = a[pl];
+                a[pl] = a[pr];
+                a[pr] = t;
+            }
+        }
+        int cut;
+        if (S < nL) { cut = lpos[S]; if (S > 0 && (int)rpos[S - 1] < cut) cut = rpos[S - 1]; }
+        else cut = rpos[S - 1];
+        wave_lds_fence();
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    if (lane == 0) std::__insertion_sort(a + first, a + last, __gnu_cxx::__ops::__iter_comp_iter(RespGreater()));
+    wave_lds_fence();
+}
 
 // reference :79-120 (HarrisResponses, blockSize 7) on the unblurred level; x,y = level coords of the corner
 __device__ float harris_response(const uint8_t* img, long long step, int x, int y) {
@@ -512,17 +596,10 @@ __device__ float harris_response(const uint8_t* img, long long step, int x, int 
     return ((float)a * (float)bb - (float)c * (float)c - 0.04f * ((float)a + (float)bb) * ((float)a + (float)bb)) * scale_sq_sq;
 }
 
-// ------------------------------------------------------------------------------------ retainBest per cell
-// KeyPointsFilter::retainBest(keysCell, n) followed by resize(n) keeps exactly the first n elements
-// that std::nth_element leaves in front (the std::partition of boundary ties is truncated away again by
-// the resize).  Which tied keypoints survive, and their ORDER, is libstdc++'s introselect;
-// std::nth_element is constexpr in C++20, so the very same library code is compiled for the device.
-// The algorithm is sequential, so one lane runs it — but on a copy of the list staged in LDS (latency
-// ~100 cycles instead of ~1-2k for global memory); the wave does the staging, the threshold filter
-// (ordered __ballot compaction) and, for HARRIS_SCORE, the per-keypoint responses in parallel.
+// One wave per (frame, cell): ordered __ballot filter of the cell's list at its threshold into LDS, Harris responses
+// in parallel when selected, wave_nth_element, first nToRetain entries out.
 __global__ __launch_bounds__(64) void k_cell_select(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    Cand* lst = reinterpret_cast<Cand*>(smem);
     const DevGeom& g = b.g;
     const int frame = blockIdx.x / g.ncells_total, cell = blockIdx.x - frame * g.ncells_total;
     const int level = find_level(g.cell_bases, cell);
@@ -532,8 +609,27 @@ __global__ __launch_bounds__(64) void k_cell_select(Batch b) {
     if (s.nretain <= 0) return;
     const int lane = threadIdx.x;
     const int n_all = b.cstate[(long long)frame * g.ncells_total + cell].n_all;
-    const Cand* c = b.cand + (long long)frame * g.frame_cands + L.cand_base + cgeo.cand_off;
+    Cand* c = b.cand + (long long)frame * g.frame_cands + L.cand_base + cgeo.cand_off;
+    Cand* out = b.sel + (long long)frame * g.frame_sel + L.sel_base + s.out_off;
     const float thr = (float)s.thr;
+    long long stride;
+    const uint8_t* img = plain_plane(b, L, level, frame, stride);
+    if (n_all > g.sel_lds_entries) {
+        // rare: list longer than the LDS staging area -> the plain sequential algorithm in global memory
+        if (lane == 0) {
+            int m = 0;
+            for (int i = 0; i < n_all; i++) { const Cand e = c[i]; if (e.resp >= thr) c[m++] = e; }
+            if (g.score_type == ORBX_HARRIS_SCORE)
+                for (int i = 0; i < m; i++) c[i].resp = harris_response(img, stride, c[i].pos & 0xFFFF, c[i].pos >> 16);
+            if (m > s.nretain) std::nth_element(c, c + s.nretain, c + m, RespGreater());
+            const int keep = min(m, s.nretain);
+            for (int i = 0; i < keep; i++) out[i] = c[i];
+        }
+        return;
+    }
+    Cand* lst = reinterpret_cast<Cand*>(smem);
+    uint16_t* lpos = reinterpret_cast<uint16_t*>(smem + (size_t)g.sel_lds_entries * sizeof(Cand));
+    uint16_t* rpos = lpos + g.sel_lds_entries;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int m = 0;
     for (int base = 0; base < n_all; base += 64) {
@@ -546,24 +642,19 @@ __global__ __launch_bounds__(64) void k_cell_select(Batch b) {
         if (pass) lst[m + __popcll(mk & lt)] = e;
         m += __popcll(mk);
     }
-    __syncthreads();
+    wave_lds_fence();
     if (g.score_type == ORBX_HARRIS_SCORE) {
-        long long stride;
-        const uint8_t* img = plain_plane(b, L, level, frame, stride);
         for (int i = lane; i < m; i += 64) lst[i].resp = harris_response(img, stride, lst[i].pos & 0xFFFF, lst[i].pos >> 16);
-        __syncthreads();
+        wave_lds_fence();
     }
-    if (m > s.nretain && lane == 0) std::nth_element(lst, lst + s.nretain, lst + m, RespGreater());
-    __syncthreads();
-    Cand* out = b.sel + (long long)frame * g.frame_sel + L.sel_base + s.out_off;
+    if (m > s.nretain) wave_nth_element(lst, 0, s.nretain, m, lpos, rpos, lane);
     const int keep = min(m, s.nretain);
     for (int i = lane; i < keep; i += 64) out[i] = lst[i];
 }
 
-// reference :697-701 (per-level cap), same LDS staging
+// reference :697-701 (per-level cap), same scheme
 __global__ __launch_bounds__(64) void k_level_select(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    Cand* lst = reinterpret_cast<Cand*>(smem);
     const DevGeom& g = b.g;
     const int frame = blockIdx.x / g.nlevels, level = blockIdx.x - frame * g.nlevels;
     const LevelGeom& L = g.lv[level];
@@ -574,14 +665,40 @@ __global__ __launch_bounds__(64) void k_level_select(Batch b) {
         n = L.ndesired;
         if (n > 0) {
             Cand* v = b.sel + (long long)frame * g.frame_sel + L.sel_base;
-            for (int i = lane; i < total; i += 64) lst[i] = v[i];
-            __syncthreads();
-            if (lane == 0) std::nth_element(lst, lst + n, lst + total, RespGreater());
-            __syncthreads();
-            for (int i = lane; i < n; i += 64) v[i] = lst[i];
+            if (total > g.sel_lds_entries) {
+                if (lane == 0) std::nth_element(v, v + n, v + total, RespGreater());
+            } else {
+                Cand* lst = reinterpret_cast<Cand*>(smem);
+                uint16_t* lpos = reinterpret_cast<uint16_t*>(smem + (size_t)g.sel_lds_entries * sizeof(Cand));
+                uint16_t* rpos = lpos + g.sel_lds_entries;
+                for (int i = lane; i < total; i += 64) lst[i] = v[i];
+                wave_lds_fence();
+                wave_nth_element(lst, 0, n, total, lpos, rpos, lane);
+                for (int i = lane; i < n; i += 64) v[i] = lst[i];
+            }
         }
     }
     if (lane == 0) b.level_count[frame * MAX_LEVELS + level] = n;
+}
+
+// diagnostics: wave_nth_element on a caller-supplied response list (pos carries the original index)
+__global__ __launch_bounds__(64) void k_debug_nth(const float* resp, int n, int nth, int* out_idx) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Cand* lst = reinterpret_cast<Cand*>(smem);
+    uint16_t* lpos = reinterpret_cast<uint16_t*>(smem + (size_t)n * sizeof(Cand));
+    uint16_t* rpos = lpos + n;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n; i += 64) { Cand e; e.pos = (uint32_t)i; e.resp = resp[i]; lst[i] = e; }
+    wave_lds_fence();
+    wave_nth_element(lst, 0, nth, n, lpos, rpos, lane);
+    for (int i = lane; i < n; i += 64) out_idx[i] = (int)lst[i].pos;
+}
+int launch_debug_nth(const float* d_resp, int n, int nth, int* d_out) {
+    const size_t lds = (size_t)n * (sizeof(Cand) + 4) + 16;
+    if (lds > 160 * 1024) return ORBX_ERR_ARG;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_debug_nth), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_debug_nth, dim3(1), dim3(64), lds, 0, d_resp, n, nth, d_out);
+    return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
 
 // ------------------------------------------------------------------------------------ blur

@@ -47,6 +47,7 @@ def lib():
         L.orc_gaussian_blur7.argtypes = [c_void_p, c_int, c_int, c_int]
         L.orc_retain_best.argtypes = [c_void_p, c_int, c_int, c_void_p]
         L.orc_sincosf.argtypes = [c_float, c_void_p, c_void_p]
+        L.orc_nth_element_perm.argtypes = [c_void_p, c_int, c_int, c_void_p]
         L.orc_hamming256.argtypes = [c_void_p, c_void_p]
         L.orc_match_top2.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
         L.orc_count_accepted.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float]
@@ -165,3 +166,10 @@ def retain_best(responses, n):
     out = np.empty(max(n, 1), dtype=np.int32)
     m = lib().orc_retain_best(r.ctypes.data, len(r), n, out.ctypes.data)
     return out[:m].copy()
+
+
+def nth_element_perm(responses, nth):
+    r = np.ascontiguousarray(responses, dtype=np.float32)
+    out = np.empty(len(r), dtype=np.int32)
+    lib().orc_nth_element_perm(r.ctypes.data, len(r), nth, out.ctypes.data)
+    return out
