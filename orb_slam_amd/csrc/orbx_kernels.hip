@@ -826,16 +826,24 @@ __global__ __launch_bounds__(256) void k_describe(Batch b) {
         const int u = (lane & 31) - HALF_PATCH;
         const int au = u < 0 ? -u : u;
         const int vm = au <= HALF_PATCH ? (int)((UMAX_NIBBLES >> (4 * (au & 15))) & 15ull) : -1;
-        const uint8_t* col = plain + (unsigned)(x + u) + __umul24((unsigned)(y - HALF_PATCH + (int)(lane >> 5)), pstride);
+        // loads are unconditional (addresses clamped into the 31x31 box, always inside the image: the keypoint is >= 16 px
+        // from every edge) and masked afterwards: 16 independent loads in flight, no divergent branches
+        const int uc = u > HALF_PATCH ? HALF_PATCH : u;
+        const uint8_t* col = plain + (unsigned)(x + uc);
+        int Iv[16];
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            int r = it * 2 + (int)(lane >> 5);
+            r = r > 2 * HALF_PATCH ? 2 * HALF_PATCH : r;
+            Iv[it] = col[__umul24((unsigned)(y - HALF_PATCH + r), pstride)];
+        }
 #pragma unroll
         for (int it = 0; it < 16; it++) {
             const int v = it * 2 + (int)(lane >> 5) - HALF_PATCH;
             const int av = v < 0 ? -v : v;
-            if (av <= vm) {
-                const int I = col[__umul24((unsigned)(2 * it), pstride)];
-                m10 += u * I;
-                m01 += v * I;
-            }
+            const int I = av <= vm ? Iv[it] : 0;
+            m10 += u * I;
+            m01 += v * I;
         }
         m10 = wave_sum(m10);
         m01 = wave_sum(m01);
