@@ -103,6 +103,21 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
         L.kp_size = (float)(int)(31 * out.scale[l]);
         L.ndesired = out.features_per_level[l];
         L.blur_wvec = (p.blur_rounding == ORBX_BLUR_X86_SSE2) ? (L.w & ~3) : 0;
+        {
+            // k_blur border lanes: v_perm_b32(S0 = D_last (px q..q+3), S1 = D_prev (px q-4..q-1)), selector byte = source index
+            // 0..3 -> D_prev, 4..7 -> D_last.  px p lives at index p-(q-4); out-of-row px p >= w reflect to 2w-2-p.
+            const int q = (L.w - 1) & ~3, rem = L.w - q;
+            unsigned sel_last = 0, sel_halo = 0;
+            for (int i = 0; i < 4; i++) {
+                const int idx_last = i < rem ? 4 + i : 2 * rem + 2 - i;          // px q+i
+                int idx_halo = 2 * rem - 2 - i;                                    // px q+4+i (only px <= w+2 are ever used)
+                if (idx_halo < 0) idx_halo = 0;
+                sel_last |= (unsigned)(idx_last & 7) << (8 * i);
+                sel_halo |= (unsigned)(idx_halo & 7) << (8 * i);
+            }
+            L.blur_sel_last = (int)sel_last;
+            L.blur_sel_halo = (int)sel_halo;
+        }
 
         // grid (:534-547)
         const int levelCols = (int)std::sqrt((float)L.ndesired / (5 * imageRatio));

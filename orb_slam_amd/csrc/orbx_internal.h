@@ -45,6 +45,7 @@ struct LevelGeom {
     int tile_base, tiles_x, tiles_y;   // 64x32 tiling of the scan area [16,w-17]x[16,h-17]
     int btile_base, btiles_x, btiles_y;// blur wave tasks: 248-px strips x 32-row bands of the whole plane
     int blur_wvec;         // columns x < blur_wvec round ties-to-even (SSE2 emulation), others half-up
+    int blur_sel_last, blur_sel_halo;   // v_perm selectors building the reflect-101 bytes of the last / right-halo dword of a row
     float scale;           // mvScaleFactor[level]
     float kp_size;         // (float)(int)(PATCH_SIZE*mvScaleFactor[level])  (:675,:692)
 };

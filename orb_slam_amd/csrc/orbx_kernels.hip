@@ -738,8 +738,10 @@ __global__ __launch_bounds__(256) void k_blur(Batch b) {
     long long stride;
     const uint8_t* src = plain_plane(b, L, level, frame, stride);
     uint8_t* dst = b.blur + (long long)frame * g.frame_plane_bytes + L.plane_off;
-    const bool interior = x >= 0 && x + 3 < w;
     const bool fetch = x >= -4 && x < w + 4;                   // halo lanes beyond that are never consumed
+    const int xq = (w - 1) & ~3;                               // first pixel of the last (possibly partial) dword of a row
+    const int xl = x < 0 ? 0 : (x > xq ? xq : x);
+    const bool is_left = x == -4, is_last = x == xq, is_halo = x == xq + 4;
     const bool writer = lane >= 1 && lane <= BLUR_STRIP_DW && x < w;
     const int te = x < L.blur_wvec;                            // blur_wvec is a multiple of 4
     const uint32_t WA = 0x37312212u;                           // taps 18,34,49,55 (little-endian bytes)
@@ -750,9 +752,18 @@ __global__ __launch_bounds__(256) void k_blur(Batch b) {
         const int yy = reflect101(y0 + r - 3, h);
         const uint8_t* row = src + (long long)yy * stride;
         uint32_t C = 0;
-        if (fetch) {
-            if (ALIGNED && interior) C = *reinterpret_cast<const uint32_t*>(row + x);
-            else C = load_px4_reflect(row, x, w);
+        if (ALIGNED) {
+            // every lane loads an aligned dword (x clamped into the row); the three kinds of border lanes then build
+            // their reflect-101 bytes from dwords already in the wave (DPP + v_perm): no divergent byte-load path
+            const uint32_t Craw = *reinterpret_cast<const uint32_t*>(row + xl);
+            const uint32_t L1 = __builtin_amdgcn_update_dpp(0u, Craw, 0x138, 0xf, 0xf, false);   // lane-1
+            const uint32_t L2 = __builtin_amdgcn_update_dpp(0u, L1, 0x138, 0xf, 0xf, false);     // lane-2
+            C = Craw;
+            if (is_left) C = __builtin_amdgcn_perm(Craw, Craw, 0x01020300u);       // px -3..-1 <- px 3,2,1 of dword 0
+            if (is_last) C = __builtin_amdgcn_perm(Craw, L1, (uint32_t)L.blur_sel_last);   // (D_last, D_prev)
+            if (is_halo) C = __builtin_amdgcn_perm(Craw, L2, (uint32_t)L.blur_sel_halo);   // Craw == D_last (clamped load)
+        } else if (fetch) {
+            C = load_px4_reflect(row, x, w);
         }
         const uint32_t Lw = __builtin_amdgcn_update_dpp(0u, C, 0x138, 0xf, 0xf, false);   // wave_shr:1  <- lane-1
         const uint32_t R = __builtin_amdgcn_update_dpp(0u, C, 0x130, 0xf, 0xf, false);    // wave_shl:1  <- lane+1
