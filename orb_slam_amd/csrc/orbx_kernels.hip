@@ -298,20 +298,15 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
                 int y, x;
                 split_px(p, cw, inv_cw, y, x);
                 const uint8_t* sp = s_sc + p;
-                const bool hasL = x > 0, hasR = x < cw - 1, hasU = y > 0, hasD = y < ch - 1;
-                int mx = 0;   // neighbours outside the cell count as 0 (cv::FAST on the cell view)
-                if (hasL) mx = imax(mx, sp[-1]);
-                if (hasR) mx = imax(mx, sp[1]);
-                if (hasU) {
-                    mx = imax(mx, sp[-cw]);
-                    if (hasL) mx = imax(mx, sp[-cw - 1]);
-                    if (hasR) mx = imax(mx, sp[-cw + 1]);
-                }
-                if (hasD) {
-                    mx = imax(mx, sp[cw]);
-                    if (hasL) mx = imax(mx, sp[cw - 1]);
-                    if (hasR) mx = imax(mx, sp[cw + 1]);
-                }
+                // neighbours outside the cell count as 0 (cv::FAST on the cell view): offsets are clamped to stay inside
+                // the score array and the values masked, so the 8 LDS loads are independent and branch-free
+                const int dl = x > 0 ? -1 : 0, dr = x < cw - 1 ? 1 : 0, du = y > 0 ? -cw : 0, dd = y < ch - 1 ? cw : 0;
+                const int nl = sp[dl], nr = sp[dr], nu = sp[du], nd_ = sp[dd];
+                const int nul = sp[du + dl], nur = sp[du + dr], ndl = sp[dd + dl], ndr = sp[dd + dr];
+                int mx = imax3(dl ? nl : 0, dr ? nr : 0, du ? nu : 0);
+                mx = imax3(mx, dd ? nd_ : 0, (du && dl) ? nul : 0);
+                mx = imax3(mx, (du && dr) ? nur : 0, (dd && dl) ? ndl : 0);
+                mx = imax(mx, (dd && dr) ? ndr : 0);
                 if (s > mx) {
                     atomicOr(&cmask[p >> 6], 1ull << (p & 63));
                     if (s >= g.fast_th) atomicAdd(&hdr->n_hi, 1);   // survivors are rare: LDS atomics beat a wave reduction
@@ -329,17 +324,23 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
             int pass[FAST_PPT];
             unsigned long long pm[FAST_PPT];
             int cnt = 0;
+            // all 4 pixels' loads are issued before any test (addresses clamped into the cell, results masked)
+            int vv[FAST_PPT], mn4[FAST_PPT], mx4[FAST_PPT];
+#pragma unroll
+            for (int k = 0; k < FAST_PPT; k++) {
+                const int p = imin(base + k * FAST_THREADS + tid, npx - 1);
+                int y, x;
+                split_px(p, cw, inv_cw, y, x);
+                const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
+                const int x0 = c[3 * S], x4 = c[3], x8 = c[-3 * S], x12 = c[-3];
+                vv[k] = c[0];
+                mn4[k] = imin(imin(x0, x4), imin(x8, x12));
+                mx4[k] = imax(imax(x0, x4), imax(x8, x12));
+            }
 #pragma unroll
             for (int k = 0; k < FAST_PPT; k++) {
                 const int p = base + k * FAST_THREADS + tid;
-                pass[k] = 0;
-                if (p < npx) {
-                    int y, x;
-                    split_px(p, cw, inv_cw, y, x);
-                    const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
-                    const int v = c[0], x0 = c[3 * S], x4 = c[3], x8 = c[-3 * S], x12 = c[-3];
-                    pass[k] = (int)(v - imin(imin(x0, x4), imin(x8, x12)) > tmin) | (int)(imax(imax(x0, x4), imax(x8, x12)) - v > tmin);
-                }
+                pass[k] = p < npx && ((vv[k] - mn4[k] > tmin) | (mx4[k] - vv[k] > tmin));
                 pm[k] = __ballot(pass[k]);
                 cnt += __popcll(pm[k]);
             }
