@@ -20,6 +20,7 @@ struct orbx_extractor {
     int gw = 0, gh = 0;
     HostGeom hg;
     CellGeom* d_cells = nullptr;
+    BandGeom* d_bands = nullptr;
     ResizeX* d_tabx = nullptr;
     ResizeY* d_taby = nullptr;
     uint8_t *d_flagx = nullptr, *d_flagy = nullptr;
@@ -61,7 +62,7 @@ static void dev_free(T*& p) {
 }
 
 static void free_geometry(orbx_extractor* h) {
-    dev_free(h->d_cells); dev_free(h->d_tabx); dev_free(h->d_taby);
+    dev_free(h->d_cells); dev_free(h->d_bands); dev_free(h->d_tabx); dev_free(h->d_taby);
     dev_free(h->d_flagx); dev_free(h->d_flagy);
     dev_free(h->d_pyr); dev_free(h->d_blur); dev_free(h->d_nms);
     dev_free(h->d_cand); dev_free(h->d_sel); dev_free(h->d_cstate); dev_free(h->d_csel);
@@ -89,6 +90,7 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
     const DevGeom& g = h->hg.g;
     const size_t B = (size_t)h->p.max_batch;
     if ((rc = upload(h, h->d_cells, h->hg.cells)) != ORBX_OK) return rc;
+    if ((rc = upload(h, h->d_bands, h->hg.bands)) != ORBX_OK) return rc;
     if ((rc = upload(h, h->d_tabx, h->hg.tabx)) != ORBX_OK) return rc;
     if ((rc = upload(h, h->d_taby, h->hg.taby)) != ORBX_OK) return rc;
     if ((rc = upload(h, h->d_flagx, h->hg.flagx)) != ORBX_OK) return rc;
@@ -97,7 +99,7 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
     HIPCHK(h, hipMalloc(&h->d_blur, B * g.frame_plane_bytes));
     HIPCHK(h, hipMalloc(&h->d_cand, B * std::max(g.frame_cands, 1) * sizeof(Cand)));
     HIPCHK(h, hipMalloc(&h->d_sel, B * std::max(g.frame_sel, 1) * sizeof(Cand)));
-    HIPCHK(h, hipMalloc(&h->d_cstate, B * g.ncells_total * sizeof(CellState)));
+    HIPCHK(h, hipMalloc(&h->d_cstate, B * g.nbands_total * sizeof(CellState)));
     HIPCHK(h, hipMalloc(&h->d_csel, B * g.ncells_total * sizeof(CellSel)));
     HIPCHK(h, hipMalloc(&h->d_level_total, B * MAX_LEVELS * sizeof(int32_t)));
     HIPCHK(h, hipMalloc(&h->d_level_count, B * MAX_LEVELS * sizeof(int32_t)));
@@ -111,7 +113,7 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
 }
 
 static void fill_batch(orbx_extractor* h, Batch& b) {
-    b.g = h->hg.g; b.cells = h->d_cells; b.tabx = h->d_tabx; b.taby = h->d_taby;
+    b.g = h->hg.g; b.cells = h->d_cells; b.bands = h->d_bands; b.tabx = h->d_tabx; b.taby = h->d_taby;
     b.flagx = h->d_flagx; b.flagy = h->d_flagy;
     b.pyr = h->d_pyr; b.blur = h->d_blur; b.nms = h->d_nms;
     b.cand = h->d_cand; b.sel = h->d_sel; b.cstate = h->d_cstate; b.csel = h->d_csel;
@@ -298,17 +300,18 @@ long orbx_debug_fetch(orbx_extractor* h, int what, int frame, int level, void* h
         const long need = (long)L.w * L.h;
         if (cap_bytes < need) return ORBX_ERR_CAPACITY;
         memset(host_out, 0, need);
-        std::vector<CellState> st(L.ncells);
-        if (hipMemcpy(st.data(), b.cstate + (size_t)frame * g.ncells_total + L.cell_base, L.ncells * sizeof(CellState), hipMemcpyDeviceToHost) != hipSuccess)
+        std::vector<CellState> st(g.nbands_total);
+        if (hipMemcpy(st.data(), b.cstate + (size_t)frame * g.nbands_total, g.nbands_total * sizeof(CellState), hipMemcpyDeviceToHost) != hipSuccess)
             return ORBX_ERR_DEVICE;
         std::vector<Cand> tmp;
-        for (int c = 0; c < L.ncells; c++) {
-            const CellGeom& cgm = h->hg.cells[L.cell_base + c];
-            const int n = st[c].n_all;
+        for (int it = 0; it < g.nbands_total; it++) {
+            const BandGeom& bgm = h->hg.bands[it];
+            if (bgm.level != level) continue;
+            const int n = st[it].n_all;
             if (n <= 0) continue;
-            if (n > cgm.cand_cap) return ORBX_ERR_CAPACITY;
+            if (n > bgm.cand_cap) return ORBX_ERR_CAPACITY;
             tmp.resize(n);
-            if (hipMemcpy(tmp.data(), b.cand + (size_t)frame * g.frame_cands + L.cand_base + cgm.cand_off, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost) != hipSuccess)
+            if (hipMemcpy(tmp.data(), b.cand + (size_t)frame * g.frame_cands + L.cand_base + bgm.cand_off, (size_t)n * sizeof(Cand), hipMemcpyDeviceToHost) != hipSuccess)
                 return ORBX_ERR_DEVICE;
             for (int i = 0; i < n; i++) ((uint8_t*)host_out)[(size_t)(tmp[i].pos >> 16) * L.w + (tmp[i].pos & 0xFFFF)] = (uint8_t)tmp[i].resp;
         }

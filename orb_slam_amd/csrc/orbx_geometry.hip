@@ -155,26 +155,31 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
                 c.skipped = (skipX || skipY) ? 1 : 0;
                 const int cw = std::max(0, c.x1 - c.x0 + 1), ch = std::max(0, c.y1 - c.y0 + 1);
                 c.cand_off = cand_off;
-                c.cand_cap = ((cw + 1) / 2) * ((ch + 1) / 2);   // strict 3x3 maxima cannot be adjacent
-                cand_off += c.cand_cap;
+                c.band0 = (int)out.bands.size();
+                const int nb = std::max(1, (cw * ch + BAND_PX - 1) / BAND_PX);
+                const int rb = std::max(1, (ch + nb - 1) / nb);
+                c.nbands = 0;
+                c.cand_cap = 0;
+                for (int k = 0; k < nb; k++) {
+                    BandGeom bg;
+                    memset(&bg, 0, sizeof(bg));
+                    bg.x0 = c.x0; bg.x1 = c.x1;
+                    bg.y0 = (int16_t)(c.y0 + k * rb);
+                    bg.y1 = (int16_t)std::min<int>(c.y1, bg.y0 + rb - 1);
+                    if (k > 0 && bg.y0 > c.y1) break;                 // (rounding left no rows for this band)
+                    bg.ey0 = (int16_t)std::max<int>(c.y0, bg.y0 - 1);
+                    bg.ey1 = (int16_t)std::min<int>(c.y1, bg.y1 + 1);
+                    bg.level = (int16_t)l;
+                    const int bh = std::max(0, bg.y1 - bg.y0 + 1);
+                    bg.cand_off = cand_off;
+                    bg.cand_cap = ((cw + 1) / 2) * ((bh + 1) / 2);    // strict 3x3 maxima cannot be adjacent
+                    cand_off += bg.cand_cap;
+                    c.cand_cap += bg.cand_cap;
+                    c.nbands++;
+                    out.bands.push_back(bg);
+                }
                 out.cells.push_back(c);
             }
-        // closed form of cand_off used by k_fast_cells (checked against the table)
-        {
-            auto capf = [&](int i, int j) { return (int)out.cells[cell_base + i * levelCols + j].cand_cap; };
-            L.cap_a = capf(0, 0);
-            L.cap_c = capf(levelRows - 1, 0);
-            L.cap_row = 0;
-            for (int j = 0; j < levelCols; j++) L.cap_row += capf(0, j);
-            if (levelRows == 1) { L.cap_a = L.cap_c; }
-            for (int i = 0; i < levelRows; i++)
-                for (int j = 0; j < levelCols; j++) {
-                    const int want = out.cells[cell_base + i * levelCols + j].cand_off;
-                    const int got = (i == levelRows - 1) ? (levelRows - 1) * L.cap_row + j * L.cap_c : i * L.cap_row + j * L.cap_a;
-                    // the last column of a row may differ, but it is the last term of the prefix: offsets still agree
-                    if (want != got) { err = "internal: closed-form list offsets disagree with the table"; return ORBX_ERR_GEOMETRY; }
-                }
-        }
         cell_base += L.ncells;
         cand_base += cand_off;
         L.sel_base = sel_base;
@@ -248,12 +253,12 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
     // LDS carve of k_fast_cells, sized by the largest cell
     {
         int max_px = 0, max_img = 0;
-        for (const CellGeom& c : out.cells) {
-            const int cw = c.x1 - c.x0 + 1, ch = c.y1 - c.y0 + 1;
+        for (const BandGeom& c : out.bands) {
+            const int cw = c.x1 - c.x0 + 1, ch = c.ey1 - c.ey0 + 1;
             if (cw <= 0 || ch <= 0) continue;
             max_px = std::max(max_px, cw * ch);
             if (cw > 1000) { err = "grid cell wider than 1000 pixels"; return ORBX_ERR_GEOMETRY; }   // k_fast_cells: a round must span > 1 row
-            if (((cw / 4 + 2) * ch + 511) / 512 > 32) { err = "grid cell needs more than 32 k_fast_cells rounds"; return ORBX_ERR_GEOMETRY; }
+            if (((cw / 4 + 2) * ch + 511) / 512 > 32) { err = "grid cell band needs more than 32 k_fast_cells rounds"; return ORBX_ERR_GEOMETRY; }
             const int nd = (3 + cw + 6 + 3) / 4;
             max_img = std::max(max_img, nd * 4 * (ch + 6));
         }
@@ -281,6 +286,7 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
         g.btile_bases[l] = live ? g.lv[l].btile_base : INT_MAX;
     }
     g.ncells_total = cell_base;
+    g.nbands_total = (int)out.bands.size();
     g.ntiles_total = tile_base;
     g.nbtiles_total = btile_base;
     g.nslots = slot_base;

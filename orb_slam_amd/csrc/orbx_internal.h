@@ -37,7 +37,6 @@ struct LevelGeom {
     int ndesired;          // mnFeaturesPerLevel[level]
     int cell_base;         // first cell index of this level in per-frame cell arrays
     int cand_base;         // first Cand slot of this level in one frame's candidate block
-    int cap_a, cap_c, cap_row;   // list capacity of a regular cell / a last-row cell, and of one full regular row (closed-form cand_off)
     int sel_base, sel_cap; // selected-keypoint list of this level in one frame's sel block
     int slot_base;         // prefix of ndesired over levels (descriptor-kernel slot -> level map)
     int tabx_off, taby_off;// offsets into the ResizeX / ResizeY tables (level >= 1)
@@ -53,7 +52,20 @@ struct LevelGeom {
 struct CellGeom {
     int16_t x0, y0, x1, y1;   // inclusive scan rectangle in level coords; empty when x1<x0 or y1<y0
     int32_t skipped;          // reference `continue` cells (hX<=0 / hY<=0): never reach the quota else-branch
-    int32_t cand_off;         // first Cand slot relative to the level's cand_base
+    int32_t cand_off;         // first Cand slot relative to the level's cand_base (= its first band's sub-list)
+    int32_t cand_cap;         // sum of its bands' capacities
+    int32_t band0, nbands;    // its k_fast_cells work items
+};
+
+// One k_fast_cells work item: a band of rows of a grid cell.  Cells above BAND_PX pixels (1080p grids) are cut into
+// row bands so that a work item's LDS footprint stays ~35 KB (4 workgroups per CU); bands concatenate in raster order.
+constexpr int BAND_PX = 10240;
+struct BandGeom {
+    int16_t x0, x1;           // the cell's column range (inclusive)
+    int16_t y0, y1;           // rows this band owns (inclusive)
+    int16_t ey0, ey1;         // rows it scores: own rows + 1 halo row towards neighbouring bands of the same cell
+    int16_t level, pad;
+    int32_t cand_off;         // first Cand slot of its sub-list relative to the level's cand_base
     int32_t cand_cap;
 };
 
@@ -63,6 +75,7 @@ struct CellSel { int32_t thr, nkeys, nretain, out_off; };
 struct DevGeom {
     int nlevels;
     int ncells_total;
+    int nbands_total;        // k_fast_cells work items per frame (>= ncells_total)
     int ntiles_total, nbtiles_total;
     int nslots;              // sum of ndesired (max keypoints per frame)
     int score_type, fast_th, tmin;
@@ -84,6 +97,7 @@ struct DevGeom {
 struct Batch {
     DevGeom g;
     const CellGeom* cells;
+    const BandGeom* bands;
     const ResizeX* tabx;
     const ResizeY* taby;
     const uint8_t* flagx;     // per column: bit0 = first column of its cell, bit1 = last column of its cell
@@ -95,7 +109,7 @@ struct Batch {
     uint8_t* nms;             // [frame][frame_plane_bytes]
     Cand* cand;               // [frame][frame_cands]
     Cand* sel;                // [frame][frame_sel]
-    CellState* cstate;        // [frame][ncells_total]
+    CellState* cstate;        // [frame][nbands_total]  (per band: survivors, and how many reach fastTh / 7)
     CellSel* csel;            // [frame][ncells_total]
     int32_t* level_total;     // [frame][MAX_LEVELS]  keypoints gathered from the cells
     int32_t* level_count;     // [frame][MAX_LEVELS]  after the per-level cap
@@ -113,6 +127,7 @@ struct Batch {
 struct HostGeom {
     DevGeom g;
     std::vector<CellGeom> cells;
+    std::vector<BandGeom> bands;
     std::vector<ResizeX> tabx;
     std::vector<ResizeY> taby;
     std::vector<uint8_t> flagx, flagy;

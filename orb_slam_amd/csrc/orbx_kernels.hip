@@ -212,24 +212,18 @@ __device__ __forceinline__ void queue_push(uint16_t* q, int* counter, int pass, 
 template <bool ALIGNED>
 __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t* smem) {
     const DevGeom& g = b.g;
-    const int frame = task / g.ncells_total;
-    const int cell = task - frame * g.ncells_total;
-    const int level = find_level(g.cell_bases, cell);
+    const int frame = task / g.nbands_total;
+    const int item = task - frame * g.nbands_total;
+    const BandGeom bg = b.bands[item];
+    const int level = bg.level;
     const LevelGeom& L = g.lv[level];
-    // the cell rectangle and its list offset follow from the level's grid (all scalar, kernarg-resident): no table load
-    CellGeom cg;
-    {
-        const int cl = cell - L.cell_base;
-        const int ci = (int)(((float)cl + 0.5f) * (1.0f / (float)L.gcols)), cj = cl - ci * L.gcols;
-        cg.x0 = (int16_t)(EDGE + cj * L.cellW);
-        cg.y0 = (int16_t)(EDGE + ci * L.cellH);
-        cg.x1 = (int16_t)(cj == L.gcols - 1 ? L.w - EDGE - 1 : cg.x0 + L.cellW - 1);
-        cg.y1 = (int16_t)(ci == L.grows - 1 ? L.h - EDGE - 1 : cg.y0 + L.cellH - 1);
-        cg.cand_off = (ci == L.grows - 1 ? (L.grows - 1) * L.cap_row + cj * L.cap_c : ci * L.cap_row + cj * L.cap_a);
-    }
+    // the band scores rows ey0..ey1 (its own rows plus one halo row towards neighbouring bands of the same cell) and
+    // emits survivors of its own rows y0..y1 only; below, "cell" coordinates are relative to (x0, ey0)
+    struct { int x0, y0, x1, y1; } cg = {bg.x0, bg.ey0, bg.x1, bg.ey1};
+    const int own_lo = bg.y0 - bg.ey0, own_hi = bg.y1 - bg.ey0;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int cw = cg.x1 - cg.x0 + 1, ch = cg.y1 - cg.y0 + 1;
-    CellState* cst = b.cstate + (long long)frame * g.ncells_total + cell;
+    CellState* cst = b.cstate + (long long)frame * g.nbands_total + item;
     if (cw <= 0 || ch <= 0) {
         if (tid == 0) { CellState st; st.n_all = 0; st.n_hi = 0; st.n_lo = 0; *cst = st; }
         return;
@@ -307,7 +301,7 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
                 mx = imax3(mx, dd ? nd_ : 0, (du && dl) ? nul : 0);
                 mx = imax3(mx, (du && dr) ? nur : 0, (dd && dl) ? ndl : 0);
                 mx = imax(mx, (dd && dr) ? ndr : 0);
-                if (s > mx) {
+                if (s > mx && y >= own_lo && y <= own_hi) {
                     atomicOr(&cmask[p >> 6], 1ull << (p & 63));
                     if (s >= g.fast_th) atomicAdd(&hdr->n_hi, 1);   // survivors are rare: LDS atomics beat a wave reduction
                     if (s >= 7) atomicAdd(&hdr->n_lo, 1);
@@ -410,7 +404,7 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
     }
     __syncthreads();
     // the cell's keypoint list in raster order (cv::FAST's order)
-    Cand* out = b.cand + (long long)frame * g.frame_cands + L.cand_base + cg.cand_off;
+    Cand* out = b.cand + (long long)frame * g.frame_cands + L.cand_base + bg.cand_off;
     for (int ci = wave; ci < nchunks; ci += FAST_THREADS / 64) {
         // the mask word is the same for the whole wave: keep it in SGPRs so that empty chunks cost a scalar branch
         const uint32_t* mw = reinterpret_cast<const uint32_t*>(cmask + ci);
@@ -451,7 +445,7 @@ __global__ __launch_bounds__(64) void k_quota(Batch b) {
     const int frame = idx / g.nlevels, level = idx - frame * g.nlevels;
     const LevelGeom& L = g.lv[level];
     const CellGeom* cg = b.cells + L.cell_base;
-    const CellState* cs = b.cstate + (long long)frame * g.ncells_total + L.cell_base;
+    const CellState* cs = b.cstate + (long long)frame * g.nbands_total;   // per band; a cell sums its bands
     CellSel* sel = b.csel + (long long)frame * g.ncells_total + L.cell_base;
     const int nCells = L.ncells, nfc = L.nfeat_cell;
     int nToDistribute = 0, nNoMore = 0;
@@ -461,7 +455,9 @@ __global__ __launch_bounds__(64) void k_quota(Batch b) {
         if (cg[c].skipped) {
             s.thr = g.fast_th; s.nkeys = 0; s.nretain = 0; s.out_off = 0;
         } else {
-            const CellState st = cs[c];
+            CellState st;
+            st.n_all = 0; st.n_hi = 0; st.n_lo = 0;
+            for (int k = 0; k < cg[c].nbands; k++) { const CellState t = cs[cg[c].band0 + k]; st.n_all += t.n_all; st.n_hi += t.n_hi; st.n_lo += t.n_lo; }
             const bool fallback = st.n_hi <= 3;               // :609  size()<=3 -> FAST(...,7,...)
             s.thr = fallback ? 7 : g.fast_th;
             s.nkeys = fallback ? st.n_lo : st.n_hi;
@@ -609,17 +605,27 @@ __global__ __launch_bounds__(64) void k_cell_select(Batch b) {
     const CellSel s = b.csel[(long long)frame * g.ncells_total + cell];
     if (s.nretain <= 0) return;
     const int lane = threadIdx.x;
-    const int n_all = b.cstate[(long long)frame * g.ncells_total + cell].n_all;
-    Cand* c = b.cand + (long long)frame * g.frame_cands + L.cand_base + cgeo.cand_off;
+    // the cell's list = its bands' sub-lists in band (= raster) order
+    const CellState* bst = b.cstate + (long long)frame * g.nbands_total + cgeo.band0;
+    const BandGeom* bgs = b.bands + cgeo.band0;
+    Cand* lbase = b.cand + (long long)frame * g.frame_cands + L.cand_base;
+    Cand* c = lbase + cgeo.cand_off;
+    int n_all = 0;
+    for (int k = 0; k < cgeo.nbands; k++) n_all += bst[k].n_all;
     Cand* out = b.sel + (long long)frame * g.frame_sel + L.sel_base + s.out_off;
     const float thr = (float)s.thr;
     long long stride;
     const uint8_t* img = plain_plane(b, L, level, frame, stride);
     if (n_all > g.sel_lds_entries) {
         // rare: list longer than the LDS staging area -> the plain sequential algorithm in global memory
+        // (filtered entries are compacted to the front of the cell's area; the write index never passes the read index)
         if (lane == 0) {
             int m = 0;
-            for (int i = 0; i < n_all; i++) { const Cand e = c[i]; if (e.resp >= thr) c[m++] = e; }
+            for (int k = 0; k < cgeo.nbands; k++) {
+                const Cand* bc = lbase + bgs[k].cand_off;
+                const int nb = bst[k].n_all;
+                for (int i = 0; i < nb; i++) { const Cand e = bc[i]; if (e.resp >= thr) c[m++] = e; }
+            }
             if (g.score_type == ORBX_HARRIS_SCORE)
                 for (int i = 0; i < m; i++) c[i].resp = harris_response(img, stride, c[i].pos & 0xFFFF, c[i].pos >> 16);
             if (m > s.nretain) std::nth_element(c, c + s.nretain, c + m, RespGreater());
@@ -633,15 +639,19 @@ __global__ __launch_bounds__(64) void k_cell_select(Batch b) {
     uint16_t* rpos = lpos + g.sel_lds_entries;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int m = 0;
-    for (int base = 0; base < n_all; base += 64) {
-        const int i = base + lane;
-        Cand e;
-        e.pos = 0; e.resp = -1.f;
-        if (i < n_all) e = c[i];
-        const bool pass = i < n_all && e.resp >= thr;
-        const unsigned long long mk = __ballot(pass);
-        if (pass) lst[m + __popcll(mk & lt)] = e;
-        m += __popcll(mk);
+    for (int k = 0; k < cgeo.nbands; k++) {
+        const Cand* bc = lbase + bgs[k].cand_off;
+        const int nb = bst[k].n_all;
+        for (int base = 0; base < nb; base += 64) {
+            const int i = base + lane;
+            Cand e;
+            e.pos = 0; e.resp = -1.f;
+            if (i < nb) e = bc[i];
+            const bool pass = i < nb && e.resp >= thr;
+            const unsigned long long mk = __ballot(pass);
+            if (pass) lst[m + __popcll(mk & lt)] = e;
+            m += __popcll(mk);
+        }
     }
     wave_lds_fence();
     if (g.score_type == ORBX_HARRIS_SCORE) {
@@ -980,7 +990,7 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
-        const int nblk = F * g.ncells_total;
+        const int nblk = F * g.nbands_total;
         if (aligned) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nblk), dim3(FAST_THREADS), lds, stream, b);
         else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nblk), dim3(FAST_THREADS), lds, stream, b);
         ORBX_LAUNCH_CHECK();

@@ -94,7 +94,8 @@ def test_stage_parity_vga(gpu_extractor_factory, family):
     dict(w=752, h=480, nfeatures=1000),                       # EuRoC-size, stride not a multiple of 64
     dict(w=641, h=479, nfeatures=500, fastTh=12),
     dict(w=320, h=240, nfeatures=300, nlevels=5),
-    dict(w=1920, h=1080, nfeatures=2000),
+    dict(w=1920, h=1080, nfeatures=2000),                     # grid cells of 33k px: cut into 4 row bands
+    dict(w=1280, h=720, nfeatures=1000),                      # 2 bands per cell on the lower levels
     dict(w=640, h=480, nfeatures=1000, scoreType=capi.HARRIS_SCORE),
     dict(w=640, h=480, nfeatures=1000, scaleFactor=1.5, nlevels=4),
     dict(w=640, h=480, nfeatures=1000, fastTh=5),             # fastTh below the fallback threshold 7
