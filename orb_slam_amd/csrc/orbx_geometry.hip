@@ -134,6 +134,7 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
         L.cellH = (int)std::ceil((float)H / levelRows);
         L.ncells = levelRows * levelCols;
         L.nfeat_cell = (int)std::ceil((float)L.ndesired / L.ncells);
+        if (L.ncells > 1024) { err = "more than 1024 grid cells on a level"; return ORBX_ERR_GEOMETRY; }   // k_quota LDS arrays
         // every cell but the last of a row/column keeps its full cellW+6 view: it must fit the level
         if ((levelCols - 1) * L.cellW > W || (levelRows - 1) * L.cellH > H) {
             err = "level " + std::to_string(l) + ": degenerate cell grid (cell views leave the image in the reference)";

@@ -437,54 +437,66 @@ __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(Batch b) {
 }
 
 // ------------------------------------------------------------------------------------ quotas
-// reference :609-670, one lane per (frame, level); sequential by definition.
+// reference :609-670.  One wave per (frame, level): the lanes gather the cells' counts in parallel into LDS, lane 0
+// runs the reference's (inherently sequential) redistribution loop on the LDS copy, the lanes write the result back.
+constexpr int QUOTA_MAX_CELLS = 1024;   // checked on the host
+
 __global__ __launch_bounds__(64) void k_quota(Batch b) {
+    __shared__ int s_nkeys[QUOTA_MAX_CELLS], s_nret[QUOTA_MAX_CELLS], s_off[QUOTA_MAX_CELLS];
+    __shared__ uint8_t s_thr[QUOTA_MAX_CELLS], s_done[QUOTA_MAX_CELLS], s_skip[QUOTA_MAX_CELLS];
+    __shared__ int s_total;
     const DevGeom& g = b.g;
-    const int idx = blockIdx.x * 64 + threadIdx.x;
-    if (idx >= b.nframes * g.nlevels) return;
-    const int frame = idx / g.nlevels, level = idx - frame * g.nlevels;
+    const int frame = blockIdx.x / g.nlevels, level = blockIdx.x - frame * g.nlevels;
+    const int lane = threadIdx.x;
     const LevelGeom& L = g.lv[level];
     const CellGeom* cg = b.cells + L.cell_base;
     const CellState* cs = b.cstate + (long long)frame * g.nbands_total;   // per band; a cell sums its bands
     CellSel* sel = b.csel + (long long)frame * g.ncells_total + L.cell_base;
     const int nCells = L.ncells, nfc = L.nfeat_cell;
-    int nToDistribute = 0, nNoMore = 0;
-    // csel.out_off doubles as the bNoMore flag during this pass
-    for (int c = 0; c < nCells; c++) {
-        CellSel s;
-        if (cg[c].skipped) {
-            s.thr = g.fast_th; s.nkeys = 0; s.nretain = 0; s.out_off = 0;
-        } else {
-            CellState st;
-            st.n_all = 0; st.n_hi = 0; st.n_lo = 0;
-            for (int k = 0; k < cg[c].nbands; k++) { const CellState t = cs[cg[c].band0 + k]; st.n_all += t.n_all; st.n_hi += t.n_hi; st.n_lo += t.n_lo; }
-            const bool fallback = st.n_hi <= 3;               // :609  size()<=3 -> FAST(...,7,...)
-            s.thr = fallback ? 7 : g.fast_th;
-            s.nkeys = fallback ? st.n_lo : st.n_hi;
-            if (s.nkeys > nfc) { s.nretain = nfc; s.out_off = 0; }
-            else { s.nretain = s.nkeys; nToDistribute += nfc - s.nkeys; s.out_off = 1; nNoMore++; }
-        }
-        sel[c] = s;
+    for (int c = lane; c < nCells; c += 64) {
+        const CellGeom cgc = cg[c];
+        int n_hi = 0, n_lo = 0;
+        for (int k = 0; k < cgc.nbands; k++) { const CellState t = cs[cgc.band0 + k]; n_hi += t.n_hi; n_lo += t.n_lo; }
+        const bool fallback = n_hi <= 3;                      // :609  size()<=3 -> FAST(...,7,...)
+        s_skip[c] = (uint8_t)cgc.skipped;
+        s_thr[c] = (uint8_t)(cgc.skipped || !fallback ? g.fast_th : 7);
+        s_nkeys[c] = cgc.skipped ? 0 : (fallback ? n_lo : n_hi);
     }
-    while (nToDistribute > 0 && nNoMore < nCells) {
-        const int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nCells - nNoMore));
-        nToDistribute = 0;
+    __syncthreads();
+    if (lane == 0) {
+        int nToDistribute = 0, nNoMore = 0;
         for (int c = 0; c < nCells; c++) {
-            CellSel s = sel[c];
-            if (!s.out_off) {
-                if (s.nkeys > nNew) { s.nretain = nNew; }
-                else { s.nretain = s.nkeys; nToDistribute += nNew - s.nkeys; s.out_off = 1; nNoMore++; }
-                sel[c] = s;
+            if (s_skip[c]) { s_nret[c] = 0; s_done[c] = 0; continue; }   // reference `continue`: never reaches the bookkeeping
+            const int nk = s_nkeys[c];
+            if (nk > nfc) { s_nret[c] = nfc; s_done[c] = 0; }
+            else { s_nret[c] = nk; nToDistribute += nfc - nk; s_done[c] = 1; nNoMore++; }
+        }
+        while (nToDistribute > 0 && nNoMore < nCells) {
+            const int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nCells - nNoMore));
+            nToDistribute = 0;
+            for (int c = 0; c < nCells; c++) {
+                if (!s_done[c]) {
+                    const int nk = s_nkeys[c];
+                    if (nk > nNew) { s_nret[c] = nNew; }
+                    else { s_nret[c] = nk; nToDistribute += nNew - nk; s_done[c] = 1; nNoMore++; }
+                }
             }
         }
+        int off = 0;
+        for (int c = 0; c < nCells; c++) { s_off[c] = off; off += s_nret[c]; }
+        if (off > L.sel_cap) { b.status[frame] = ORBX_ERR_CAPACITY; off = -1; }
+        s_total = off;
+        b.level_total[frame * MAX_LEVELS + level] = off < 0 ? 0 : off;
     }
-    int off = 0;
-    for (int c = 0; c < nCells; c++) {
-        sel[c].out_off = off;
-        off += sel[c].nretain;
+    __syncthreads();
+    const bool bad = s_total < 0;
+    for (int c = lane; c < nCells; c += 64) {
+        CellSel r;
+        r.thr = s_thr[c]; r.nkeys = s_nkeys[c];
+        r.nretain = bad ? 0 : s_nret[c];
+        r.out_off = bad ? 0 : s_off[c];
+        sel[c] = r;
     }
-    if (off > L.sel_cap) { b.status[frame] = ORBX_ERR_CAPACITY; off = 0; for (int c = 0; c < nCells; c++) { sel[c].nretain = 0; sel[c].out_off = 0; } }
-    b.level_total[frame * MAX_LEVELS + level] = off;
 }
 
 // ------------------------------------------------------------------------------------ retainBest per cell
@@ -595,7 +607,10 @@ __device__ float harris_response(const uint8_t* img, long long step, int x, int 
 
 // One wave per (frame, cell): ordered __ballot filter of the cell's list at its threshold into LDS, Harris responses
 // in parallel when selected, wave_nth_element, first nToRetain entries out.
-__global__ __launch_bounds__(64) void k_cell_select(Batch b) {
+// Launched twice: lists of up to SEL_SMALL entries with a small LDS footprint (many waves per CU — the common case),
+// longer ones with the full staging area; each launch skips the cells of the other class.
+constexpr int SEL_SMALL = 384;
+__global__ __launch_bounds__(64) void k_cell_select(Batch b, int lds_entries, int min_entries) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const DevGeom& g = b.g;
     const int frame = blockIdx.x / g.ncells_total, cell = blockIdx.x - frame * g.ncells_total;
@@ -612,11 +627,12 @@ __global__ __launch_bounds__(64) void k_cell_select(Batch b) {
     Cand* c = lbase + cgeo.cand_off;
     int n_all = 0;
     for (int k = 0; k < cgeo.nbands; k++) n_all += bst[k].n_all;
+    if (n_all < min_entries || (n_all > lds_entries && lds_entries < g.sel_lds_entries)) return;   // the other launch's class
     Cand* out = b.sel + (long long)frame * g.frame_sel + L.sel_base + s.out_off;
     const float thr = (float)s.thr;
     long long stride;
     const uint8_t* img = plain_plane(b, L, level, frame, stride);
-    if (n_all > g.sel_lds_entries) {
+    if (n_all > lds_entries) {
         // rare: list longer than the LDS staging area -> the plain sequential algorithm in global memory
         // (filtered entries are compacted to the front of the cell's area; the write index never passes the read index)
         if (lane == 0) {
@@ -635,8 +651,8 @@ __global__ __launch_bounds__(64) void k_cell_select(Batch b) {
         return;
     }
     Cand* lst = reinterpret_cast<Cand*>(smem);
-    uint16_t* lpos = reinterpret_cast<uint16_t*>(smem + (size_t)g.sel_lds_entries * sizeof(Cand));
-    uint16_t* rpos = lpos + g.sel_lds_entries;
+    uint16_t* lpos = reinterpret_cast<uint16_t*>(smem + (size_t)lds_entries * sizeof(Cand));
+    uint16_t* rpos = lpos + lds_entries;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int m = 0;
     for (int k = 0; k < cgeo.nbands; k++) {
@@ -1005,7 +1021,7 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     if (stop_after == ST_COMPACT) return ORBX_OK;
     {
         StageScope sc(timer, stream, ST_QUOTA);
-        hipLaunchKernelGGL(k_quota, dim3((F * g.nlevels + 63) / 64), dim3(64), 0, stream, b);
+        hipLaunchKernelGGL(k_quota, dim3(F * g.nlevels), dim3(64), 0, stream, b);
         ORBX_LAUNCH_CHECK();
     }
     if (stop_after == ST_QUOTA) return ORBX_OK;
@@ -1013,7 +1029,10 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         StageScope sc(timer, stream, ST_CELL_SELECT);
         const size_t lds = (size_t)g.sel_lds_cell;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cell_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_cell_select, dim3(F * g.ncells_total), dim3(64), lds, stream, b);
+        const int small = std::min(SEL_SMALL, g.sel_lds_entries);
+        hipLaunchKernelGGL(k_cell_select, dim3(F * g.ncells_total), dim3(64), (size_t)small * (sizeof(Cand) + 4) + 16, stream, b, small, 0);
+        ORBX_LAUNCH_CHECK();
+        if (small < g.sel_lds_entries) hipLaunchKernelGGL(k_cell_select, dim3(F * g.ncells_total), dim3(64), lds, stream, b, g.sel_lds_entries, small + 1);
         ORBX_LAUNCH_CHECK();
     }
     if (stop_after == ST_CELL_SELECT) return ORBX_OK;
