@@ -96,6 +96,9 @@ def test_stage_parity_vga(gpu_extractor_factory, family):
     dict(w=320, h=240, nfeatures=300, nlevels=5),
     dict(w=1920, h=1080, nfeatures=2000),                     # grid cells of 33k px: cut into 4 row bands
     dict(w=1280, h=720, nfeatures=1000),                      # 2 bands per cell on the lower levels
+    dict(w=3840, h=2160, nfeatures=4000),                     # 4K: 130k-px cells, 13 bands each
+    dict(w=160, h=120, nfeatures=100, nlevels=3),             # tiny image, 1-2 cells per level
+    dict(w=200, h=600, nfeatures=400, nlevels=4),             # portrait aspect (more columns than rows in the grid)
     dict(w=640, h=480, nfeatures=1000, scoreType=capi.HARRIS_SCORE),
     dict(w=640, h=480, nfeatures=1000, scaleFactor=1.5, nlevels=4),
     dict(w=640, h=480, nfeatures=1000, fastTh=5),             # fastTh below the fallback threshold 7
