@@ -179,13 +179,14 @@ def main():
         kernel_ms = sum(stage_ms.values())
         pipe_bytes = (a_extract + (a_match if do_match else 0)) * B
         pipe_gbs = pipe_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic = None
+        traffic, valu_busy = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")      # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 if tj.get("workload") == "vga_640x480_nf1000" and tj.get("batch") == B:
                     traffic = tj.get("per_launch_bytes", {}).get(dom)
+                    valu_busy = tj.get("sq_activity", {}).get(dom, {}).get("valu_busy")
             except Exception:
                 traffic = None
         out = {
@@ -208,7 +209,7 @@ def main():
                        "mean_keypoints_per_frame": round(float(counters[1]) / total_frames, 2),
                        "frames_with_error_status": int(counters[2]), "accepted_matches_last_frame": accepted},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(dom_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(dom_gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "valu_busy": valu_busy,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(stage_ms[dom], 4)},
             "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(pipe_gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": pipe_bytes,

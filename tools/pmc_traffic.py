@@ -24,7 +24,24 @@ for k, stage in STAGE.items():
     wb = sum(w[k]) / len(w[k]) * 1024 * n_per_step if k in w else 0.0
     per_launch[stage] = int(fb + wb)
     detail[stage] = {"fetch_bytes": int(fb), "write_bytes": int(wb), "dispatches_sampled": len(f[k])}
-json.dump({"workload": "vga_640x480_nf1000", "batch": batch, "per_launch_bytes": per_launch, "detail": detail,
+# optional: VALU / LDS activity from the SQ counter passes of tools/run_pmc.sh (argv[5] = directory with a_*/b_* CSVs)
+valu = {}
+if len(sys.argv) > 5:
+    d = sys.argv[5]
+    busy = load(d + "/b_counter_collection.csv", "SQ_ACTIVE_INST_VALU")
+    lds = load(d + "/b_counter_collection.csv", "SQ_LDS_IDX_ACTIVE")
+    insts = load(d + "/a_counter_collection.csv", "SQ_INSTS_VALU")
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(d + "/b_kernel_trace.csv")):
+        m = re.search(r"orbx::(k_[a-z_]+)", r["Kernel_Name"])
+        if m: dur[m.group(1)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, stage in STAGE.items():
+        if k in busy and k in dur:
+            cyc = sum(dur[k]) / len(dur[k]) * 1e-9 * 2.4e9
+            valu[stage] = {"valu_busy": round(sum(busy[k]) / len(busy[k]) * 4 / (cyc * 1024), 3),       # quad-cycles -> SIMD cycles, 1024 SIMDs
+                           "lds_busy": round(sum(lds[k]) / len(lds[k]) / (cyc * 256), 3) if k in lds else None,
+                           "valu_wave_insts_per_launch": int(sum(insts[k]) / len(insts[k])) if k in insts else None}
+json.dump({"workload": "vga_640x480_nf1000", "batch": batch, "sq_activity": valu, "per_launch_bytes": per_launch, "detail": detail,
            "read_correction": "none applied (4 B/lane and 1 B/lane accesses; the guide's x2 applies to 16 B/lane reads)",
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py"}, open(out, "w"), indent=1)
 print(json.dumps(per_launch))
