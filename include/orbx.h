@@ -16,6 +16,8 @@
  *   orbm_match_top2[_device|_batch_device]
  *                                   <- the best / second-best scan shared by every ORBmatcher search
  *                                      (src/ORBmatcher.cc:87-111, :201-222, :454-474, :629-650, ...)
+ *   orbm_match_top2_segments[_device]
+ *                                   <- the same scan over a per-query candidate list (window / vocabulary node): "next" row N2
  *   orbm_count_accepted             <- accept rule `best<=TH && (float)best < mfNNratio*(float)second` (src/ORBmatcher.cc:224-226)
  *
  * All compute runs in hand-written HIP kernels for gfx950.  There is NO CPU fallback: every
@@ -116,6 +118,15 @@ int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
 int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const uint8_t* dT, const int32_t* d_nt,
                                  int nbatch, int cap, int32_t* d_best_idx, int32_t* d_best, int32_t* d_second,
                                  void* stream);
+/* Candidate-set form — the shape every ORBmatcher search actually scans (GetFeaturesInArea windows,
+ * src/Frame.cc:200-265; the features of one vocabulary node, src/ORBmatcher.cc:171-260): query q scans the train
+ * descriptors with indices cand[seg_off[q] .. seg_off[q+1]) in LIST order; best_idx = the first listed candidate
+ * attaining the best distance (a train index), -1 / INT_MAX / INT_MAX for an empty list.  seg_off has nq+1 entries;
+ * candidate indices outside [0, nt) are skipped. */
+int orbm_match_top2_segments(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int32_t* seg_off, const int32_t* cand,
+                             int32_t* best_idx, int32_t* best, int32_t* second, int device);
+int orbm_match_top2_segments_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt, const int32_t* d_seg_off,
+                                    const int32_t* d_cand, int32_t* d_best_idx, int32_t* d_best, int32_t* d_second, void* stream);
 /* number of queries passing  best <= th && (float)best < ratio*(float)second  (host arrays) */
 int orbm_count_accepted(const int32_t* best, const int32_t* second, int nq, int th, float ratio);
 

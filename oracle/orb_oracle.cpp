@@ -790,6 +790,21 @@ void orc_match_top2(const uint8_t* Q, int nq, const uint8_t* T, int nt, int32_t*
         best_idx[q] = bestIdx; best[q] = bestDist1; second[q] = bestDist2;
     }
 }
+// the same scan over a per-query candidate list (e.g. src/ORBmatcher.cc:87-111 over vNearIndices, :201-222 over vIndicesF)
+void orc_match_top2_segments(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int32_t* seg_off, const int32_t* cand,
+                             int32_t* best_idx, int32_t* best, int32_t* second) {
+    for (int q = 0; q < nq; q++) {
+        int bestDist1 = INT_MAX, bestIdx = -1, bestDist2 = INT_MAX;
+        for (int p = seg_off[q]; p < seg_off[q + 1]; p++) {
+            const int t = cand[p];
+            if (t < 0 || t >= nt) continue;
+            const int dist = descriptor_distance(Q + (size_t)q * 32, T + (size_t)t * 32);
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx = t; }
+            else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        best_idx[q] = bestIdx; best[q] = bestDist1; second[q] = bestDist2;
+    }
+}
 // accept rule of SearchByBoW (src/ORBmatcher.cc:224-226): best<=th && (float)best < ratio*(float)second
 int orc_count_accepted(const int32_t* best, const int32_t* second, int nq, int th, float ratio) {
     int n = 0;

@@ -26,7 +26,7 @@ EXPORTS = [
     "orbx_default_params", "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_scale_factor",
     "orbx_max_keypoints", "orbx_last_error", "orbx_extract", "orbx_extract_batch_device",
     "orbm_hamming256", "orbm_match_top2", "orbm_match_top2_device", "orbm_match_top2_batch_device",
-    "orbm_count_accepted", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
+    "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
     "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element",
 ]
 
@@ -79,6 +79,8 @@ def lib():
         L.orbm_match_top2_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp]
         L.orbm_match_top2_batch_device.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, vp]
         L.orbm_count_accepted.argtypes = [vp, vp, ci, ci, cf]
+        L.orbm_match_top2_segments.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci]
+        L.orbm_match_top2_segments_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp]
         L.orbx_debug_set_stop_after.argtypes = [vp, ci]
         L.orbx_debug_level_size.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.orbx_debug_fetch.argtypes = [vp, ci, ci, ci, vp, cl]
@@ -215,6 +217,22 @@ def match_top2(Q, T, device=0):
     rc = lib().orbm_match_top2(Q.ctypes.data, nq, T.ctypes.data, nt, idx.ctypes.data, best.ctypes.data, sec.ctypes.data, device)
     if rc != ORBX_OK:
         raise OrbxError(rc, "orbm_match_top2")
+    return idx, best, sec
+
+
+def match_top2_segments(Q, T, seg_off, cand, device=0):
+    """per-query candidate lists (CSR): query q scans T[cand[seg_off[q]:seg_off[q+1]]] in list order"""
+    Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 32)
+    T = np.ascontiguousarray(T, dtype=np.uint8).reshape(-1, 32)
+    seg = np.ascontiguousarray(seg_off, dtype=np.int32)
+    cd = np.ascontiguousarray(cand, dtype=np.int32)
+    nq = len(Q)
+    assert len(seg) == nq + 1
+    idx = np.empty(nq, np.int32); best = np.empty(nq, np.int32); sec = np.empty(nq, np.int32)
+    rc = lib().orbm_match_top2_segments(Q.ctypes.data, nq, T.ctypes.data, len(T), seg.ctypes.data, cd.ctypes.data if len(cd) else None,
+                                        idx.ctypes.data, best.ctypes.data, sec.ctypes.data, device)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbm_match_top2_segments")
     return idx, best, sec
 
 

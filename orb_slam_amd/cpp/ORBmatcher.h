@@ -31,6 +31,19 @@ public:
         if (rc != ORBX_OK) throw std::runtime_error("orbm_match_top2 failed: no usable MI355X / HIP runtime");
     }
 
+    // Candidate-set form of the same scan (GetFeaturesInArea windows, vocabulary-node feature lists): query q scans
+    // T rows cand[segOff[q] .. segOff[q+1]) in list order; bestIdx holds train row indices.
+    void MatchTop2Candidates(const cv::Mat& Q, const cv::Mat& T, const std::vector<int>& segOff, const std::vector<int>& cand,
+                             std::vector<int>& bestIdx, std::vector<int>& bestDist, std::vector<int>& bestDist2) const {
+        const int nq = Q.rows;
+        if ((int)segOff.size() != nq + 1) throw std::runtime_error("MatchTop2Candidates: segOff must have Q.rows+1 entries");
+        bestIdx.assign(nq, -1); bestDist.assign(nq, INT_MAX); bestDist2.assign(nq, INT_MAX);
+        if (nq == 0) return;
+        const int rc = orbm_match_top2_segments(Q.data, nq, T.data, T.rows, segOff.data(), cand.empty() ? nullptr : cand.data(),
+                                                bestIdx.data(), bestDist.data(), bestDist2.data(), device_);
+        if (rc != ORBX_OK) throw std::runtime_error("orbm_match_top2_segments failed");
+    }
+
     // Accept rule of SearchByBoW (reference src/ORBmatcher.cc:224-226) applied to MatchTop2's output
     int CountAccepted(const std::vector<int>& bestDist, const std::vector<int>& bestDist2, int th = TH_LOW) const {
         return orbm_count_accepted(bestDist.data(), bestDist2.data(), (int)bestDist.size(), th, mfNNratio);

@@ -156,6 +156,58 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match_batch(const uint32_t* __r
     }
 }
 
+// Candidate-set form (what every ORBmatcher search really scans: the grid window of GetFeaturesInArea or the features of
+// one vocabulary node): query q scans the train descriptors cand[seg_off[q] .. seg_off[q+1]) IN LIST ORDER.  One wave per
+// query, one candidate per lane and step; key = (distance << 22) | position-in-list keeps the reference's "first candidate
+// attaining the best distance" rule; a butterfly of min / med3 steps reduces the 64 lanes' (k1,k2) pairs.
+__device__ __forceinline__ void top2_merge(uint32_t& k1, uint32_t& k2, uint32_t o1, uint32_t o2) {
+    // two sorted pairs -> the two smallest of the four keys
+    const uint32_t lo = min(k1, o1), hi = max(k1, o1);
+    k2 = min(hi, min(k2, o2));
+    k1 = lo;
+}
+
+__global__ __launch_bounds__(256) void k_match_segments(const uint32_t* __restrict__ Q, int nq, const uint32_t* __restrict__ T, int nt,
+                                                        const int32_t* __restrict__ seg_off, const int32_t* __restrict__ cand,
+                                                        int32_t* __restrict__ idx, int32_t* __restrict__ best, int32_t* __restrict__ second) {
+    const int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (q >= nq) return;
+    const int lane = threadIdx.x & 63;
+    const int s0 = seg_off[q], s1 = seg_off[q + 1];
+    uint32_t qw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) qw[i] = Q[(long long)q * 8 + i];   // wave-uniform: scalar loads
+    uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+    for (int base = s0; base < s1; base += 64) {
+        const int p = base + lane;
+        if (p < s1) {
+            const int t = cand[p];
+            uint32_t key = KEY_NONE - 1;   // invalid candidate index: never wins, never reported
+            if ((unsigned)t < (unsigned)nt) {
+                const uint4* tp = reinterpret_cast<const uint4*>(T + (long long)t * 8);
+                const uint4 a = tp[0], c = tp[1];
+                uint32_t d = 0;
+                d = bcnt_acc(qw[0] ^ a.x, d); d = bcnt_acc(qw[1] ^ a.y, d); d = bcnt_acc(qw[2] ^ a.z, d); d = bcnt_acc(qw[3] ^ a.w, d);
+                d = bcnt_acc(qw[4] ^ c.x, d); d = bcnt_acc(qw[5] ^ c.y, d); d = bcnt_acc(qw[6] ^ c.z, d); d = bcnt_acc(qw[7] ^ c.w, d);
+                key = (d << KEY_SHIFT) | (uint32_t)(p - s0);
+                top2_update(k1, k2, key);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)k1, off, 64), o2 = (uint32_t)__shfl_xor((int)k2, off, 64);
+        top2_merge(k1, k2, o1, o2);
+    }
+    if (lane == 0) {
+        int32_t bi, bd, sd;
+        write_result(k1, k2, &bi, &bd, &sd);
+        idx[q] = bi < 0 ? -1 : cand[s0 + bi];   // list position -> train index
+        best[q] = bd;
+        second[q] = sd;
+    }
+}
+
 struct MatchScratch {
     uint32_t* buf = nullptr;
     size_t bytes = 0;
@@ -229,6 +281,49 @@ int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const u
     hipLaunchKernelGGL(k_match_batch<1>, dim3((cap + MATCH_BLOCK - 1) / MATCH_BLOCK, nbatch), dim3(MATCH_BLOCK), 0, stream, (const uint32_t*)dQ,
                        d_nq, (const uint32_t*)dT, d_nt, cap, d_best_idx, d_best, d_second);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbm_match_top2_segments_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt, const int32_t* d_seg_off, const int32_t* d_cand,
+                                    int32_t* d_best_idx, int32_t* d_best, int32_t* d_second, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nq < 0 || nt < 0 || !d_seg_off || !d_cand) return ORBX_ERR_ARG;
+    if (nq == 0) return ORBX_OK;
+    if (((uintptr_t)dQ & 3) || ((uintptr_t)dT & 15)) return ORBX_ERR_ARG;
+    hipLaunchKernelGGL(k_match_segments, dim3((nq + 3) / 4), dim3(256), 0, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt, d_seg_off,
+                       d_cand, d_best_idx, d_best, d_second);
+    return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbm_match_top2_segments(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int32_t* seg_off, const int32_t* cand, int32_t* best_idx,
+                             int32_t* best, int32_t* second, int device) {
+    if (nq < 0 || nt < 0 || !seg_off || (nq > 0 && seg_off[nq] > 0 && !cand)) return ORBX_ERR_ARG;
+    if (nq == 0) return ORBX_OK;
+    const int ncand = seg_off[nq];
+    if (ncand < 0 || ncand >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
+    for (int q = 0; q < nq; q++)
+        if (seg_off[q] > seg_off[q + 1] || seg_off[q] < 0) return ORBX_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    uint8_t *dQ = nullptr, *dT = nullptr;
+    int32_t *dseg = nullptr, *dcand = nullptr, *dout = nullptr;
+    int rc = ORBX_ERR_DEVICE;
+    if (hipMalloc(&dQ, (size_t)nq * 32) == hipSuccess && hipMalloc(&dT, (size_t)std::max(nt, 1) * 32) == hipSuccess &&
+        hipMalloc(&dseg, (size_t)(nq + 1) * 4) == hipSuccess && hipMalloc(&dcand, (size_t)std::max(ncand, 1) * 4) == hipSuccess &&
+        hipMalloc(&dout, (size_t)nq * 12) == hipSuccess && hipMemcpy(dQ, Q, (size_t)nq * 32, hipMemcpyHostToDevice) == hipSuccess &&
+        (nt == 0 || hipMemcpy(dT, T, (size_t)nt * 32, hipMemcpyHostToDevice) == hipSuccess) &&
+        hipMemcpy(dseg, seg_off, (size_t)(nq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+        (ncand == 0 || hipMemcpy(dcand, cand, (size_t)ncand * 4, hipMemcpyHostToDevice) == hipSuccess)) {
+        rc = orbm_match_top2_segments_device(dQ, nq, dT, nt, dseg, dcand, dout, dout + nq, dout + 2 * (size_t)nq, nullptr);
+        if (rc == ORBX_OK && (hipMemcpy(best_idx, dout, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                              hipMemcpy(best, dout + nq, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                              hipMemcpy(second, dout + 2 * (size_t)nq, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess))
+            rc = ORBX_ERR_DEVICE;
+    }
+    if (dQ) (void)hipFree(dQ);
+    if (dT) (void)hipFree(dT);
+    if (dseg) (void)hipFree(dseg);
+    if (dcand) (void)hipFree(dcand);
+    if (dout) (void)hipFree(dout);
+    return rc;
 }
 
 int orbm_match_top2(const uint8_t* Q, int nq, const uint8_t* T, int nt, int32_t* best_idx, int32_t* best, int32_t* second, int device) {

@@ -51,6 +51,7 @@ def lib():
         L.orc_hamming256.argtypes = [c_void_p, c_void_p]
         L.orc_match_top2.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
         L.orc_count_accepted.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float]
+        L.orc_match_top2_segments.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         _LIB = L
     return _LIB
 
@@ -173,3 +174,15 @@ def nth_element_perm(responses, nth):
     out = np.empty(len(r), dtype=np.int32)
     lib().orc_nth_element_perm(r.ctypes.data, len(r), nth, out.ctypes.data)
     return out
+
+
+def match_top2_segments(Q, T, seg_off, cand):
+    Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 32)
+    T = np.ascontiguousarray(T, dtype=np.uint8).reshape(-1, 32)
+    seg = np.ascontiguousarray(seg_off, dtype=np.int32)
+    cd = np.ascontiguousarray(cand, dtype=np.int32)
+    nq = len(Q)
+    idx = np.empty(nq, np.int32); best = np.empty(nq, np.int32); sec = np.empty(nq, np.int32)
+    lib().orc_match_top2_segments(Q.ctypes.data, nq, T.ctypes.data, len(T), seg.ctypes.data, cd.ctypes.data if len(cd) else None,
+                                  idx.ctypes.data, best.ctypes.data, sec.ctypes.data)
+    return idx, best, sec

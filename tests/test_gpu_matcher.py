@@ -79,3 +79,36 @@ def test_full_size_properties():
     np.testing.assert_array_equal(gi[sample], ri)
     np.testing.assert_array_equal(gs[sample], rs)
     assert capi.count_accepted(gb, gs, 50, 0.6) == orc.lib().orc_count_accepted(gb.ctypes.data, gs.ctypes.data, n, 50, 0.6)
+
+
+def _random_segments(rng, nq, nt, max_len):
+    lens = rng.integers(0, max_len + 1, nq)
+    lens[rng.integers(0, nq, max(nq // 10, 1))] = 0                       # empty candidate sets
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cand = rng.integers(0, nt, int(seg[-1])).astype(np.int32)            # unsorted, with repeats
+    return seg, cand
+
+
+@pytest.mark.parametrize("nq,nt,max_len", [(1, 10, 5), (100, 1000, 40), (1000, 1000, 130), (257, 5000, 300), (2000, 2000, 64)])
+def test_candidate_lists(nq, nt, max_len):
+    """window / vocabulary-node candidate sets: scan in LIST order, first listed candidate wins ties"""
+    rng = np.random.default_rng(nq + nt)
+    Q, T = synth.descriptors(nq, 3), synth.descriptors(nt, 4)
+    T[: nt // 3] = T[0]                                                   # heavy duplication -> ties decided by list order
+    seg, cand = _random_segments(rng, nq, nt, max_len)
+    gi, gb, gs = capi.match_top2_segments(Q, T, seg, cand)
+    ri, rb, rs = orc.match_top2_segments(Q, T, seg, cand)
+    np.testing.assert_array_equal(gb, rb)
+    np.testing.assert_array_equal(gs, rs)
+    np.testing.assert_array_equal(gi, ri)
+
+
+def test_candidate_lists_equal_dense_when_lists_are_full():
+    nq, nt = 300, 500
+    Q, T = synth.descriptors(nq, 8), synth.descriptors(nt, 9)
+    seg = (np.arange(nq + 1) * nt).astype(np.int32)
+    cand = np.tile(np.arange(nt, dtype=np.int32), nq)
+    a = capi.match_top2_segments(Q, T, seg, cand)
+    b = capi.match_top2(Q, T)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
