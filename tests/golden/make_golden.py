@@ -5,7 +5,7 @@ The reference has no tests / golden vectors of its own and canno
 vectors are OUR oracle's outputs on exact-integer synthetic frames: they pin the oracle against drift and
 let the GPU tests run without the oracle.  Re-run only when the oracle definition changes on purpose."""
 import hashlib, json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib as orc

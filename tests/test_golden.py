@@ -1,4 +1,4 @@
-"""Committed golden vectors (tests/golden/, made by tools/make_golden.py from the oracle):
+"""Committed golden vectors (tests/golden/, made by tests/golden/make_golden.py from the oracle):
 CPU: the oracle still reproduces them (pins the oracle); GPU: the HIP path reproduces them without the oracle."""
 import hashlib
 import json
