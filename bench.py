@@ -42,8 +42,7 @@ def algorithmic_bytes(w, h, nkp, nlevels=8):
     p_total, p0 = sum(P), P[0]
     per_stage = {
         "pyramid": sum(P[:-1]) + sum(P[1:]),          # every source level read once, every derived level written once
-        "fast_nms": p_total,                          # every pyramid pixel enters the ring test once
-        "compact": p_total,                           # survivor map walked once
+        "fast_cells": p_total,                        # every pyramid pixel enters the ring test once
         "blur": 2 * p_total,                          # read + write of every level
         "describe": nkp * (749 + 512 + 60),           # patch + BRIEF taps + outputs per keypoint
     }

@@ -135,8 +135,8 @@ int orbm_count_accepted(const int32_t* best, const int32_t* second, int nq, int 
 #define ORBX_DBG_BLUR       1   /* blurred level plane, tight w*h bytes */
 #define ORBX_DBG_NMS        2   /* per-pixel FAST score of NMS survivors (0 elsewhere), tight w*h bytes */
 #define ORBX_DBG_LEVEL_KPS  3   /* selected keypoints of a level before orientation: int32 triples (x,y,response bits) */
-/* run the kernel sequence only up to `stage` (0 pyramid, 1 FAST+NMS, 2 cell lists, 3 quotas, 4 per-cell
- * retainBest, 5 per-level cap, 6 blur, 7 describe); <0 = everything (default) */
+/* run the kernel sequence only up to `stage` (0 pyramid, 1 FAST + NMS + cell lists, 2 quotas, 3 per-cell retainBest,
+ * 4 per-level cap, 5 blur, 6 describe); <0 = everything (default) */
 int orbx_debug_set_stop_after(orbx_extractor* h, int stage);
 /* per-stage GPU time from HIP events recorded on the launch stream: enable = 0 off, 1 on, 2 on + reset totals.
  * orbx_debug_stage_time synchronises the device and returns the accumulated ms / launch-group count of a stage. */

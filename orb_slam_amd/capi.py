@@ -16,7 +16,7 @@ ORBX_ERR_ARG, ORBX_ERR_DEVICE, ORBX_ERR_CAPACITY, ORBX_ERR_GEOMETRY = -1, -2, -3
 HARRIS_SCORE, FAST_SCORE = 0, 1
 BLUR_X86_SSE2, BLUR_HALF_UP = 0, 1
 DBG_PLANE, DBG_BLUR, DBG_NMS, DBG_LEVEL_KPS = 0, 1, 2, 3
-(ST_PYRAMID, ST_FAST_NMS, ST_COMPACT, ST_QUOTA, ST_CELL_SELECT, ST_LEVEL_SELECT, ST_BLUR, ST_DESCRIBE) = range(8)
+(ST_PYRAMID, ST_FAST_CELLS, ST_QUOTA, ST_CELL_SELECT, ST_LEVEL_SELECT, ST_BLUR, ST_DESCRIBE) = range(7)
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -158,7 +158,7 @@ class ORBextractor:
     def set_stop_after(self, stage):
         self.L.orbx_debug_set_stop_after(self.h, stage)
 
-    STAGE_NAMES = ["pyramid", "fast_nms", "compact", "quota", "cell_select", "level_select", "blur", "describe"]
+    STAGE_NAMES = ["pyramid", "fast_cells", "quota", "cell_select", "level_select", "blur", "describe"]
 
     def stage_timing(self, enable):
         """0 off, 1 on, 2 on + reset"""

@@ -85,7 +85,7 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
     // --- per-level geometry
     const float imageRatio = (float)w / h;   // level 0 cols/rows (:526)
     int plane_off = 0, cell_base = 0, cand_base = 0, sel_base = 0, slot_base = 0;
-    int tile_base = 0, btile_base = 0, flagx = 0, flagy = 0;
+    int btile_base = 0;
     for (int l = 0; l < nl; l++) {
         LevelGeom& L = g.lv[l];
         const float s = out.inv_scale[l];
@@ -189,29 +189,7 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
         L.slot_base = slot_base;
         slot_base += L.ndesired;
 
-        // cell-boundary flags for the cell-local NMS (neighbours in another cell count as 0)
-        L.flag_off_x = flagx;
-        L.flag_off_y = flagy;
-        out.flagx.resize(flagx + L.w, 0);
-        out.flagy.resize(flagy + L.h, 0);
-        for (int x = minB; x < maxBX; x++) {
-            int j = std::min((x - minB) / L.cellW, levelCols - 1);
-            int x0 = minB + j * L.cellW, x1 = (j == levelCols - 1) ? maxBX - 1 : x0 + L.cellW - 1;
-            out.flagx[flagx + x] = (uint8_t)((x == x0 ? 1 : 0) | (x == x1 ? 2 : 0) | 4);
-        }
-        for (int y = minB; y < maxBY; y++) {
-            int i = std::min((y - minB) / L.cellH, levelRows - 1);
-            int y0 = minB + i * L.cellH, y1 = (i == levelRows - 1) ? maxBY - 1 : y0 + L.cellH - 1;
-            out.flagy[flagy + y] = (uint8_t)((y == y0 ? 1 : 0) | (y == y1 ? 2 : 0) | 4);
-        }
-        flagx += L.w;
-        flagy += L.h;
-
-        // tilings
-        L.tiles_x = (W + TILE_W - 1) / TILE_W;
-        L.tiles_y = (H + TILE_H - 1) / TILE_H;
-        L.tile_base = tile_base;
-        tile_base += L.tiles_x * L.tiles_y;
+        // blur work items
         L.btiles_x = (L.w + 247) / 248;        // blur: 248-px column strips x 32-row bands, one wave each
         L.btiles_y = (L.h + 31) / 32;
         L.btile_base = btile_base;
@@ -288,7 +266,6 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
     }
     g.ncells_total = cell_base;
     g.nbands_total = (int)out.bands.size();
-    g.ntiles_total = tile_base;
     g.nbtiles_total = btile_base;
     g.nslots = slot_base;
     g.frame_plane_bytes = align_up(plane_off, 256);

@@ -12,8 +12,6 @@ namespace orbx {
 constexpr int MAX_LEVELS = 16;
 constexpr int EDGE = 16;        // EDGE_THRESHOLD, reference src/ORBextractor.cc:77
 constexpr int HALF_PATCH = 15;  // HALF_PATCH_SIZE, :76
-constexpr int TILE_W = 64;      // FAST/NMS and blur tile (pixels)
-constexpr int TILE_H = 32;
 
 // One detected corner that survived NMS.  resp is the float response the reference sorts by
 // (FAST score, or Harris when score_type==HARRIS_SCORE).
@@ -40,8 +38,6 @@ struct LevelGeom {
     int sel_base, sel_cap; // selected-keypoint list of this level in one frame's sel block
     int slot_base;         // prefix of ndesired over levels (descriptor-kernel slot -> level map)
     int tabx_off, taby_off;// offsets into the ResizeX / ResizeY tables (level >= 1)
-    int flag_off_x, flag_off_y;   // offsets into the column / row cell-boundary flag tables
-    int tile_base, tiles_x, tiles_y;   // 64x32 tiling of the scan area [16,w-17]x[16,h-17]
     int btile_base, btiles_x, btiles_y;// blur wave tasks: 248-px strips x 32-row bands of the whole plane
     int blur_wvec;         // columns x < blur_wvec round ties-to-even (SSE2 emulation), others half-up
     int blur_sel_last, blur_sel_halo;   // v_perm selectors building the reflect-101 bytes of the last / right-halo dword of a row
@@ -76,7 +72,7 @@ struct DevGeom {
     int nlevels;
     int ncells_total;
     int nbands_total;        // k_fast_cells work items per frame (>= ncells_total)
-    int ntiles_total, nbtiles_total;
+    int nbtiles_total;
     int nslots;              // sum of ndesired (max keypoints per frame)
     int score_type, fast_th, tmin;
     int frame_plane_bytes;   // bytes of one frame's pyramid block (== blur block == nms block)
@@ -100,13 +96,10 @@ struct Batch {
     const BandGeom* bands;
     const ResizeX* tabx;
     const ResizeY* taby;
-    const uint8_t* flagx;     // per column: bit0 = first column of its cell, bit1 = last column of its cell
-    const uint8_t* flagy;
     const uint8_t* img;       // level 0 (caller's frames)
     long long img_row_stride, img_frame_stride;
     uint8_t* pyr;             // [frame][frame_plane_bytes]  levels >= 1 (level-0 slot unused)
     uint8_t* blur;            // [frame][frame_plane_bytes]
-    uint8_t* nms;             // [frame][frame_plane_bytes]
     Cand* cand;               // [frame][frame_cands]
     Cand* sel;                // [frame][frame_sel]
     CellState* cstate;        // [frame][nbands_total]  (per band: survivors, and how many reach fastTh / 7)
@@ -130,7 +123,6 @@ struct HostGeom {
     std::vector<BandGeom> bands;
     std::vector<ResizeX> tabx;
     std::vector<ResizeY> taby;
-    std::vector<uint8_t> flagx, flagy;
     std::vector<int> features_per_level;
     std::vector<float> scale, inv_scale;
 };
@@ -138,7 +130,7 @@ struct HostGeom {
 // Fills `out` for a w x h input; returns ORBX_OK / ORBX_ERR_GEOMETRY / ORBX_ERR_ARG.
 int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::string& err);
 
-enum Stage { ST_PYRAMID = 0, ST_FAST_NMS, ST_COMPACT, ST_QUOTA, ST_CELL_SELECT, ST_LEVEL_SELECT, ST_BLUR, ST_DESCRIBE, ST_COUNT };
+enum Stage { ST_PYRAMID = 0, ST_FAST_CELLS, ST_QUOTA, ST_CELL_SELECT, ST_LEVEL_SELECT, ST_BLUR, ST_DESCRIBE, ST_COUNT };
 
 // Optional per-stage timing with HIP events recorded on the launch stream (diagnostics / bench roofline).
 struct StageTimer {

@@ -1005,7 +1005,7 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     };
     const bool overlap = side && side->aux && stop_after < 0;
     {
-        StageScope sc(timer, stream, ST_FAST_NMS);
+        StageScope sc(timer, stream, ST_FAST_CELLS);
         const bool aligned = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
         const size_t lds = (size_t)g.fast_lds_bytes;
         if (lds > 64 * 1024) {   // opt in to > 64 KiB dynamic LDS (big cells, e.g. 1080p)
@@ -1017,14 +1017,13 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nblk), dim3(FAST_THREADS), lds, stream, b);
         ORBX_LAUNCH_CHECK();
     }
-    if (stop_after == ST_FAST_NMS) return ORBX_OK;
+    if (stop_after == ST_FAST_CELLS) return ORBX_OK;
     if (overlap) {
         // fork: the VALU-bound blur runs on the side stream next to the latency-bound quota / retainBest kernels
         if (hipEventRecord(side->fork, stream) != hipSuccess || hipStreamWaitEvent(side->aux, side->fork, 0) != hipSuccess) return ORBX_ERR_DEVICE;
         if (launch_blur(side->aux) != ORBX_OK) return ORBX_ERR_DEVICE;
         if (hipEventRecord(side->join, side->aux) != hipSuccess) return ORBX_ERR_DEVICE;
     }
-    if (stop_after == ST_COMPACT) return ORBX_OK;
     {
         StageScope sc(timer, stream, ST_QUOTA);
         hipLaunchKernelGGL(k_quota, dim3(F * g.nlevels), dim3(64), 0, stream, b);

@@ -59,7 +59,7 @@ def test_stage_parity_vga(gpu_extractor_factory, family):
     for l in range(nl):
         np.testing.assert_array_equal(ex.fetch_plane(capi.DBG_BLUR, l), orc.gaussian_blur7(o.level_plane(l, 0)), err_msg="blur level %d" % l)
     # FAST score + cell-local NMS map at tmin = 7 (survivor lists are permuted by the later stages: stop after FAST)
-    ex.set_stop_after(capi.ST_FAST_NMS)
+    ex.set_stop_after(capi.ST_FAST_CELLS)
     ex(img)
     nms_planes = [ex.fetch_plane(capi.DBG_NMS, l) for l in range(nl)]
     ex.set_stop_after(-1)

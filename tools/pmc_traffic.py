@@ -6,7 +6,7 @@ kernels read 4 B/lane (dword) or 1 B/lane, for which the guide gives no correcti
 and `read_correction` records that no factor was applied."""
 import csv, json, re, sys, collections
 fetch_csv, write_csv, out, batch = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-STAGE = {"k_resize": "pyramid", "k_fast_cells": "fast_nms", "k_quota": "quota", "k_cell_select": "cell_select",
+STAGE = {"k_resize": "pyramid", "k_fast_cells": "fast_cells", "k_quota": "quota", "k_cell_select": "cell_select",
          "k_level_select": "level_select", "k_blur": "blur", "k_describe": "describe", "k_match_batch": "match"}
 def load(path, counter):
     acc = collections.defaultdict(list)
