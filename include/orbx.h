@@ -146,6 +146,9 @@ int orbx_debug_level_size(const orbx_extractor* h, int level, int* w, int* hgt);
 /* copies stage data of `frame` (index inside the last batch) / `level` into host memory; returns bytes or <0 */
 long orbx_debug_fetch(orbx_extractor* h, int what, int frame, int level, void* host_out, long cap_bytes);
 /* evaluate the device arithmetic on arrays (kind 0: fast_atan2(in0,in1)->out0; kind 1: sincos(in0)->out0,out1) */
+/* host-only (needs no GPU): the geometry the library derives for a w x h image — per level 8 ints
+ * {w, h, quota, grid_cols, grid_rows, cell_w, cell_h, n_bands}; returns the number of levels or an ORBX_ERR_* code */
+int orbx_debug_geometry(const orbx_params* p, int w, int hgt, int32_t* out, int cap_levels);
 /* the wave-parallel std::nth_element (greater-by-response) used by the retainBest kernels, on one list:
  * out_perm[i] = original index of the element that ends up at position i (n <= 13000) */
 int orbx_debug_nth_element(const float* resp, int n, int nth, int32_t* out_perm, int device);

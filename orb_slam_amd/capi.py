@@ -27,7 +27,7 @@ EXPORTS = [
     "orbx_max_keypoints", "orbx_last_error", "orbx_extract", "orbx_extract_batch_device",
     "orbm_hamming256", "orbm_match_top2", "orbm_match_top2_device", "orbm_match_top2_batch_device",
     "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
-    "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element",
+    "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element", "orbx_debug_geometry",
 ]
 
 
@@ -87,6 +87,7 @@ def lib():
         L.orbx_debug_fetch.restype = cl
         L.orbx_debug_eval_math.argtypes = [ci, vp, vp, vp, vp, ci, ci]
         L.orbx_debug_nth_element.argtypes = [vp, ci, ci, vp, ci]
+        L.orbx_debug_geometry.argtypes = [ctypes.POINTER(Params), ci, ci, vp, ci]
         L.orbx_debug_stage_timing.argtypes = [vp, ci]
         L.orbx_debug_stage_time.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(cl)]
         _LIB = L
@@ -252,6 +253,20 @@ def count_accepted(best, second, th=50, ratio=0.6):
     best = np.ascontiguousarray(best, dtype=np.int32)
     second = np.ascontiguousarray(second, dtype=np.int32)
     return lib().orbm_count_accepted(best.ctypes.data, second.ctypes.data, len(best), th, ratio)
+
+
+def geometry(w, h, nfeatures=1000, scaleFactor=1.2, nlevels=8, scoreType=FAST_SCORE, fastTh=20):
+    """host-side geometry (no GPU needed): list of dicts per level, or raises OrbxError"""
+    L = lib()
+    p = Params()
+    L.orbx_default_params(ctypes.byref(p))
+    p.nfeatures, p.scale_factor, p.nlevels, p.score_type, p.fast_th = nfeatures, scaleFactor, nlevels, scoreType, fastTh
+    out = np.zeros((16, 8), np.int32)
+    rc = L.orbx_debug_geometry(ctypes.byref(p), w, h, out.ctypes.data, 16)
+    if rc < 0:
+        raise OrbxError(rc, "orbx_debug_geometry")
+    keys = ("w", "h", "quota", "grid_cols", "grid_rows", "cell_w", "cell_h", "n_bands")
+    return [dict(zip(keys, map(int, out[l]))) for l in range(rc)]
 
 
 def nth_element_perm(resp, nth, device=0):

@@ -347,6 +347,23 @@ long orbx_debug_fetch(orbx_extractor* h, int what, int frame, int level, void* h
     return ORBX_ERR_ARG;
 }
 
+int orbx_debug_geometry(const orbx_params* p, int w, int hgt, int32_t* out, int cap_levels) {
+    if (!p || !out) return ORBX_ERR_ARG;
+    HostGeom hg;
+    std::string err;
+    const int rc = build_geometry(*p, w, hgt, hg, err);
+    if (rc != ORBX_OK) return rc;
+    if (cap_levels < hg.g.nlevels) return ORBX_ERR_CAPACITY;
+    for (int l = 0; l < hg.g.nlevels; l++) {
+        const LevelGeom& L = hg.g.lv[l];
+        int nb = 0;
+        for (const BandGeom& b : hg.bands) nb += b.level == l;
+        int32_t* o = out + 8 * l;
+        o[0] = L.w; o[1] = L.h; o[2] = L.ndesired; o[3] = L.gcols; o[4] = L.grows; o[5] = L.cellW; o[6] = L.cellH; o[7] = nb;
+    }
+    return hg.g.nlevels;
+}
+
 int orbx_debug_nth_element(const float* resp, int n, int nth, int32_t* out_perm, int device) {
     if (!resp || !out_perm || n < 1 || nth < 0 || nth > n || n > 13000) return ORBX_ERR_ARG;
     if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;

@@ -1,0 +1,55 @@
+"""Host logic of the product without a GPU: the geometry liborbx derives from (constructor args, image size) must equal
+the oracle's (which follows the reference's float/double arithmetic) and the numbers SURVEY.md §8d derived independently."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from orb_slam_amd import capi, synth
+
+
+def test_vga_geometry_matches_survey():
+    g = capi.geometry(640, 480, nfeatures=1000)
+    assert [(l["w"], l["h"]) for l in g] == [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
+    assert [l["quota"] for l in g] == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert [(l["grid_cols"], l["grid_rows"]) for l in g] == [(5, 6), (5, 6), (4, 5), (4, 5), (3, 4), (3, 4), (3, 4), (3, 4)]
+    assert [(l["cell_w"], l["cell_h"]) for l in g] == [(122, 75), (101, 62), (103, 61), (85, 50), (93, 50), (75, 41), (61, 33), (49, 26)]
+    assert all(l["n_bands"] == l["grid_cols"] * l["grid_rows"] for l in g)       # VGA cells are single-band
+
+
+def test_hd_and_init_extractor_geometry():
+    g = capi.geometry(1920, 1080, nfeatures=2000)
+    assert [l["quota"] for l in g] == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert [(l["grid_cols"], l["grid_rows"]) for l in g] == [(6, 10), (6, 10), (5, 8), (5, 8), (4, 7), (4, 7), (4, 7), (3, 5)]
+    assert g[0]["n_bands"] > g[0]["grid_cols"] * g[0]["grid_rows"]                 # 33k-px cells are cut into row bands
+    gi = capi.geometry(640, 480, nfeatures=2000)                                  # the reference's init extractor
+    assert [(l["grid_cols"], l["grid_rows"]) for l in gi] == [(8, 10), (7, 9), (6, 8), (6, 8), (5, 6), (5, 6), (4, 5), (4, 5)]
+
+
+@pytest.mark.parametrize("w,h,kw", [(752, 480, dict(nfeatures=1000)), (641, 479, dict(nfeatures=500)), (320, 240, dict(nfeatures=300, nlevels=5)),
+                                    (640, 480, dict(nfeatures=1000, scaleFactor=1.5, nlevels=4)), (3840, 2160, dict(nfeatures=4000)),
+                                    (200, 600, dict(nfeatures=400, nlevels=4))])
+def test_geometry_equals_oracle(w, h, kw):
+    g = capi.geometry(w, h, **kw)
+    o = orc.OracleExtractor(dumps=True, **kw)
+    o(synth.frame(w, h, synth.FLAT, 0))
+    assert [(l["w"], l["h"]) for l in g] == [o.level_size(i) for i in range(len(g))]
+    assert [l["quota"] for l in g] == o.features_per_level()
+    # the oracle's cell dump gives the grid: cells per level and their view sizes (cell + 6 px, clipped at the last row/col)
+    cells = o.cells()
+    for lvl, l in enumerate(g):
+        mine = [c for c, _ in cells if c[0] == lvl]
+        assert len(mine) <= l["grid_cols"] * l["grid_rows"]
+        first = [c for c in mine if c[1] == 0 and c[2] == 0][0]
+        if l["grid_cols"] > 1:
+            assert first[6] == l["cell_w"] + 6
+        if l["grid_rows"] > 1:
+            assert first[7] == l["cell_h"] + 6
+
+
+def test_geometry_errors():
+    with pytest.raises(capi.OrbxError) as e:
+        capi.geometry(100, 80)                       # top levels smaller than the 16-px border + FAST ring
+    assert e.value.code == capi.ORBX_ERR_GEOMETRY
+    with pytest.raises(capi.OrbxError) as e:
+        capi.geometry(640, 480, nlevels=40)
+    assert e.value.code == capi.ORBX_ERR_ARG
