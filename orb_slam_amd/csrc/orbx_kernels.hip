@@ -5,8 +5,8 @@
 // Stage            reference (under /root/reference/src/ORBextractor.cc)        kernel
 //   pyramid        ComputePyramid :781-822 (cv::resize INTER_LINEAR)             k_resize (per level, 7 launches)
 //   FAST + NMS     cv::FAST(cell, th, true) :607/:613 + raster-ordered cell lists  k_fast_cells (one workgroup per grid cell)
-//   quotas         :622-670                                                      k_quota      (sequential, one lane per level)
-//   retainBest     :683-685 (per cell), :697-701 (per level)                     k_cell_select / k_level_select (libstdc++ introselect)
+//   quotas         :622-670                                                      k_quota      (one wave per level; lane 0 runs the sequential rule)
+//   retainBest     :683-685 (per cell), :697-701 (per level)                     k_cell_select / k_level_select (wave-parallel, permutation-exact introselect)
 //   blur           GaussianBlur 7x7 s=2 :760                                     k_blur
 //   orientation    IC_Angle :124-151, descriptor :155-194, scaling :769-775      k_describe   (one wave per keypoint)
 //
@@ -146,17 +146,20 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
 }
 
 // ------------------------------------------------------------------------------------ FAST + NMS + cell lists
-// One workgroup = one grid cell of one level of one frame — the unit the reference calls cv::FAST on
-// (src/ORBextractor.cc:599-614).  Because the NMS of cv::FAST never looks outside the cell view, a
-// cell-native workgroup needs no score halo, no survivor plane in HBM and no separate compaction pass:
-//   1. stage the cell's pixels (+3 halo) in LDS with dword loads;
-//   2. per 1024-pixel round, every lane runs a cheap exact-necessary test on 4 pixels (each opposite ring
-//      pair {k,k+8} must contain a pixel beyond the threshold) and the survivors are queued in LDS by
-//      __ballot/popcount; the full FAST-9 score (9-arc extrema of the RAW ring bytes by two rounds of
-//      v_min3/v_max3: dark = v - min_arcs(max9), bright = max_arcs(min9) - v) then runs on the dense queue;
-//   3. 3x3 strict NMS from the LDS score array, one 64-pixel raster chunk per wave step; the survivor
-//      ballots are kept, a wave-level scan turns their popcounts into list offsets, and the cell's keypoint
-//      list comes out in cv::FAST's raster order together with its counts at fastTh and at 7.
+// One workgroup = one grid cell of one level of one frame (or one row band of a big cell) — the unit the reference
+// calls cv::FAST on (src/ORBextractor.cc:599-614).  Because the NMS of cv::FAST never looks outside the cell view, a
+// cell-native workgroup needs no score halo towards other cells, no survivor plane in HBM and no compaction pass:
+//   1. stage the cell's pixels (+3 halo) in LDS with pipelined dword loads;
+//   2. rounds of 2048 pixels —
+//      A1: every lane tests 4 pixels against the 4 compass ring pixels (two of them, with one polarity, must be beyond the
+//          threshold: exact necessary condition); survivors are queued in LDS by __ballot/popcount;
+//      A2: dense over that queue, OpenCV's opposite-pair pre-test on the raw ring bytes; survivors queued again;
+//      B : dense over those, the exact FAST-9 score (9-arc extrema of the RAW ring bytes by two rounds of
+//          v_min3/v_max3: dark = v - min_arcs(max9), bright = max_arcs(min9) - v);
+//      N : 3x3 strict NMS, dense over the PREVIOUS round's scored pixels (all their neighbours are scored by then);
+//          survivors of the band's own rows set their bit in an LDS bitmask;
+//   3. a wave-level scan over the bitmask popcounts gives list offsets and the keypoint list comes out in cv::FAST's
+//      raster order together with its counts at fastTh and at 7.
 constexpr int FAST_THREADS = 512;     // 8 waves per cell: more work between barriers, full CU occupancy at ~35 KB LDS per cell
 constexpr int FAST_PPT = 4;           // pixels per lane per round
 constexpr int FAST_ROUND = FAST_THREADS * FAST_PPT;   // pixels per round
