@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
 constexpr int FAST_THREADS = 512;     // 8 waves per cell: more work between barriers, full CU occupancy at ~35 KB LDS per cell
 constexpr int FAST_PPT = 4;           // pixels per lane per round
 constexpr int FAST_ROUND = FAST_THREADS * FAST_PPT;   // pixels per round
+constexpr int FAST_QCAP = FAST_ROUND + 512;   // queue capacity: a batch is flushed once it holds more than FAST_QCAP - FAST_ROUND survivors
 constexpr int FAST_MAX_ROUNDS = 32;   // cells hold < 65536 pixels (checked on the host)
 
 struct FastLds {
@@ -238,8 +239,8 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
     unsigned long long* cmask = reinterpret_cast<unsigned long long*>(smem + sizeof(FastLds));
     int* coffs = reinterpret_cast<int*>(smem + sizeof(FastLds) + g.fast_max_chunks * 8);
     uint16_t* q1 = reinterpret_cast<uint16_t*>(smem + sizeof(FastLds) + g.fast_max_chunks * 12);
-    uint16_t* q2 = q1 + FAST_ROUND;                 // two buffers: the NMS of round i-1 runs while round i is being scored
-    uint8_t* s_sc = reinterpret_cast<uint8_t*>(q2 + 2 * FAST_ROUND);
+    uint16_t* q2 = q1 + FAST_QCAP;                  // two buffers: the NMS of batch i-1 runs after batch i has been scored
+    uint8_t* s_sc = reinterpret_cast<uint8_t*>(q2 + 2 * FAST_QCAP);
     uint8_t* s_img = s_sc + g.fast_max_px;
     // image region: rows y0-3..y1+3, columns from the dword-aligned start at or left of x0-3
     const int gxb = (cg.x0 - 3) & ~3;
@@ -313,9 +314,14 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
         }
     };
 
-    int rnd = 0;
-    for (int base = 0; base < ((b.dbg & 4) ? imin(npx, 1) : npx); base += FAST_ROUND, rnd++) {
-        uint16_t* q2cur = q2 + (rnd & 1) * FAST_ROUND;
+    // Rounds of 2048 pixels run A1 and append to q1; the later phases run per BATCH of rounds, flushed once q1 holds more
+    // than FAST_QCAP - FAST_ROUND entries (or at the end): on ordinary images one or two flushes per cell instead of one
+    // per round, i.e. fewer barriers and full waves in A2 / B / N.  Batches cover whole rounds (> 1 pixel row each), so the
+    // neighbours of a batch's pixels lie in the previous, the same or the next batch: N lags by one batch.
+    int batch = 0, rnd = 0, qfill = 0;   // qfill: entries in q1 (block-uniform; every lane adds the final per-round counts)
+    const int npx_scan = (b.dbg & 4) ? imin(npx, 1) : npx;
+    for (int base = 0; base < npx_scan; base += FAST_ROUND, rnd++) {
+        uint16_t* q2cur = q2 + (batch & 1) * FAST_QCAP;
         // A1: compass test on every pixel
         {
             int pass[FAST_PPT];
@@ -349,7 +355,7 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
             }
             if (cnt) {
                 int qb = 0;
-                if (lane == 0) qb = atomicAdd(&hdr->n1[rnd], cnt);
+                if (lane == 0) qb = qfill + atomicAdd(&hdr->n1[rnd], cnt);   // per-round counter: final once the barrier is passed
                 qb = __shfl(qb, 0, 64);
 #pragma unroll
                 for (int k = 0; k < FAST_PPT; k++) {
@@ -361,7 +367,11 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
         __syncthreads();
         // A2: opposite-pair test, dense over the compass survivors.  n1 / n2 are block-uniform after the barriers, so
         // rounds without candidates (flat image regions) skip the remaining phases and their barriers altogether.
-        const int n1 = (b.dbg & 1) ? 0 : hdr->n1[rnd];
+        qfill += hdr->n1[rnd];
+        const bool last_round = base + FAST_ROUND >= npx_scan;
+        if (qfill <= FAST_QCAP - FAST_ROUND && !last_round) continue;   // keep filling q1 (block-uniform decision)
+        const int n1 = (b.dbg & 1) ? 0 : qfill;
+        qfill = 0;
         if (n1 > 0) {
             for (int i0 = 0; i0 < n1; i0 += FAST_THREADS) {
                 const int i = i0 + tid;
@@ -373,11 +383,11 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
                     const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
                     pass = fast_pair_test(c, S, c[0], tmin);
                 }
-                queue_push(q2cur, &hdr->n2[rnd], pass, p, lane, lt);
+                queue_push(q2cur, &hdr->n2[batch], pass, p, lane, lt);
             }
             __syncthreads();
             // B: exact FAST score, dense over the pair-test survivors
-            const int n2 = (b.dbg & 2) ? 0 : hdr->n2[rnd];
+            const int n2 = (b.dbg & 2) ? 0 : hdr->n2[batch];
             if (n2 > 0) {
                 for (int i = tid; i < n2; i += FAST_THREADS) {
                     const int p = q2cur[i];
@@ -389,11 +399,12 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
                 __syncthreads();
             }
         }
-        // N: every neighbour of the previous round's pixels is scored now
-        if (rnd > 0) nms_round(q2 + ((rnd - 1) & 1) * FAST_ROUND, hdr->n2[rnd - 1]);
+        // N: every neighbour of the previous batch's pixels is scored now
+        if (batch > 0) nms_round(q2 + ((batch - 1) & 1) * FAST_QCAP, hdr->n2[batch - 1]);
+        batch++;
     }
     if (b.dbg & 16) return;
-    nms_round(q2 + ((rnd - 1) & 1) * FAST_ROUND, hdr->n2[rnd - 1]);
+    if (batch > 0) nms_round(q2 + ((batch - 1) & 1) * FAST_QCAP, hdr->n2[batch - 1]);
     __syncthreads();
     // exclusive scan of the per-chunk survivor counts (wave 0): lane-local run, wave scan, lane-local fix-up
     if (wave == 0) {
