@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
 constexpr int FAST_THREADS = 512;     // 8 waves per cell: more work between barriers, full CU occupancy at ~35 KB LDS per cell
 constexpr int FAST_PPT = 4;           // pixels per lane per round
 constexpr int FAST_ROUND = FAST_THREADS * FAST_PPT;   // pixels per round
-constexpr int FAST_QCAP = FAST_ROUND + 512;   // queue capacity: a batch is flushed once it holds more than FAST_QCAP - FAST_ROUND survivors
+constexpr int FAST_QCAP = FAST_ROUND + 1024;   // queue capacity: a batch is flushed once it holds more than FAST_QCAP - FAST_ROUND survivors
 constexpr int FAST_MAX_ROUNDS = 32;   // cells hold < 65536 pixels (checked on the host)
 
 struct FastLds {
