@@ -8,7 +8,7 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -ffp-contract=off -Wal
 ORBX_SRCS  := $(wildcard orb_slam_amd/csrc/*.hip)
 ORBX_HDRS  := $(wildcard orb_slam_amd/csrc/*.h orb_slam_amd/csrc/*.inc include/*.h)
 
-all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so orb_slam_amd/cpp/example_frame
+all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so oracle_ref orb_slam_amd/cpp/example_frame
 
 orb_slam_amd/liborbx.so: $(ORBX_SRCS) $(ORBX_HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared $(ORBX_SRCS) -o $@
@@ -17,8 +17,12 @@ orb_slam_amd/libsynthframes.so: orb_slam_amd/csrc/synth_frames.c
 	$(CC) -O2 -fPIC -shared $< -o $@
 
 # oracle: scalar restatement, ISO float evaluation (no FMA contraction), the CPU baseline build flags of SURVEY §8d
-oracle/liborb_oracle.so: oracle/orb_oracle.cpp oracle/orb_pattern_points.inc
-	$(CXX) -O3 -march=native -ffp-contract=off -std=c++17 -fPIC -shared $< -o $@
+oracle/liborb_oracle.so: oracle/orb_oracle.cpp oracle/bow_oracle.cpp oracle/orb_pattern_points.inc
+	$(MAKE) -C oracle liborb_oracle.so
+
+# the reference's own sources compiled against stand-in cv headers (only where /root/reference exists): oracle/Makefile
+oracle_ref: oracle/liborb_oracle.so
+	$(MAKE) -C oracle ref
 
 # C++ shim demo: the reference's Frame-side call sequence against the drop-in classes (host C++, links the C ABI)
 orb_slam_amd/cpp/example_frame: orb_slam_amd/cpp/example_frame.cpp orb_slam_amd/cpp/ORBextractor.h orb_slam_amd/cpp/ORBmatcher.h orb_slam_amd/cpp/cvcompat.h include/orbx.h orb_slam_amd/liborbx.so
@@ -26,5 +30,6 @@ orb_slam_amd/cpp/example_frame: orb_slam_amd/cpp/example_frame.cpp orb_slam_amd/
 
 clean:
 	rm -f orb_slam_amd/cpp/example_frame orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
+	rm -rf oracle/_ref
 
-.PHONY: all clean
+.PHONY: all clean oracle_ref

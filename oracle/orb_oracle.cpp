@@ -15,11 +15,17 @@
 // algorithms (modules/imgproc/src/imgwarp.cpp, smooth.cpp, filter.cpp; modules/features2d/
 // src/fast.cpp, fast_score.cpp, keypoint.cpp; modules/core/src/copy.cpp, mathfuncs.cpp).
 //
-// PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path
-//  and cannot be compiled here (needs OpenCV/ROS/Boost/Eigen), so this
-// oracle could not be checked against reference outputs.  It is pinned only by known-answer
-// tests of its primitives (tests/test_oracle_kat.py) and by its own committed golden
-// fixtures (tests/golden/).  Each function cites the reference lines it follows.
+// PARITY — what is pinned and what is not:
+//  * PINNED (by executing the reference's source): everything ORB_SLAM computes itself.  oracle/Makefile compiles
+//    /root/reference/src/ORBextractor.cc where it lies against oracle/cvstub (stand-in OpenCV headers) into
+//    oracle/_ref/libref_orbextractor.so; tests/test_ref_pin.py requires this restatement to reproduce its
+//    keypoints (order, coordinates, size, angle bits, response, octave) and descriptors byte for byte.
+//  * PARITY UNPINNED for the OpenCV 2.4 pixel primitives (resize, FAST+NMS, GaussianBlur, retainBest,
+//    fastAtan2): OpenCV is not vendored in the reference and not installed here, the reference ships no
+//    tests, golden vectors or fixtures, and behind the stand-in headers those calls
+//    resolve to the restatements below.  They are pinned only by known-answer tests
+//    (tests/test_oracle_kat.py) and this oracle's own committed golden fixtures (tests/golden/).
+// Each function cites the reference lines it follows.
 //
 // Float discipline: built with -ffp-contract=off (ISO evaluation, no FMA fusion); the
 // reference's own -O3 -march=native build may fuse differently per CPU.
@@ -771,6 +777,23 @@ void orc_nth_element_perm(const float* responses, int count, int nth, int* out_p
     for (int i = 0; i < count; i++) { v[i] = KeyPoint{0, 0, 0, 0, responses[i], 0, i}; }
     std::nth_element(v.begin(), v.begin() + nth, v.end(), ResponseGreater());
     for (int i = 0; i < count; i++) out_perm[i] = v[i].class_id;
+}
+// --- entry points used only by oracle/cvstub (the reference's own sources compiled against stand-in cv headers)
+// KeyPointsFilter::retainBest in place on a keypoint array (ties at the boundary kept): returns the new size
+int orc_retain_best_kps(orc_keypoint* kps, int count, int n) {
+    std::vector<KeyPoint> v(count);
+    if (count) memcpy(v.data(), kps, sizeof(KeyPoint) * count);
+    retainBest(v, n);
+    if (!v.empty()) memcpy(kps, v.data(), sizeof(KeyPoint) * v.size());
+    return (int)v.size();
+}
+// in-place 7x7 blur of the centred w*h view of a tight (w+32)x(h+32) buffer; the 16-px frame is read, not written
+void orc_gaussian_blur7_level(uint8_t* whole, int w, int hh, int blur_mode) {
+    Level L;
+    L.alloc(w, hh);
+    memcpy(L.buf.data(), whole, L.buf.size());
+    gaussian_blur7_inplace(L, blur_mode);
+    memcpy(whole, L.buf.data(), L.buf.size());
 }
 void orc_sincosf(float a, float* s, float* c) { *s = sinf(a); *c = cosf(a); }
 

@@ -29,6 +29,11 @@ EXPORTS = [
     "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
     "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element", "orbx_debug_geometry",
 ]
+# include/orbv.h (bag-of-words transform)
+EXPORTS_V = [
+    "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_descend", "orbv_descend_device",
+    "orbv_transform", "orbv_transform_batch_device", "orbv_score",
+]
 
 
 class OrbxError(RuntimeError):
@@ -90,6 +95,17 @@ def lib():
         L.orbx_debug_geometry.argtypes = [ctypes.POINTER(Params), ci, ci, vp, ci]
         L.orbx_debug_stage_timing.argtypes = [vp, ci]
         L.orbx_debug_stage_time.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(cl)]
+        L.orbv_create.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, ctypes.POINTER(vp)]
+        L.orbv_load_text.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(vp)]
+        L.orbv_destroy.argtypes = [vp]
+        L.orbv_destroy.restype = None
+        L.orbv_info.argtypes = [vp] + [ctypes.POINTER(ci)] * 6
+        L.orbv_descend.argtypes = [vp, vp, ci, ci, vp, vp, vp]
+        L.orbv_descend_device.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
+        L.orbv_transform.argtypes = [vp, vp, ci, ci, vp, vp, ctypes.POINTER(ci), vp, vp, vp, ctypes.POINTER(ci)]
+        L.orbv_transform_batch_device.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.orbv_score.argtypes = [vp, vp, vp, ci, vp, vp, ci]
+        L.orbv_score.restype = ctypes.c_double
         _LIB = L
     return _LIB
 
@@ -288,3 +304,86 @@ def eval_math(kind, in0, in1=None, device=0):
     if rc != ORBX_OK:
         raise OrbxError(rc, "orbx_debug_eval_math")
     return out0, out1
+
+
+class ORBVocabulary:
+    """Mirror of ORB_SLAM::ORBVocabulary (reference include/ORBVocabulary.h:31-32 = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>)
+    for the per-frame transform: construct from a node table (`from_nodes`) or the reference's text file (`loadFromTextFile`)."""
+
+    def __init__(self):
+        self.h = ctypes.c_void_p()
+
+    @classmethod
+    def from_nodes(cls, k, L, scoring, weighting, parent, is_leaf, desc, weight, device=0):
+        parent = np.ascontiguousarray(parent, dtype=np.int32)
+        is_leaf = np.ascontiguousarray(is_leaf, dtype=np.uint8)
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        weight = np.ascontiguousarray(weight, dtype=np.float64)
+        n = len(parent)
+        assert len(is_leaf) == n and len(desc) == n and len(weight) == n
+        v = cls()
+        rc = lib().orbv_create(k, L, scoring, weighting, n, parent.ctypes.data, is_leaf.ctypes.data, desc.ctypes.data, weight.ctypes.data,
+                               device, ctypes.byref(v.h))
+        if rc != ORBX_OK:
+            raise OrbxError(rc, "orbv_create")
+        return v
+
+    @classmethod
+    def loadFromTextFile(cls, path, device=0):
+        v = cls()
+        rc = lib().orbv_load_text(os.fsencode(path), device, ctypes.byref(v.h))
+        if rc != ORBX_OK:
+            raise OrbxError(rc, "orbv_load_text")
+        return v
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().orbv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def info(self):
+        vals = [ctypes.c_int() for _ in range(6)]
+        lib().orbv_info(self.h, *[ctypes.byref(x) for x in vals])
+        return dict(zip(("k", "L", "scoring", "weighting", "n_words", "n_nodes"), [x.value for x in vals]))
+
+    def size(self):
+        return self.info()["n_words"]
+
+    def descend(self, desc, levelsup=4):
+        """per-descriptor (word id, weight, node id at level L-levelsup)"""
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        n = len(desc)
+        word = np.empty(n, np.uint32); weight = np.empty(n, np.float64); node = np.empty(n, np.uint32)
+        rc = lib().orbv_descend(self.h, desc.ctypes.data, n, levelsup, word.ctypes.data, weight.ctypes.data, node.ctypes.data)
+        if rc != ORBX_OK:
+            raise OrbxError(rc, "orbv_descend")
+        return word, weight, node
+
+    def transform(self, desc, levelsup=4):
+        """Frame::ComputeBoW: -> (bow_ids, bow_vals, fv_nodes, fv_off, fv_feat); BowVector / FeatureVector in map order"""
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        n = len(desc)
+        m = max(n, 1)
+        bid = np.empty(m, np.uint32); bval = np.empty(m, np.float64)
+        fnode = np.empty(m, np.uint32); foff = np.zeros(m + 1, np.int32); ffeat = np.empty(m, np.uint32)
+        nb, nf = ctypes.c_int(), ctypes.c_int()
+        rc = lib().orbv_transform(self.h, desc.ctypes.data, n, levelsup, bid.ctypes.data, bval.ctypes.data, ctypes.byref(nb),
+                                  fnode.ctypes.data, foff.ctypes.data, ffeat.ctypes.data, ctypes.byref(nf))
+        if rc != ORBX_OK:
+            raise OrbxError(rc, "orbv_transform")
+        return bid[:nb.value], bval[:nb.value], fnode[:nf.value], foff[:nf.value + 1], ffeat[:foff[nf.value]]
+
+    def transform_batch_device(self, d_desc, d_n, nframes, cap, levelsup, d_bow_id, d_bow_val, d_n_bow, d_fv_node, d_fv_off, d_fv_feat,
+                               d_n_fv, stream=0):
+        rc = lib().orbv_transform_batch_device(self.h, d_desc, d_n, nframes, cap, levelsup, d_bow_id, d_bow_val, d_n_bow, d_fv_node,
+                                               d_fv_off, d_fv_feat, d_n_fv, stream or None)
+        if rc != ORBX_OK:
+            raise OrbxError(rc, "orbv_transform_batch_device")
+
+    def score(self, ids1, vals1, ids2, vals2):
+        a = np.ascontiguousarray(ids1, dtype=np.uint32); av = np.ascontiguousarray(vals1, dtype=np.float64)
+        b = np.ascontiguousarray(ids2, dtype=np.uint32); bv = np.ascontiguousarray(vals2, dtype=np.float64)
+        return lib().orbv_score(self.h, a.ctypes.data, av.ctypes.data, len(a), b.ctypes.data, bv.ctypes.data, len(b))

@@ -52,6 +52,17 @@ def lib():
         L.orc_match_top2.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
         L.orc_count_accepted.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float]
         L.orc_match_top2_segments.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.orc_voc_load_text.restype = c_void_p
+        L.orc_voc_load_text.argtypes = [ctypes.c_char_p]
+        L.orc_voc_create.restype = c_void_p
+        L.orc_voc_create.argtypes = [c_int] * 5 + [c_void_p] * 4
+        L.orc_voc_destroy.argtypes = [c_void_p]
+        L.orc_voc_info.argtypes = [c_void_p] * 7
+        L.orc_forb_distance.argtypes = [c_void_p, c_void_p]
+        L.orc_voc_descend.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]
+        L.orc_voc_transform.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7
+        L.orc_voc_score.restype = c_double
+        L.orc_voc_score.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]
         _LIB = L
     return _LIB
 
@@ -186,3 +197,137 @@ def match_top2_segments(Q, T, seg_off, cand):
     lib().orc_match_top2_segments(Q.ctypes.data, nq, T.ctypes.data, len(T), seg.ctypes.data, cd.ctypes.data if len(cd) else None,
                                   idx.ctypes.data, best.ctypes.data, sec.ctypes.data)
     return idx, best, sec
+
+
+class _VocBase:
+    """shared marshalling for the oracle vocabulary (prefix 'orc_') and the compiled reference (prefix 'ref_')"""
+    PFX = "orc_"
+
+    def _f(self, name):
+        return getattr(self.L, self.PFX + name)
+
+    def descend(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        n = len(desc)
+        word = np.zeros(n, np.uint32); weight = np.zeros(n, np.float64); node = np.zeros(n, np.uint32)
+        self._f("voc_descend")(self.h, desc.ctypes.data, n, levelsup, word.ctypes.data, weight.ctypes.data, node.ctypes.data)
+        return word, weight, node
+
+    def transform(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        n = len(desc)
+        m = max(n, 1)
+        bid = np.zeros(m, np.uint32); bval = np.zeros(m, np.float64)
+        fnode = np.zeros(m, np.uint32); foff = np.zeros(m + 1, np.int32); ffeat = np.zeros(m, np.uint32)
+        nb, nf = ctypes.c_int(), ctypes.c_int()
+        self._f("voc_transform")(self.h, desc.ctypes.data, n, levelsup, bid.ctypes.data, bval.ctypes.data, ctypes.byref(nb),
+                                 fnode.ctypes.data, foff.ctypes.data, ffeat.ctypes.data, ctypes.byref(nf))
+        return bid[:nb.value], bval[:nb.value], fnode[:nf.value], foff[:nf.value + 1], ffeat[:foff[nf.value]]
+
+    def score(self, ids1, vals1, ids2, vals2):
+        a = np.ascontiguousarray(ids1, dtype=np.uint32); av = np.ascontiguousarray(vals1, dtype=np.float64)
+        b = np.ascontiguousarray(ids2, dtype=np.uint32); bv = np.ascontiguousarray(vals2, dtype=np.float64)
+        return self._f("voc_score")(self.h, a.ctypes.data, av.ctypes.data, len(a), b.ctypes.data, bv.ctypes.data, len(b))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._f("voc_destroy")(self.h)
+            self.h = None
+
+
+class OracleVocabulary(_VocBase):
+    def __init__(self, path=None, voc=None, scoring=0, weighting=0):
+        self.L = lib()
+        if path is not None:
+            self.h = self.L.orc_voc_load_text(os.fsencode(path))
+        else:
+            p = np.ascontiguousarray(voc["parent"], dtype=np.int32)
+            lf = np.ascontiguousarray(voc["is_leaf"], dtype=np.uint8)
+            d = np.ascontiguousarray(voc["desc"], dtype=np.uint8)
+            w = np.ascontiguousarray(voc["weight"], dtype=np.float64)
+            self.h = self.L.orc_voc_create(voc["k"], voc["L"], scoring, weighting, len(p), p.ctypes.data, lf.ctypes.data, d.ctypes.data, w.ctypes.data)
+        assert self.h, "vocabulary load failed"
+
+    def info(self):
+        vals = [ctypes.c_int() for _ in range(6)]
+        self.L.orc_voc_info(self.h, *[ctypes.byref(x) for x in vals])
+        return dict(zip(("k", "L", "scoring", "weighting", "n_words", "n_nodes"), [x.value for x in vals]))
+
+
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+def ref_available():
+    return os.path.exists(os.path.join(REF_DIR, "libref_orbextractor.so")) and os.path.exists(os.path.join(REF_DIR, "libref_dbow2.so"))
+
+
+_REF = {}
+
+
+def ref_lib(name):
+    """the reference's own sources compiled against oracle/cvstub (oracle/Makefile → oracle/_ref/)"""
+    if name not in _REF:
+        lib()     # liborb_oracle.so first: the stand-in cv primitives resolve into it
+        R = ctypes.CDLL(os.path.join(REF_DIR, name), mode=ctypes.RTLD_GLOBAL)
+        if name == "libref_orbextractor.so":
+            R.ref_orb_create.restype = c_void_p
+            R.ref_orb_create.argtypes = [c_int, c_float, c_int, c_int, c_int]
+            R.ref_orb_destroy.argtypes = [c_void_p]
+            R.ref_orb_levels.argtypes = [c_void_p]
+            R.ref_orb_scale_factor.argtypes = [c_void_p]
+            R.ref_orb_scale_factor.restype = c_float
+            R.ref_orb_extract.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int]
+            R.cvstub_set_blur_mode.argtypes = [c_int]
+        else:
+            R.ref_voc_load_text.restype = c_void_p
+            R.ref_voc_load_text.argtypes = [ctypes.c_char_p]
+            R.ref_voc_destroy.argtypes = [c_void_p]
+            R.ref_voc_info.argtypes = [c_void_p] * 6
+            R.ref_forb_distance.argtypes = [c_void_p, c_void_p]
+            R.ref_voc_descend.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]
+            R.ref_voc_transform.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7
+            R.ref_voc_score.restype = c_double
+            R.ref_voc_score.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]
+        _REF[name] = R
+    return _REF[name]
+
+
+class RefExtractor:
+    """ORB_SLAM::ORBextractor compiled from /root/reference/src/ORBextractor.cc (OpenCV primitives = the oracle's)"""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, scoreType=FAST_SCORE, fastTh=20, blur_mode=0):
+        self.R = ref_lib("libref_orbextractor.so")
+        self.blur_mode = blur_mode
+        self.nfeatures = nfeatures
+        self.h = self.R.ref_orb_create(nfeatures, scaleFactor, nlevels, scoreType, fastTh)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.R.ref_orb_destroy(self.h)
+            self.h = None
+
+    def __call__(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        hh, w = img.shape
+        cap = max(2 * self.nfeatures, 16)
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        self.R.cvstub_set_blur_mode(self.blur_mode)
+        n = self.R.ref_orb_extract(self.h, img.ctypes.data, w, hh, img.strides[0], kps.ctypes.data, desc.ctypes.data, cap)
+        assert n >= 0, "reference extractor failed: %d" % n
+        return kps[:n].copy(), desc[:n].copy()
+
+
+class RefVocabulary(_VocBase):
+    """ORB_SLAM::ORBVocabulary compiled from the reference's vendored DBoW2 sources"""
+    PFX = "ref_"
+
+    def __init__(self, path):
+        self.L = ref_lib("libref_dbow2.so")
+        self.h = self.L.ref_voc_load_text(os.fsencode(path))
+        assert self.h, "reference loadFromTextFile failed"
+
+    def info(self):
+        vals = [ctypes.c_int() for _ in range(5)]
+        self.L.ref_voc_info(self.h, *[ctypes.byref(x) for x in vals])
+        return dict(zip(("k", "L", "scoring", "weighting", "n_words"), [x.value for x in vals]))
