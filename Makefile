@@ -25,7 +25,7 @@ oracle_ref: oracle/liborb_oracle.so
 	$(MAKE) -C oracle ref
 
 # C++ shim demo: the reference's Frame-side call sequence against the drop-in classes (host C++, links the C ABI)
-orb_slam_amd/cpp/example_frame: orb_slam_amd/cpp/example_frame.cpp orb_slam_amd/cpp/ORBextractor.h orb_slam_amd/cpp/ORBmatcher.h orb_slam_amd/cpp/cvcompat.h include/orbx.h orb_slam_amd/liborbx.so
+orb_slam_amd/cpp/example_frame: orb_slam_amd/cpp/example_frame.cpp orb_slam_amd/cpp/ORBextractor.h orb_slam_amd/cpp/ORBmatcher.h orb_slam_amd/cpp/ORBVocabulary.h orb_slam_amd/cpp/cvcompat.h include/orbx.h include/orbv.h orb_slam_amd/liborbx.so
 	$(CXX) -O2 -std=c++14 -Iinclude -Iorb_slam_amd/cpp $< -o $@ -Lorb_slam_amd -lorbx -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
 
 clean:

@@ -193,6 +193,27 @@ def test_cpp_shim_reference_call_sequence(tmp_path):
     _assert_kps_equal(k, ok)
     np.testing.assert_array_equal(d, od)
     assert "N=%d " % n in res.stdout and "levels=8" in res.stdout
+    # Frame::ComputeBoW through the ORBVocabulary shim (main.cc's loadFromTextFile, Frame.cc's transform(..., 4))
+    voc = synth.vocabulary(10, 5, seed=4, order="kmeans")
+    vpath, bout = tmp_path / "voc.txt", tmp_path / "bow.bin"
+    synth.write_vocabulary_text(str(vpath), voc)
+    res = subprocess.run([exe, "640", "480", str(raw), str(out), str(vpath), str(bout)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert "words=100000 " in res.stdout and "same=1" in res.stdout
+    wid, wval, fnode, foff, ffeat = orc.OracleVocabulary(path=str(vpath)).transform(od, 4)
+    blob = bout.read_bytes()
+    nb = int(np.frombuffer(blob[:4], np.uint32)[0])
+    rec = np.frombuffer(blob[4:4 + 12 * nb], np.dtype([("w", "<u4"), ("v", "<f8")]))
+    assert nb == len(wid) and np.array_equal(rec["w"], wid) and rec["v"].tobytes() == wval.tobytes()
+    pos = 4 + 12 * nb
+    nn = int(np.frombuffer(blob[pos:pos + 4], np.uint32)[0])
+    pos += 4
+    assert nn == len(fnode)
+    for j in range(nn):
+        node, cnt = np.frombuffer(blob[pos:pos + 8], np.uint32)
+        feats = np.frombuffer(blob[pos + 8:pos + 8 + 4 * cnt], np.uint32)
+        pos += 8 + 4 * int(cnt)
+        assert node == fnode[j] and np.array_equal(feats, ffeat[foff[j]:foff[j + 1]])
 
 
 def test_batch_device_unaligned_frames(gpu_extractor_factory):
