@@ -29,6 +29,11 @@ EXPORTS = [
     "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
     "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element", "orbx_debug_geometry",
 ]
+# include/orbf.h (Frame-side steps: undistortion, search grid, window query)
+EXPORTS_F = [
+    "orbf_image_bounds", "orbf_undistort_grid", "orbf_undistort_grid_batch_device", "orbf_features_in_area",
+    "orbf_features_in_area_device",
+]
 # include/orbv.h (bag-of-words transform)
 EXPORTS_V = [
     "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_descend", "orbv_descend_device",
@@ -47,6 +52,34 @@ class Params(ctypes.Structure):
                 ("score_type", ctypes.c_int32), ("fast_th", ctypes.c_int32), ("device", ctypes.c_int32),
                 ("max_batch", ctypes.c_int32), ("blur_rounding", ctypes.c_int32), ("reserved", ctypes.c_int32 * 8)]
 
+
+class Camera(ctypes.Structure):
+    """orbf_camera: mK (row-major 3x3), mDistCoef, image size"""
+    _fields_ = [("K", ctypes.c_float * 9), ("dist", ctypes.c_float * 8), ("ndist", ctypes.c_int32),
+                ("width", ctypes.c_int32), ("height", ctypes.c_int32)]
+
+    @classmethod
+    def make(cls, fx, fy, cx, cy, dist, width, height):
+        c = cls()
+        for i, v in enumerate((fx, 0, cx, 0, fy, cy, 0, 0, 1)):
+            c.K[i] = v
+        for i, v in enumerate(dist):
+            c.dist[i] = v
+        c.ndist, c.width, c.height = len(dist), width, height
+        return c
+
+
+class Bounds(ctypes.Structure):
+    """orbf_bounds: Frame::mnMinX/mnMaxX/mnMinY/mnMaxY and the inverse grid cell sizes"""
+    _fields_ = [("min_x", ctypes.c_int32), ("max_x", ctypes.c_int32), ("min_y", ctypes.c_int32), ("max_y", ctypes.c_int32),
+                ("inv_w", ctypes.c_float), ("inv_h", ctypes.c_float)]
+
+    def astuple(self):
+        return (self.min_x, self.max_x, self.min_y, self.max_y, self.inv_w, self.inv_h)
+
+
+GRID_COLS, GRID_ROWS = 64, 48
+GRID_CELLS = GRID_COLS * GRID_ROWS
 
 _LIB = None
 
@@ -95,6 +128,11 @@ def lib():
         L.orbx_debug_geometry.argtypes = [ctypes.POINTER(Params), ci, ci, vp, ci]
         L.orbx_debug_stage_timing.argtypes = [vp, ci]
         L.orbx_debug_stage_time.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(cl)]
+        L.orbf_image_bounds.argtypes = [ctypes.POINTER(Camera), ctypes.POINTER(Bounds)]
+        L.orbf_undistort_grid.argtypes = [ctypes.POINTER(Camera), ctypes.POINTER(Bounds), vp, ci, vp, vp, vp, ci]
+        L.orbf_undistort_grid_batch_device.argtypes = [ctypes.POINTER(Camera), ctypes.POINTER(Bounds), vp, vp, ci, ci, vp, vp, vp, vp]
+        L.orbf_features_in_area.argtypes = [ctypes.POINTER(Bounds), vp, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci]
+        L.orbf_features_in_area_device.argtypes = [ctypes.POINTER(Bounds), vp, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp]
         L.orbv_create.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, ctypes.POINTER(vp)]
         L.orbv_load_text.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(vp)]
         L.orbv_destroy.argtypes = [vp]
@@ -387,3 +425,56 @@ class ORBVocabulary:
         a = np.ascontiguousarray(ids1, dtype=np.uint32); av = np.ascontiguousarray(vals1, dtype=np.float64)
         b = np.ascontiguousarray(ids2, dtype=np.uint32); bv = np.ascontiguousarray(vals2, dtype=np.float64)
         return lib().orbv_score(self.h, a.ctypes.data, av.ctypes.data, len(a), b.ctypes.data, bv.ctypes.data, len(b))
+
+
+def image_bounds(cam):
+    """Frame::ComputeImageBounds + the inverse grid cell sizes (host side, once per camera)"""
+    b = Bounds()
+    rc = lib().orbf_image_bounds(ctypes.byref(cam), ctypes.byref(b))
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbf_image_bounds")
+    return b
+
+
+def undistort_grid(cam, bounds, kps, device=0):
+    """Frame::UndistortKeyPoints + the mGrid fill for one frame: -> (kps_un, cell_off[3073], cell_feat)"""
+    kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+    n = len(kps)
+    un = np.zeros(n, dtype=KP_DTYPE)
+    off = np.zeros(GRID_CELLS + 1, np.int32)
+    feat = np.zeros(max(n, 1), np.int32)
+    rc = lib().orbf_undistort_grid(ctypes.byref(cam), ctypes.byref(bounds), kps.ctypes.data if n else None, n, un.ctypes.data if n else None,
+                                   off.ctypes.data, feat.ctypes.data, device)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbf_undistort_grid")
+    return un, off, feat[:off[GRID_CELLS]]
+
+
+def undistort_grid_batch_device(cam, bounds, d_kps, d_n, nframes, cap, d_kps_un, d_cell_off, d_cell_feat, stream=0):
+    rc = lib().orbf_undistort_grid_batch_device(ctypes.byref(cam), ctypes.byref(bounds), d_kps, d_n, nframes, cap, d_kps_un, d_cell_off, d_cell_feat,
+                                                stream or None)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbf_undistort_grid_batch_device")
+
+
+def features_in_area(bounds, kps_un, cell_off, cell_feat, qxyr, qlev, cand_cap=None, device=0):
+    """Frame::GetFeaturesInArea for many (x, y, r, minLevel, maxLevel) queries: -> (seg_off, cand) CSR"""
+    kps_un = np.ascontiguousarray(kps_un, dtype=KP_DTYPE)
+    cell_off = np.ascontiguousarray(cell_off, dtype=np.int32)
+    cell_feat = np.ascontiguousarray(cell_feat, dtype=np.int32)
+    qxyr = np.ascontiguousarray(qxyr, dtype=np.float32).reshape(-1, 3)
+    qlev = np.ascontiguousarray(qlev, dtype=np.int32).reshape(-1, 2)
+    nq = len(qxyr)
+    assert len(qlev) == nq and len(cell_off) == GRID_CELLS + 1
+    cap = cand_cap if cand_cap is not None else max(1, nq * 64)
+    while True:
+        seg = np.zeros(nq + 1, np.int32)
+        cand = np.zeros(max(cap, 1), np.int32)
+        rc = lib().orbf_features_in_area(ctypes.byref(bounds), kps_un.ctypes.data, len(kps_un), cell_off.ctypes.data, cell_feat.ctypes.data,
+                                         qxyr.ctypes.data, qlev.ctypes.data, nq, seg.ctypes.data, cand.ctypes.data, cap, device)
+        if rc == ORBX_ERR_CAPACITY and cand_cap is None:
+            cap = int(seg[nq])
+            continue
+        if rc != ORBX_OK:
+            raise OrbxError(rc, "orbf_features_in_area")
+        return seg, cand[:seg[nq]]

@@ -52,6 +52,10 @@ def lib():
         L.orc_match_top2.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
         L.orc_count_accepted.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float]
         L.orc_match_top2_segments.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.orc_frame_bounds.argtypes = [c_void_p, c_void_p]
+        L.orc_frame_undistort.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
+        L.orc_frame_grid.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+        L.orc_frame_features_in_area.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int, c_int, c_void_p]
         L.orc_voc_load_text.restype = c_void_p
         L.orc_voc_load_text.argtypes = [ctypes.c_char_p]
         L.orc_voc_create.restype = c_void_p
@@ -331,3 +335,34 @@ class RefVocabulary(_VocBase):
         vals = [ctypes.c_int() for _ in range(5)]
         self.L.ref_voc_info(self.h, *[ctypes.byref(x) for x in vals])
         return dict(zip(("k", "L", "scoring", "weighting", "n_words"), [x.value for x in vals]))
+
+
+# ---- Frame-side steps (oracle/frame_oracle.cpp).  cam / bounds are ctypes structs with the layout of orbf_camera /
+# orbf_bounds (tests pass orb_slam_amd.capi.Camera / Bounds: plain data carriers, no product code runs here).
+def frame_bounds(cam, bounds_cls):
+    b = bounds_cls()
+    lib().orc_frame_bounds(ctypes.addressof(cam), ctypes.addressof(b))
+    return b
+
+
+def frame_undistort(cam, kps):
+    kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+    out = np.zeros(len(kps), dtype=KP_DTYPE)
+    lib().orc_frame_undistort(ctypes.addressof(cam), kps.ctypes.data, len(kps), out.ctypes.data)
+    return out
+
+
+def frame_grid(bounds, kps_un):
+    kps_un = np.ascontiguousarray(kps_un, dtype=KP_DTYPE)
+    off = np.zeros(64 * 48 + 1, np.int32)
+    feat = np.zeros(max(len(kps_un), 1), np.int32)
+    lib().orc_frame_grid(ctypes.addressof(bounds), kps_un.ctypes.data, len(kps_un), off.ctypes.data, feat.ctypes.data)
+    return off, feat[:off[-1]]
+
+
+def frame_features_in_area(bounds, kps_un, cell_off, cell_feat, x, y, r, min_level, max_level):
+    kps_un = np.ascontiguousarray(kps_un, dtype=KP_DTYPE)
+    out = np.zeros(max(len(kps_un), 1), np.int32)
+    n = lib().orc_frame_features_in_area(ctypes.addressof(bounds), kps_un.ctypes.data, cell_off.ctypes.data, cell_feat.ctypes.data,
+                                         x, y, r, min_level, max_level, out.ctypes.data)
+    return out[:n]

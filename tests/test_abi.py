@@ -36,6 +36,28 @@ def test_library_exports_every_symbol_of_orbv_h():
     assert sorted(capi.EXPORTS_V) == declared
 
 
+def test_library_exports_every_symbol_of_orbf_h_and_bounds_match_oracle():
+    src = open(os.path.join(ROOT, "include", "orbf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(orbf_[a-z0-9_]+)\s*\(", src)))
+    L = capi.lib()
+    assert len(declared) == 5 and not [f for f in declared if not hasattr(L, f)]
+    assert sorted(capi.EXPORTS_F) == declared
+    assert ctypes.sizeof(capi.Camera) == 80 and ctypes.sizeof(capi.Bounds) == 24
+    # Frame::ComputeImageBounds is host-side setup (four points, once per camera): same numbers as the oracle
+    import oracle_lib as ol
+    cams = [capi.Camera.make(517.3, 516.5, 318.6, 255.3, (0.2624, -0.9531, -0.0054, 0.0026), 640, 480),      # TUM fr1 (Data/Settings.yaml shape)
+            capi.Camera.make(458.654, 457.296, 367.215, 248.375, (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05), 752, 480),
+            capi.Camera.make(535.4, 539.2, 320.1, 247.6, (0.0, 0.0, 0.0, 0.0), 640, 480),                       # undistorted camera: plain image box
+            capi.Camera.make(1400.0, 1400.0, 960.0, 540.0, (-0.1, 0.02, 0.001, -0.002, 0.003), 1920, 1080)]
+    for cam in cams:
+        got = capi.image_bounds(cam)
+        want = ol.frame_bounds(cam, capi.Bounds)
+        assert got.astuple()[:4] == want.astuple()[:4]
+        assert np.float32(got.inv_w).tobytes() == np.float32(want.inv_w).tobytes() and np.float32(got.inv_h).tobytes() == np.float32(want.inv_h).tobytes()
+    assert capi.image_bounds(cams[2]).astuple()[:4] == (0, 640, 0, 480)
+
+
 def test_vocabulary_table_validation_needs_no_device():
     """orbv_create rejects inconsistent node tables before touching the device; the text loader mirrors the
     reference's header checks (TemplatedVocabulary.h:1366-1370)"""
