@@ -17,7 +17,7 @@ orb_slam_amd/libsynthframes.so: orb_slam_amd/csrc/synth_frames.c
 	$(CC) -O2 -fPIC -shared $< -o $@
 
 # oracle: scalar restatement, ISO float evaluation (no FMA contraction), the CPU baseline build flags of SURVEY §8d
-oracle/liborb_oracle.so: oracle/orb_oracle.cpp oracle/bow_oracle.cpp oracle/frame_oracle.cpp oracle/orb_pattern_points.inc
+oracle/liborb_oracle.so: oracle/orb_oracle.cpp oracle/bow_oracle.cpp oracle/frame_oracle.cpp oracle/search_oracle.cpp oracle/orb_pattern_points.inc
 	$(MAKE) -C oracle liborb_oracle.so
 
 # the reference's own sources compiled against stand-in cv headers (only where /root/reference exists): oracle/Makefile

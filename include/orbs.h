@@ -1,0 +1,80 @@
+/* orbs.h — C ABI of the greedy grid-window searches (part of liborbx.so).
+ *
+ * SURVEY.md §8f row N2 with §8a rows M2–M4: the per-frame searches of ORBmatcher that scan a Frame's 64x48 grid window
+ * around every query, skip train features claimed by EARLIER queries (the sequential "already matched" masking), apply
+ * the accept rule and, where the reference does, the rotation-consistency histogram.  Exact reference semantics, batched
+ * over many independent search problems (one per frame / frame pair), all inputs and outputs device resident.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference), selected by `rule`:
+ *   ORBS_RULE_MAPPOINTS  <- int ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, float th)   src/ORBmatcher.cc:48-125
+ *                           (best / second with their octaves; reject only when both lie on one level and best > ratio*second)
+ *   ORBS_RULE_WINDOW     <- int ORBmatcher::WindowSearch(Frame&, Frame&, int, vector<MapPoint*>&, int, int)   :408-516
+ *                           int ORBmatcher::SearchByProjection(Frame&, Frame&, int, vector<MapPoint*>&)       :519-594
+ *                           (accept best <= second*ratio && best <= th)
+ *   ORBS_RULE_BEST       <- int ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, float th)   :1508-1619
+ *                           (accept best <= th)
+ *   ORBS_RULE_INIT       <- int ORBmatcher::SearchForInitialization(Frame&, Frame&, vector<Point2f>&, vector<int>&, int)   :596-716
+ *                           (a train feature may be re-matched by a later query with a strictly smaller distance)
+ *   rotation filter      <- the rotHist blocks of those functions + ORBmatcher::ComputeThreeMaxima            :1748-1789
+ *   candidate windows    <- Frame::GetFeaturesInArea                                                          src/Frame.cc:200-265
+ *
+ * What stays with the caller (pointer-graph work on MapPoint / Frame objects): which queries are valid (pMP != NULL,
+ * !isBad(), mbTrackInView, level bounds → d_qvalid), their window centre / radius / level range (projection,
+ * RadiusByViewingCos, scale factors → d_qxyr, d_qlev) and what a match means (vpMapPointMatches2[i2] = F1.mvpMapPoints[q]).
+ *
+ * Layout: problem p uses train slots [p*cap, p*cap + d_nt[p]) of d_kps_un / d_desc / d_claimed / d_t2q, its grid at
+ * d_cell_off + p*(ORBF_GRID_CELLS+1), d_cell_feat + p*cap (exactly what orbf_undistort_grid_batch_device writes), and query
+ * slots [p*qcap, p*qcap + d_nq[p]).  Status codes are orbx.h's; there is no CPU fallback.
+ */
+#ifndef ORBS_H
+#define ORBS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "orbf.h"
+#include "orbx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBS_RULE_MAPPOINTS 0
+#define ORBS_RULE_WINDOW    1
+#define ORBS_RULE_BEST      2
+#define ORBS_RULE_INIT      3
+
+#define ORBS_TH_HIGH 100      /* ORBmatcher::TH_HIGH src/ORBmatcher.cc:40 */
+#define ORBS_TH_LOW  50       /* ORBmatcher::TH_LOW  src/ORBmatcher.cc:41 */
+
+typedef struct orbs_params {
+    int32_t rule;               /* ORBS_RULE_* */
+    int32_t th;                 /* TH_HIGH / TH_LOW / ORBdist */
+    float ratio;                /* mfNNratio */
+    int32_t check_orientation;  /* mbCheckOrientation (ignored by ORBS_RULE_MAPPOINTS, which has no rotation check) */
+} orbs_params;
+
+/* LDS bytes one problem needs (the train frame is staged in LDS); ORBX_ERR_CAPACITY from the search when this exceeds
+ * what a gfx950 workgroup can have (160 KiB).  cap = 1000 / qcap = 1000 needs ~60 KiB. */
+size_t orbs_lds_bytes(int cap, int qcap);
+
+/* Outputs per problem: d_q2t[qcap] the train feature each query is finally matched to (-1 none), d_t2q[cap] the query each
+ * train feature is finally matched to (-1 none), d_best / d_second[qcap] the two distances the scan left (INT_MAX as in the
+ * reference; -1 for queries that were skipped or had an empty window; may be NULL), d_nmatches[p] the function's return
+ * value.  d_claimed (may be NULL): train features that already hold a map point on entry (F.mvpMapPoints[idx] != NULL).
+ * d_qangle: the query keypoints' angles (needed when check_orientation; may be NULL otherwise); d_qvalid may be NULL. */
+int orbs_window_search_batch_device(const orbf_bounds* b, const orbs_params* prm,
+                                    const orbx_keypoint* d_kps_un, const uint8_t* d_desc, const int32_t* d_cell_off,
+                                    const int32_t* d_cell_feat, const int32_t* d_nt, int cap, const uint8_t* d_claimed,
+                                    const float* d_qxyr, const int32_t* d_qlev, const uint8_t* d_qdesc, const float* d_qangle,
+                                    const uint8_t* d_qvalid, const int32_t* d_nq, int qcap, int nproblems,
+                                    int32_t* d_q2t, int32_t* d_t2q, int32_t* d_best, int32_t* d_second, int32_t* d_nmatches,
+                                    void* stream);
+
+/* ORBmatcher::ComputeThreeMaxima on a histogram of bin sizes (host, re-entrant): ind[3], -1 = none */
+void orbs_three_maxima(const int32_t* sizes, int L, int32_t* ind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,134 @@
+// =====================================================================================
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orb_oracle.cpp's header; the same rules apply).
+//
+// CPU restatement of the greedy grid-window searches of ORBmatcher on flattened arrays:
+// one loop over the queries IN ORDER, each scanning Frame::GetFeaturesInArea's candidates while skipping train
+// features claimed by earlier queries, then the accept rule, then (optionally) the rotation-consistency filter.
+//   rule 0  ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, float)      src/ORBmatcher.cc:48-125
+//   rule 1  ORBmatcher::WindowSearch(Frame&, Frame&, int, vector<MapPoint*>&, int, int)   :408-516
+//           ORBmatcher::SearchByProjection(Frame&, Frame&, int, vector<MapPoint*>&)       :519-594 (no rotation check)
+//   rule 2  ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, float)      :1508-1619
+//   rule 3  ORBmatcher::SearchForInitialization(Frame&, Frame&, vector<Point2f>&, vector<int>&, int)   :596-716
+//   ORBmatcher::ComputeThreeMaxima                                                        :1748-1789
+// What stays with the caller (pointer-graph work): which queries are valid (pMP != NULL, !isBad(), mbTrackInView, level
+// bounds), their window centres / radii (projection, RadiusByViewingCos, scale factors) and what a match means
+// (vpMapPointMatches2[i2] = pMP1 ...).  Candidate windows come from frame_oracle.cpp (Frame::GetFeaturesInArea).
+// PARITY UNPINNED (ORBmatcher.cc cannot be compiled here: Frame / KeyFrame / MapPoint / g2o / Boost).
+// =====================================================================================
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+extern "C" int orc_frame_features_in_area(const void* b, const void* kps_un, const int32_t* cell_off, const int32_t* cell_feat,
+                                          float x, float y, float r, int minLevel, int maxLevel, int32_t* out);
+extern "C" int orc_hamming256(const uint8_t* a, const uint8_t* b);
+
+namespace {
+struct KeyPoint { float x, y, size, angle, response; int32_t octave, class_id; };
+const int HISTO_LENGTH = 30;      // src/ORBmatcher.cc:42
+
+// src/ORBmatcher.cc:1748-1789
+void ComputeThreeMaxima(const std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+int rot_bin(float a1, float a2) {
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+}  // namespace
+
+extern "C" {
+void orc_three_maxima(const int32_t* sizes, int L, int32_t* ind) {
+    std::vector<std::vector<int> > h(L);
+    for (int i = 0; i < L; i++) h[i].resize(sizes[i]);
+    int a = -1, b = -1, c = -1;
+    ComputeThreeMaxima(h.data(), L, a, b, c);
+    ind[0] = a; ind[1] = b; ind[2] = c;
+}
+
+// One search problem.  q2t[nq]: the train feature a query ended up matched to (-1 none); t2q[nt]: the query a train feature
+// ended up matched to (-1 none; features with claimed[] set on entry keep -1).  best/second[nq]: the two distances the scan
+// left for the query (INT_MAX where the reference had INT_MAX; untouched (-1) for skipped queries).  Returns nmatches.
+int orc_window_search(const void* bounds, int rule, int th, float ratio, int check_orientation,
+                      const KeyPoint* kps_un, const uint8_t* desc, const int32_t* cell_off, const int32_t* cell_feat, int nt,
+                      const uint8_t* claimed_in,
+                      const float* qxyr, const int32_t* qlev, const uint8_t* qdesc, const float* qangle, const uint8_t* qvalid, int nq,
+                      int32_t* q2t, int32_t* t2q, int32_t* best_out, int32_t* second_out) {
+    int nmatches = 0;
+    std::vector<uint8_t> claimed(nt, 0);
+    if (claimed_in) memcpy(claimed.data(), claimed_in, nt);
+    std::vector<int> vMatchedDistance(nt, INT_MAX);           // rule 3 (:608)
+    for (int i = 0; i < nq; i++) { q2t[i] = -1; best_out[i] = -1; second_out[i] = -1; }
+    for (int i = 0; i < nt; i++) t2q[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    std::vector<int32_t> near(nt > 0 ? nt : 1);
+    for (int q = 0; q < nq; q++) {
+        if (qvalid && !qvalid[q]) continue;
+        const int nn = orc_frame_features_in_area(bounds, kps_un, cell_off, cell_feat, qxyr[3 * q], qxyr[3 * q + 1], qxyr[3 * q + 2],
+                                                  qlev[2 * q], qlev[2 * q + 1], near.data());
+        if (nn == 0) continue;
+        int bestDist = INT_MAX, bestLevel = -1, bestDist2 = INT_MAX, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < nn; c++) {
+            const int idx = near[c];
+            if (rule != 3 && claimed[idx]) continue;
+            const int dist = orc_hamming256(qdesc + (size_t)q * 32, desc + (size_t)idx * 32);
+            if (rule == 3 && vMatchedDistance[idx] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kps_un[idx].octave; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = kps_un[idx].octave; bestDist2 = dist; }
+        }
+        best_out[q] = bestDist;
+        second_out[q] = bestDist2;
+        bool accept = false;
+        if (rule == 0) {                    // :114-121
+            if (bestDist <= th) accept = !(bestLevel == bestLevel2 && bestDist > ratio * bestDist2);
+        } else if (rule == 1) {             // :476 / :585
+            accept = bestDist <= bestDist2 * ratio && bestDist <= th;
+        } else if (rule == 2) {             // :1583
+            accept = bestDist <= th;
+        } else {                            // :652-654
+            accept = bestDist <= th && bestDist < (float)bestDist2 * ratio;
+        }
+        if (!accept) continue;
+        if (rule == 3) {
+            if (t2q[bestIdx] >= 0) { q2t[t2q[bestIdx]] = -1; nmatches--; }
+            q2t[q] = bestIdx; t2q[bestIdx] = q; vMatchedDistance[bestIdx] = bestDist; nmatches++;
+            if (check_orientation) rotHist[rot_bin(qangle[q], kps_un[bestIdx].angle)].push_back(q);
+        } else {
+            claimed[bestIdx] = 1; q2t[q] = bestIdx; t2q[bestIdx] = q; nmatches++;
+            if (check_orientation && rule != 0) rotHist[rot_bin(qangle[q], kps_un[bestIdx].angle)].push_back(bestIdx);
+        }
+    }
+    if (check_orientation && rule != 0) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                if (rule == 3) {            // :696-703
+                    const int idx1 = rotHist[i][j];
+                    if (q2t[idx1] >= 0) { t2q[q2t[idx1]] = -1; q2t[idx1] = -1; nmatches--; }
+                } else {                    // :503-507 / :1609-1613
+                    const int i2 = rotHist[i][j];
+                    q2t[t2q[i2]] = -1; t2q[i2] = -1; nmatches--;
+                }
+            }
+        }
+    }
+    return nmatches;
+}
+}

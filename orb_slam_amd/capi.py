@@ -34,6 +34,10 @@ EXPORTS_F = [
     "orbf_image_bounds", "orbf_undistort_grid", "orbf_undistort_grid_batch_device", "orbf_features_in_area",
     "orbf_features_in_area_device",
 ]
+# include/orbs.h (greedy grid-window searches)
+EXPORTS_S = ["orbs_lds_bytes", "orbs_three_maxima", "orbs_window_search_batch_device"]
+RULE_MAPPOINTS, RULE_WINDOW, RULE_BEST, RULE_INIT = 0, 1, 2, 3
+TH_HIGH, TH_LOW = 100, 50
 # include/orbv.h (bag-of-words transform)
 EXPORTS_V = [
     "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_descend", "orbv_descend_device",
@@ -76,6 +80,11 @@ class Bounds(ctypes.Structure):
 
     def astuple(self):
         return (self.min_x, self.max_x, self.min_y, self.max_y, self.inv_w, self.inv_h)
+
+
+class SearchParams(ctypes.Structure):
+    """orbs_params"""
+    _fields_ = [("rule", ctypes.c_int32), ("th", ctypes.c_int32), ("ratio", ctypes.c_float), ("check_orientation", ctypes.c_int32)]
 
 
 GRID_COLS, GRID_ROWS = 64, 48
@@ -133,6 +142,12 @@ def lib():
         L.orbf_undistort_grid_batch_device.argtypes = [ctypes.POINTER(Camera), ctypes.POINTER(Bounds), vp, vp, ci, ci, vp, vp, vp, vp]
         L.orbf_features_in_area.argtypes = [ctypes.POINTER(Bounds), vp, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci]
         L.orbf_features_in_area_device.argtypes = [ctypes.POINTER(Bounds), vp, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp]
+        L.orbs_lds_bytes.argtypes = [ci, ci]
+        L.orbs_lds_bytes.restype = ctypes.c_size_t
+        L.orbs_three_maxima.argtypes = [vp, ci, vp]
+        L.orbs_three_maxima.restype = None
+        L.orbs_window_search_batch_device.argtypes = [ctypes.POINTER(Bounds), ctypes.POINTER(SearchParams), vp, vp, vp, vp, vp, ci, vp,
+                                                      vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp]
         L.orbv_create.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, ctypes.POINTER(vp)]
         L.orbv_load_text.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(vp)]
         L.orbv_destroy.argtypes = [vp]
@@ -478,3 +493,23 @@ def features_in_area(bounds, kps_un, cell_off, cell_feat, qxyr, qlev, cand_cap=N
         if rc != ORBX_OK:
             raise OrbxError(rc, "orbf_features_in_area")
         return seg, cand[:seg[nq]]
+
+
+def three_maxima(sizes):
+    """ORBmatcher::ComputeThreeMaxima on bin sizes (host)"""
+    sz = np.ascontiguousarray(sizes, dtype=np.int32)
+    out = np.zeros(3, np.int32)
+    lib().orbs_three_maxima(sz.ctypes.data, len(sz), out.ctypes.data)
+    return tuple(int(v) for v in out)
+
+
+def window_search_batch_device(bounds, rule, th, ratio, check_orientation, d_kps_un, d_desc, d_cell_off, d_cell_feat, d_nt, cap, d_claimed,
+                               d_qxyr, d_qlev, d_qdesc, d_qangle, d_qvalid, d_nq, qcap, nproblems, d_q2t, d_t2q, d_best, d_second, d_nmatches,
+                               stream=0):
+    """the greedy grid-window searches of ORBmatcher (include/orbs.h), device pointers as ints (0 = NULL)"""
+    prm = SearchParams(rule, th, ratio, 1 if check_orientation else 0)
+    rc = lib().orbs_window_search_batch_device(ctypes.byref(bounds), ctypes.byref(prm), d_kps_un, d_desc, d_cell_off, d_cell_feat, d_nt, cap,
+                                               d_claimed or None, d_qxyr, d_qlev, d_qdesc, d_qangle or None, d_qvalid or None, d_nq, qcap,
+                                               nproblems, d_q2t, d_t2q, d_best or None, d_second or None, d_nmatches, stream or None)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbs_window_search_batch_device")

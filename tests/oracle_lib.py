@@ -56,6 +56,9 @@ def lib():
         L.orc_frame_undistort.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
         L.orc_frame_grid.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         L.orc_frame_features_in_area.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int, c_int, c_void_p]
+        L.orc_three_maxima.argtypes = [c_void_p, c_int, c_void_p]
+        L.orc_window_search.argtypes = [c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
         L.orc_voc_load_text.restype = c_void_p
         L.orc_voc_load_text.argtypes = [ctypes.c_char_p]
         L.orc_voc_create.restype = c_void_p
@@ -366,3 +369,32 @@ def frame_features_in_area(bounds, kps_un, cell_off, cell_feat, x, y, r, min_lev
     n = lib().orc_frame_features_in_area(ctypes.addressof(bounds), kps_un.ctypes.data, cell_off.ctypes.data, cell_feat.ctypes.data,
                                          x, y, r, min_level, max_level, out.ctypes.data)
     return out[:n]
+
+
+def three_maxima(sizes):
+    sz = np.ascontiguousarray(sizes, dtype=np.int32)
+    out = np.zeros(3, np.int32)
+    lib().orc_three_maxima(sz.ctypes.data, len(sz), out.ctypes.data)
+    return tuple(int(v) for v in out)
+
+
+def window_search(bounds, rule, th, ratio, check_orientation, kps_un, desc, cell_off, cell_feat, claimed, qxyr, qlev, qdesc, qangle, qvalid):
+    """one greedy grid-window search problem (oracle/search_oracle.cpp): -> (nmatches, q2t, t2q, best, second)"""
+    kps_un = np.ascontiguousarray(kps_un, dtype=KP_DTYPE)
+    desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+    qxyr = np.ascontiguousarray(qxyr, dtype=np.float32).reshape(-1, 3)
+    qlev = np.ascontiguousarray(qlev, dtype=np.int32).reshape(-1, 2)
+    qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8).reshape(-1, 32)
+    nt, nq = len(kps_un), len(qxyr)
+    cell_off = np.ascontiguousarray(cell_off, dtype=np.int32)
+    cell_feat = np.ascontiguousarray(cell_feat, dtype=np.int32)
+    cl = None if claimed is None else np.ascontiguousarray(claimed, dtype=np.uint8)
+    qa = None if qangle is None else np.ascontiguousarray(qangle, dtype=np.float32)
+    qv = None if qvalid is None else np.ascontiguousarray(qvalid, dtype=np.uint8)
+    q2t = np.zeros(max(nq, 1), np.int32); t2q = np.zeros(max(nt, 1), np.int32)
+    best = np.zeros(max(nq, 1), np.int32); second = np.zeros(max(nq, 1), np.int32)
+    n = lib().orc_window_search(ctypes.addressof(bounds), rule, th, ratio, 1 if check_orientation else 0, kps_un.ctypes.data, desc.ctypes.data,
+                                cell_off.ctypes.data, cell_feat.ctypes.data, nt, cl.ctypes.data if cl is not None else None,
+                                qxyr.ctypes.data, qlev.ctypes.data, qdesc.ctypes.data, qa.ctypes.data if qa is not None else None,
+                                qv.ctypes.data if qv is not None else None, nq, q2t.ctypes.data, t2q.ctypes.data, best.ctypes.data, second.ctypes.data)
+    return n, q2t[:nq], t2q[:nt], best[:nq], second[:nq]

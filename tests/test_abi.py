@@ -58,6 +58,24 @@ def test_library_exports_every_symbol_of_orbf_h_and_bounds_match_oracle():
     assert capi.image_bounds(cams[2]).astuple()[:4] == (0, 640, 0, 480)
 
 
+def test_library_exports_every_symbol_of_orbs_h_and_three_maxima():
+    src = open(os.path.join(ROOT, "include", "orbs.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(orbs_[a-z0-9_]+)\s*\(", src)))
+    L = capi.lib()
+    assert declared == sorted(capi.EXPORTS_S) and not [f for f in declared if not hasattr(L, f)]
+    assert ctypes.sizeof(capi.SearchParams) == 16
+    assert 40 * 1024 < L.orbs_lds_bytes(1000, 1000) < 64 * 1024 and L.orbs_lds_bytes(0, 5) == 0
+    # ORBmatcher::ComputeThreeMaxima (host helper) against the oracle's verbatim restatement
+    import oracle_lib as ol
+    rng = np.random.default_rng(3)
+    cases = [np.zeros(30, np.int32), np.arange(30), np.arange(30)[::-1].copy(), np.full(30, 7), [100, 9, 9] + [0] * 27, [100, 10, 9] + [0] * 27,
+             [0, 50, 0, 50, 4] + [0] * 25, [5] + [0] * 29]
+    cases += [rng.integers(0, 40, 30) for _ in range(200)] + [rng.integers(0, 3, 30) * rng.integers(0, 100, 30) for _ in range(200)]
+    for c in cases:
+        assert capi.three_maxima(c) == ol.three_maxima(c), list(c)
+
+
 def test_vocabulary_table_validation_needs_no_device():
     """orbv_create rejects inconsistent node tables before touching the device; the text loader mirrors the
     reference's header checks (TemplatedVocabulary.h:1366-1370)"""

@@ -1,0 +1,168 @@
+"""GPU parity of the greedy grid-window searches (include/orbs.h) against oracle/search_oracle.cpp: every query's final
+match, both inverse maps, the two scan distances and the return value, for all four accept rules."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from orb_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+CAM = capi.Camera.make(517.3, 516.5, 318.6, 255.3, (0.2624, -0.9531, -0.0054, 0.0026), 640, 480)
+
+
+def _problem(seed, nt, nq, radius, crowd=False, level_mode="pm1"):
+    """a train frame + ordered queries that compete for its features: queries are noisy copies of train features (several
+    per feature when crowd), so later queries meet claimed candidates"""
+    rng = np.random.default_rng(seed)
+    k = np.zeros(nt, dtype=capi.KP_DTYPE)
+    if crowd:
+        cx, cy = rng.random(40) * 600 + 20, rng.random(40) * 440 + 20
+        c = rng.integers(0, 40, nt)
+        k["x"] = (cx[c] + rng.normal(0, 6, nt)).astype(np.float32)
+        k["y"] = (cy[c] + rng.normal(0, 6, nt)).astype(np.float32)
+    else:
+        k["x"] = (rng.random(nt) * 640).astype(np.float32)
+        k["y"] = (rng.random(nt) * 480).astype(np.float32)
+    k["angle"] = (rng.random(nt) * 360).astype(np.float32)
+    k["octave"] = rng.integers(0, 8, nt)
+    k["size"], k["class_id"] = 31, -1
+    desc = synth.descriptors(nt, seed + 1000)
+    if crowd:
+        desc[rng.integers(0, nt, nt // 3)] = desc[0]                     # duplicate descriptors: distance ties inside windows
+    src = rng.integers(0, max(nt, 1), nq) if nt else np.zeros(nq, np.int64)
+    qxyr = np.zeros((nq, 3), np.float32)
+    qlev = np.zeros((nq, 2), np.int32)
+    qdesc = synth.descriptors(nq, seed + 2000)
+    qangle = (rng.random(nq) * 360).astype(np.float32)
+    lv = k["octave"][src] if nt else rng.integers(0, 8, nq)
+    rad = np.full(nq, radius, np.float32) if np.isscalar(radius) else np.asarray(radius, np.float32)[lv]
+    if nt:
+        qxyr[:, 0] = k["x"][src] + rng.normal(0, 1, nq) * rad / 3
+        qxyr[:, 1] = k["y"][src] + rng.normal(0, 1, nq) * rad / 3
+        flips = rng.integers(0, 256, (nq, 6))
+        qd = desc[src].copy()
+        for j in range(6):
+            qd[np.arange(nq), flips[:, j] // 8] ^= (1 << (flips[:, j] % 8)).astype(np.uint8)
+        keep = rng.random(nq) < 0.85
+        qdesc[keep] = qd[keep]
+        near = rng.random(nq) < 0.7
+        qangle[near] = (k["angle"][src][near] + rng.normal(12, 8, int(near.sum()))).astype(np.float32) % np.float32(360)
+    qxyr[:, 2] = rad
+    if level_mode == "pm1":
+        qlev[:, 0], qlev[:, 1] = lv - 1, lv + 1
+    elif level_mode == "same":
+        qlev[:, 0], qlev[:, 1] = lv, lv
+    elif level_mode == "below":
+        qlev[:, 0], qlev[:, 1] = lv - 1, lv
+    else:
+        qlev[:] = -1
+    qvalid = (rng.random(nq) < 0.9).astype(np.uint8)
+    claimed = (rng.random(nt) < 0.2).astype(np.uint8)
+    return dict(kps=k, desc=desc, qxyr=qxyr, qlev=qlev, qdesc=qdesc, qangle=qangle, qvalid=qvalid, claimed=claimed)
+
+
+def _run_batch(problems, rule, th, ratio, check, use_claimed, use_valid, cap, qcap):
+    torch = pytest.importorskip("torch")
+    P = len(problems)
+    b = capi.image_bounds(CAM)
+    K = np.zeros((P, cap), dtype=capi.KP_DTYPE)
+    D = np.zeros((P, cap, 32), np.uint8)
+    C = np.zeros((P, cap), np.uint8)
+    QX = np.zeros((P, qcap, 3), np.float32); QL = np.zeros((P, qcap, 2), np.int32); QD = np.zeros((P, qcap, 32), np.uint8)
+    QA = np.zeros((P, qcap), np.float32); QV = np.zeros((P, qcap), np.uint8)
+    nt = np.array([len(p["kps"]) for p in problems], np.int32)
+    nq = np.array([len(p["qxyr"]) for p in problems], np.int32)
+    for i, p in enumerate(problems):
+        K[i, :nt[i]] = p["kps"]; D[i, :nt[i]] = p["desc"]; C[i, :nt[i]] = p["claimed"]
+        QX[i, :nq[i]] = p["qxyr"]; QL[i, :nq[i]] = p["qlev"]; QD[i, :nq[i]] = p["qdesc"]; QA[i, :nq[i]] = p["qangle"]; QV[i, :nq[i]] = p["qvalid"]
+    st = torch.cuda.current_stream().cuda_stream
+    dK = torch.from_numpy(K.view(np.uint8).reshape(P, cap, 28)).cuda()
+    dnt, dnq = torch.from_numpy(nt).cuda(), torch.from_numpy(nq).cuda()
+    dUn = torch.zeros((P, cap, 28), dtype=torch.uint8, device="cuda")
+    dOff = torch.zeros((P, capi.GRID_CELLS + 1), dtype=torch.int32, device="cuda")
+    dFeat = torch.zeros((P, cap), dtype=torch.int32, device="cuda")
+    capi.undistort_grid_batch_device(CAM, b, dK.data_ptr(), dnt.data_ptr(), P, cap, dUn.data_ptr(), dOff.data_ptr(), dFeat.data_ptr(), st)
+    dD, dC = torch.from_numpy(D).cuda(), torch.from_numpy(C).cuda()
+    dQX, dQL, dQD = torch.from_numpy(QX).cuda(), torch.from_numpy(QL).cuda(), torch.from_numpy(QD).cuda()
+    dQA, dQV = torch.from_numpy(QA).cuda(), torch.from_numpy(QV).cuda()
+    q2t = torch.full((P, qcap), -9, dtype=torch.int32, device="cuda"); t2q = torch.full((P, cap), -9, dtype=torch.int32, device="cuda")
+    best = torch.full((P, qcap), -9, dtype=torch.int32, device="cuda"); second = torch.full((P, qcap), -9, dtype=torch.int32, device="cuda")
+    nm = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+    capi.window_search_batch_device(b, rule, th, ratio, check, dUn.data_ptr(), dD.data_ptr(), dOff.data_ptr(), dFeat.data_ptr(), dnt.data_ptr(), cap,
+                                    dC.data_ptr() if use_claimed else 0, dQX.data_ptr(), dQL.data_ptr(), dQD.data_ptr(), dQA.data_ptr(),
+                                    dQV.data_ptr() if use_valid else 0, dnq.data_ptr(), qcap, P, q2t.data_ptr(), t2q.data_ptr(), best.data_ptr(),
+                                    second.data_ptr(), nm.data_ptr(), st)
+    torch.cuda.synchronize()
+    un = dUn.cpu().numpy().reshape(P, cap * 28).view(capi.KP_DTYPE).reshape(P, cap)
+    off, feat = dOff.cpu().numpy(), dFeat.cpu().numpy()
+    q2t, t2q, best, second, nm = (t.cpu().numpy() for t in (q2t, t2q, best, second, nm))
+    total = 0
+    for i, p in enumerate(problems):
+        want = ol.window_search(b, rule, th, ratio, check, un[i, :nt[i]], p["desc"], off[i], feat[i, :max(off[i][-1], 1)],
+                                p["claimed"] if use_claimed else None, p["qxyr"], p["qlev"], p["qdesc"], p["qangle"],
+                                p["qvalid"] if use_valid else None)
+        assert nm[i] == want[0], (i, nm[i], want[0])
+        np.testing.assert_array_equal(q2t[i, :nq[i]], want[1], err_msg="q2t problem %d" % i)
+        np.testing.assert_array_equal(t2q[i, :nt[i]], want[2], err_msg="t2q problem %d" % i)
+        np.testing.assert_array_equal(best[i, :nq[i]], want[3], err_msg="best problem %d" % i)
+        np.testing.assert_array_equal(second[i, :nq[i]], want[4], err_msg="second problem %d" % i)
+        total += want[0]
+    return total
+
+
+SCALE = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+
+
+@pytest.mark.parametrize("rule,th,ratio,check,level_mode,radius", [
+    (capi.RULE_MAPPOINTS, capi.TH_HIGH, 0.8, False, "below", 4.0 * SCALE),      # Tracking.cc:724 SearchByProjection(F, localMapPoints, th)
+    (capi.RULE_MAPPOINTS, capi.TH_HIGH, 0.8, False, "below", 20.0 * SCALE),
+    (capi.RULE_WINDOW, capi.TH_HIGH, 0.8, True, "same", 100.0),                 # Tracking.cc:502 WindowSearch(last, current, 100, ...)
+    (capi.RULE_WINDOW, capi.TH_HIGH, 0.8, True, "same", 200.0),                 # Tracking.cc:497
+    (capi.RULE_WINDOW, capi.TH_HIGH, 0.9, False, "same", 15.0),                 # Tracking.cc:528 SearchByProjection(last, current, 15, ...)
+    (capi.RULE_BEST, capi.TH_HIGH, 0.9, True, "pm1", 15.0 * SCALE),             # Tracking.cc:565 SearchByProjection(current, last, 15)
+    (capi.RULE_BEST, capi.TH_HIGH, 0.9, False, "all", 30.0),
+    (capi.RULE_INIT, capi.TH_LOW, 0.9, True, "same", 100.0),                    # Tracking.cc:353 SearchForInitialization(..., 100)
+    (capi.RULE_INIT, capi.TH_HIGH, 0.9, False, "all", 40.0),
+], ids=["mappoints_r4", "mappoints_r20", "window100_rot", "window200_rot", "window15", "best15_rot", "best30_all", "init100_rot", "init40_all"])
+def test_rules_against_oracle(rule, th, ratio, check, level_mode, radius):
+    cap = qcap = 1000
+    problems = [_problem(10 + i, nt, nq, radius, crowd=(i % 2 == 1), level_mode=level_mode)
+                for i, (nt, nq) in enumerate([(1000, 1000), (1000, 1000), (700, 1000), (1000, 300), (1, 5), (0, 7), (5, 0), (64, 65), (999, 513)])]
+    if rule == capi.RULE_INIT:
+        for p in problems:                       # SearchForInitialization only takes level-0 queries (src/ORBmatcher.cc:613-614)
+            p["qlev"][:] = 0 if level_mode == "same" else -1
+            p["kps"]["octave"][: len(p["kps"]) * 3 // 4] = 0
+    total = _run_batch(problems, rule, th, ratio, check, use_claimed=(rule == capi.RULE_MAPPOINTS), use_valid=True, cap=cap, qcap=qcap)
+    assert total > 200                           # the scenario really produces matches (and therefore contention)
+
+
+def test_contention_changes_results():
+    """sanity of the scenario itself: with claims honoured the outcome differs from an order-free top-2 (otherwise the
+    sequential masking would be untested)"""
+    p = _problem(77, 1000, 1000, 30.0, crowd=True, level_mode="all")
+    b = capi.image_bounds(CAM)
+    un = ol.frame_undistort(CAM, p["kps"])
+    off, feat = ol.frame_grid(b, un)
+    n1, q2t, _, best, _ = ol.window_search(b, capi.RULE_BEST, 100, 0.9, False, un, p["desc"], off, feat, None, p["qxyr"], p["qlev"], p["qdesc"], None, None)
+    free = 0
+    for q in range(1000):
+        c = ol.frame_features_in_area(b, un, off, feat, *[float(v) for v in p["qxyr"][q]], -1, -1)
+        if len(c):
+            d = [int(np.unpackbits(p["qdesc"][q] ^ p["desc"][i]).sum()) for i in c]
+            free += int(best[q] != min(d))
+    assert free > 20
+
+
+def test_large_frames_and_capacity():
+    radius = 25.0
+    problems = [_problem(200 + i, 2000, 2000, radius, crowd=(i == 1), level_mode="pm1") for i in range(2)]
+    _run_batch(problems, capi.RULE_WINDOW, 100, 0.8, True, False, False, cap=2000, qcap=2000)
+    assert capi.lib().orbs_lds_bytes(2000, 2000) < 160 * 1024 < capi.lib().orbs_lds_bytes(8192, 8192)
+    torch = pytest.importorskip("torch")
+    z = torch.zeros(64, dtype=torch.int32, device="cuda")
+    with pytest.raises(capi.OrbxError) as e:
+        capi.window_search_batch_device(capi.image_bounds(CAM), capi.RULE_BEST, 100, 0.9, False, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(),
+                                        z.data_ptr(), 8192, 0, z.data_ptr(), z.data_ptr(), z.data_ptr(), 0, 0, z.data_ptr(), 8192, 1, z.data_ptr(),
+                                        z.data_ptr(), 0, 0, z.data_ptr())
+    assert e.value.code == capi.ORBX_ERR_CAPACITY
