@@ -5,18 +5,19 @@
 // Mapping.  The sequential dependence runs through ~2 bytes of state per train feature, so one problem = one wavefront
 // and the whole TRAIN FRAME IS STAGED IN LDS in grid (CSR) order: x, y, (index | octave << 16), the 32-byte descriptor,
 // the 3073 cell offsets (u16) and the claim state.  A query then touches only LDS:
-//   * its window is a few grid columns; the cells (col, y0..y1) of one column are one contiguous CSR run, so the wave
-//     takes 8 columns at a time, 8 lanes per column, each lane striding its column's run;
+//   * its window is a few grid columns; the cells (col, y0..y1) of one column are one contiguous CSR run;
 //   * a candidate's key is (distance << 16 | CSR position): CSR position order IS the reference's candidate order
 //     (cells x-major, then y, then push_back order), so the two smallest keys are exactly the best / second-best the
-//     reference's `if(d<best)... else if(d<best2)` scan ends with, first-listed candidate on ties;
-//   * two DPP min-reductions give best and second; the accept rule and the state update are wave-uniform.
-// 64 queries at a time are preloaded (one per lane) and broadcast with v_readlane, so the in-order loop has no global
-// loads on its critical path except the matched keypoint's angle when the rotation histogram is on.
-// Per problem the cost is ~nq x (LDS latency chain + 2 reductions); problems run concurrently, 1-2 per CU.
+//     reference's `if(d<best)... else if(d<best2)` scan ends with, first-listed candidate on ties.
+// Queries go 256 at a time, one per thread (four waves): every lane scans its own window SPECULATIVELY against the claim
+// state of the group start and keeps its four smallest keys; the group is then committed in query order, wave after wave,
+// in vectorised rounds (see k_window_search).  Claims only ever remove candidates, so a query's exact best / second are
+// the first two still-admissible entries of its list; only a list that runs dry makes the wave rescan that one window
+// (8 columns x 8 lanes, two DPP min-reductions).  Nothing on the in-order path touches global memory.
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 
 #include "orbf_math.h"
@@ -26,21 +27,21 @@ namespace orbs {
 
 constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 constexpr int HISTO_LENGTH = 30;             // src/ORBmatcher.cc:42
-constexpr int CHUNK = 64;
 
-struct Layout { uint32_t off16, tx, ty, tmeta, tdesc, state, t2q, q2t, binv, qdesc, hist, total; };
+struct Layout { uint32_t off16, tx, ty, tang, tmeta, tdesc, state, claim, t2q, q2t, binv, hist, total; };
 
 __host__ __device__ inline Layout make_layout(int cap, int qcap) {
     auto al = [](uint32_t x) { return (x + 15u) & ~15u; };
     Layout L;
     uint32_t o = 0;
     L.tdesc = o; o += al((uint32_t)cap * 32);
-    L.qdesc = o; o += CHUNK * 32;
     L.tx = o; o += al((uint32_t)cap * 4);
     L.ty = o; o += al((uint32_t)cap * 4);
+    L.tang = o; o += al((uint32_t)cap * 4);
     L.tmeta = o; o += al((uint32_t)cap * 4);
     L.off16 = o; o += al((ORBF_GRID_CELLS + 1) * 2);
     L.state = o; o += al((uint32_t)cap * 2);
+    L.claim = o; o += al((uint32_t)cap * 4);
     L.t2q = o; o += al((uint32_t)cap * 2);
     L.q2t = o; o += al((uint32_t)qcap * 2);
     L.binv = o; o += al((uint32_t)(cap > qcap ? cap : qcap));
@@ -98,32 +99,120 @@ __device__ __forceinline__ int rot_bin(float a1, float a2) {
 __host__ __device__ inline void three_maxima(const int* sizes, int L, int& ind1, int& ind2, int& ind3) {
     int max1 = 0, max2 = 0, max3 = 0;
     ind1 = ind2 = ind3 = -1;
-    for (int i = 0; i < L; i++) {
+    for (int i = 0; i < L; i++) {           // the reference's if / else-if chain as selects (keeps everything in registers)
         const int s = sizes[i];
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-        else if (s > max3) { max3 = s; ind3 = i; }
+        const bool g1 = s > max1, g2 = !g1 && s > max2, g3 = !g1 && !g2 && s > max3;
+        const int n3 = (g1 || g2) ? max2 : (g3 ? s : max3), j3 = (g1 || g2) ? ind2 : (g3 ? i : ind3);
+        const int n2 = g1 ? max1 : (g2 ? s : max2), j2 = g1 ? ind1 : (g2 ? i : ind2);
+        max3 = n3; ind3 = j3; max2 = n2; ind2 = j2;
+        if (g1) { max1 = s; ind1 = i; }
     }
     if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
     else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
-__global__ __launch_bounds__(64) void k_window_search(orbf_bounds b, orbs_params prm, Args a) {
+// LDS views of one staged problem
+struct Staged {
+    const uint16_t* off16;
+    const float* tx;
+    const float* ty;
+    const uint32_t* tmeta;
+    const uint4* tdesc;
+    const uint16_t* state;
+};
+
+__device__ __forceinline__ uint32_t hamming_key(const uint4& t0, const uint4& t1, const uint4& q0, const uint4& q1) {
+    return __popc(t0.x ^ q0.x) + __popc(t0.y ^ q0.y) + __popc(t0.z ^ q0.z) + __popc(t0.w ^ q0.w) +
+           __popc(t1.x ^ q1.x) + __popc(t1.y ^ q1.y) + __popc(t1.z ^ q1.z) + __popc(t1.w ^ q1.w);
+}
+
+// One candidate of a window: its key (distance << 16 | CSR position) when it is admissible under the current claim state,
+// KEY_NONE when it is in the window but claimed; `inwin` says whether it was in the window at all.
+__device__ __forceinline__ uint32_t candidate_key(const Staged& S, int rule, int j, float x, float y, float r, int minLevel, int maxLevel,
+                                                  const uint4& q0, const uint4& q1, bool& inwin) {
+    const uint32_t meta = S.tmeta[j];
+    inwin = orbf::in_window(S.tx[j], S.ty[j], (int)(meta >> 16), x, y, r, minLevel, maxLevel);
+    if (!inwin) return KEY_NONE;
+    const uint32_t st = S.state[meta & 0xFFFFu];
+    if (rule != ORBS_RULE_INIT && st) return KEY_NONE;                              // `if(F.mvpMapPoints[idx]) continue;`
+    const uint32_t dist = hamming_key(S.tdesc[2 * j], S.tdesc[2 * j + 1], q0, q1);
+    if (rule == ORBS_RULE_INIT && st <= dist) return KEY_NONE;                      // `if(vMatchedDistance[i2]<=dist) continue;`
+    return (dist << 16) | (uint32_t)j;
+}
+
+// The whole wave scans ONE query's window (8 grid columns at a time, 8 lanes per column) under the current claim state and
+// reduces to the two smallest keys: the in-order fallback for queries whose speculative result was overtaken by a claim.
+__device__ __forceinline__ void scan_wave(const Staged& S, int rule, int lane, int x0, int x1, int y0, int y1, float x, float y, float r,
+                                          int minLevel, int maxLevel, const uint4& q0, const uint4& q1, uint32_t& k1, uint32_t& k2) {
+    uint32_t a1 = KEY_NONE, a2 = KEY_NONE;
+    for (int cx = x0; cx <= x1; cx += 8) {
+        const int col = cx + (lane >> 3);
+        int j = 0, jend = 0;
+        if (col <= x1) {
+            j = S.off16[col * ORBF_GRID_ROWS + y0] + (lane & 7);
+            jend = S.off16[col * ORBF_GRID_ROWS + y1 + 1];
+        }
+        for (; j < jend; j += 8) {
+            bool inwin;
+            const uint32_t key = candidate_key(S, rule, j, x, y, r, minLevel, maxLevel, q0, q1, inwin);
+            a2 = min(a2, max(a1, key));          // branch-free two-smallest update (a1 <= a2)
+            a1 = min(a1, key);
+        }
+    }
+    k1 = wave_min_u32(a1);
+    if (a1 == k1) a1 = a2;
+    k2 = wave_min_u32(a1);
+}
+
+__device__ __forceinline__ uint4 lane_u4(const uint4& v, int l) {
+    uint4 r;
+    r.x = (uint32_t)__builtin_amdgcn_readlane((int)v.x, l); r.y = (uint32_t)__builtin_amdgcn_readlane((int)v.y, l);
+    r.z = (uint32_t)__builtin_amdgcn_readlane((int)v.z, l); r.w = (uint32_t)__builtin_amdgcn_readlane((int)v.w, l);
+    return r;
+}
+
+// accept rule of the four searches (wave-uniform or per lane alike)
+__device__ __forceinline__ bool accept_rule(const orbs_params& prm, int bestDist, int bestDist2, int bestLevel, int bestLevel2) {
+    if (prm.rule == ORBS_RULE_MAPPOINTS)       // src/ORBmatcher.cc:114-121
+        return bestDist <= prm.th && !(bestLevel == bestLevel2 && (float)bestDist > prm.ratio * (float)bestDist2);
+    if (prm.rule == ORBS_RULE_WINDOW)          // :476, :585
+        return (float)bestDist <= (float)bestDist2 * prm.ratio && bestDist <= prm.th;
+    if (prm.rule == ORBS_RULE_BEST)            // :1583
+        return bestDist <= prm.th;
+    return bestDist <= prm.th && (float)bestDist < (float)bestDist2 * prm.ratio;      // :652-654
+}
+
+// Per group of 256 queries (one per thread, four waves):
+//  (1) speculative, parallel: every lane scans its own query's window against the claim state as of the group start and
+//      keeps its FOUR smallest keys with the train index / octave of each.
+//  (2) commit, wave after wave, in query order.  A claim can only REMOVE candidates (claims are never released during the
+//      scan; SearchForInitialization's matched distance only decreases), so at any moment a query's exact best / second are
+//      the first two STILL-ADMISSIBLE entries of its list — as long as two survive or the list was never full.  A commit
+//      round therefore refreshes every lane's 4-bit alive mask from the state array, lets every accepting lane post its
+//      claim (LDS atomicMax of stamp | lane: the earliest lane wins), and finalises ALL lanes up to the first one that an
+//      earlier lane of the same round would affect (its best or second was just claimed) or whose list ran dry.  Affected
+//      lanes simply go again next round under the refreshed state; a dry lane has the whole wave rescan its window.
+//      With little contention a wave commits its 64 queries in two or three rounds.
+constexpr int GROUP = 256;
+
+__global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_params prm, Args a) {
     extern __shared__ __align__(16) uint8_t lds[];
     const Layout L = make_layout(a.cap, a.qcap);
     uint16_t* off16 = (uint16_t*)(lds + L.off16);
     float* tx = (float*)(lds + L.tx);
     float* ty = (float*)(lds + L.ty);
+    float* tang = (float*)(lds + L.tang);
     uint32_t* tmeta = (uint32_t*)(lds + L.tmeta);
     uint4* tdesc = (uint4*)(lds + L.tdesc);
     uint16_t* state = (uint16_t*)(lds + L.state);
+    uint32_t* claim_by = (uint32_t*)(lds + L.claim);
     int16_t* t2q = (int16_t*)(lds + L.t2q);
     int16_t* q2t = (int16_t*)(lds + L.q2t);
     uint8_t* binv = lds + L.binv;
-    uint4* qdl = (uint4*)(lds + L.qdesc);
     int* hist = (int*)(lds + L.hist);
+    const Staged S{off16, tx, ty, tmeta, tdesc, state};
 
-    const int p = blockIdx.x, lane = threadIdx.x;
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int nt = min(a.nt[p], a.cap), nq = min(a.nq[p], a.qcap);
     const int rule = prm.rule;
     const size_t tb = (size_t)p * a.cap, qb = (size_t)p * a.qcap;
@@ -132,128 +221,185 @@ __global__ __launch_bounds__(64) void k_window_search(orbf_bounds b, orbs_params
     const orbx_keypoint* kps = a.kps_un + tb;
 
     // ---- stage the train frame in LDS, in grid order
-    for (int i = lane; i <= ORBF_GRID_CELLS; i += 64) off16[i] = (uint16_t)min(coff[i], a.cap);
+    for (int i = tid; i <= ORBF_GRID_CELLS; i += GROUP) off16[i] = (uint16_t)min(coff[i], a.cap);
     const int m = min(coff[ORBF_GRID_CELLS], a.cap);
-    for (int j = lane; j < m; j += 64) {
+    for (int j = tid; j < m; j += GROUP) {
         const int f = cfeat[j];
         const orbx_keypoint kp = kps[f];
         tx[j] = kp.x;
         ty[j] = kp.y;
+        tang[j] = kp.angle;
         tmeta[j] = (uint32_t)f | ((uint32_t)kp.octave << 16);
         const uint4* d = (const uint4*)(a.desc + (tb + f) * 32);
         tdesc[2 * j] = d[0];
         tdesc[2 * j + 1] = d[1];
     }
-    for (int i = lane; i < nt; i += 64) {
+    for (int i = tid; i < nt; i += GROUP) {
         state[i] = rule == ORBS_RULE_INIT ? (uint16_t)0xFFFF : (uint16_t)((a.claimed && a.claimed[tb + i]) ? 1 : 0);
         t2q[i] = -1;
+        claim_by[i] = 0;
     }
-    for (int i = lane; i < nq; i += 64) q2t[i] = -1;
+    for (int i = tid; i < nq; i += GROUP) q2t[i] = -1;
     const int nbin = rule == ORBS_RULE_INIT ? nq : nt;
-    for (int i = lane; i < nbin; i += 64) binv[i] = 255;
-    if (lane < 32) hist[lane] = 0;
+    for (int i = tid; i < nbin; i += GROUP) binv[i] = 255;
+    if (tid < 32) hist[tid] = 0;
     __syncthreads();
 
-    const bool rot_on = prm.check_orientation != 0 && rule != ORBS_RULE_MAPPOINTS;
+    const bool rot_on = (prm.check_orientation & 1) != 0 && rule != ORBS_RULE_MAPPOINTS;
+    const int dbg = prm.check_orientation >> 8;            // development switches (ORBS_DBG): 1 = no speculative scan, 2 = no commit
 
-    for (int q0 = 0; q0 < nq; q0 += CHUNK) {
-        // ---- one query per lane: parameters into registers, descriptors into LDS
-        const int qi = q0 + lane;
+    for (int q0 = 0, group = 0; q0 < nq; q0 += GROUP, ++group) {
+        // ---- one query per thread
+        const int qi = q0 + tid;
         float qx = 0.f, qy = 0.f, qr = 0.f, qa = 0.f;
         int ql0 = 0, ql1 = 0, qv = 0;
+        uint4 qd0 = make_uint4(0, 0, 0, 0), qd1 = qd0;
         if (qi < nq) {
             qx = a.qxyr[(qb + qi) * 3]; qy = a.qxyr[(qb + qi) * 3 + 1]; qr = a.qxyr[(qb + qi) * 3 + 2];
             ql0 = a.qlev[(qb + qi) * 2]; ql1 = a.qlev[(qb + qi) * 2 + 1];
             qv = a.qvalid ? (a.qvalid[qb + qi] != 0) : 1;
             if (a.qangle) qa = a.qangle[qb + qi];
             const uint4* d = (const uint4*)(a.qdesc + (qb + qi) * 32);
-            qdl[2 * lane] = d[0];
-            qdl[2 * lane + 1] = d[1];
+            qd0 = d[0];
+            qd1 = d[1];
         }
-        __syncthreads();
+        // ---- (1) speculative scan of the lane's own query: four smallest keys e0 <= e1 <= e2 <= e3
+        int wx0 = 0, wx1 = -1, wy0 = 0, wy1 = 0;
+        if (qv && !orbf::window_cells(b, qx, qy, qr, &wx0, &wx1, &wy0, &wy1)) { wx0 = 0; wx1 = -1; }
+        if (!qv || (dbg & 1)) wx1 = -1;
+        uint32_t e0 = KEY_NONE, e1 = KEY_NONE, e2 = KEY_NONE, e3 = KEY_NONE;
+        bool any = false;
+        for (int col = wx0; col <= wx1; ++col) {
+            const int jend = off16[col * ORBF_GRID_ROWS + wy1 + 1];
+            for (int j = off16[col * ORBF_GRID_ROWS + wy0]; j < jend; ++j) {
+                bool inwin;
+                uint32_t t = candidate_key(S, rule, j, qx, qy, qr, ql0, ql1, qd0, qd1, inwin);
+                any |= inwin;
+                uint32_t lo;
+                lo = min(e0, t); t = max(e0, t); e0 = lo;
+                lo = min(e1, t); t = max(e1, t); e1 = lo;
+                lo = min(e2, t); t = max(e2, t); e2 = lo;
+                e3 = min(e3, t);
+            }
+        }
+        // train index | octave << 16 of the four entries
+        const uint32_t f0 = e0 != KEY_NONE ? tmeta[e0 & 0xFFFFu] : 0u, f1 = e1 != KEY_NONE ? tmeta[e1 & 0xFFFFu] : 0u;
+        const uint32_t f2 = e2 != KEY_NONE ? tmeta[e2 & 0xFFFFu] : 0u, f3 = e3 != KEY_NONE ? tmeta[e3 & 0xFFFFu] : 0u;
+        const bool full = e3 != KEY_NONE;              // a fifth candidate may exist
         int my_best = -1, my_second = -1;
-        const int nchunk = min(CHUNK, nq - q0);
-        for (int jq = 0; jq < nchunk; jq++) {
-            if (!__builtin_amdgcn_readlane(qv, jq)) continue;
-            const float x = lane_f(qx, jq), y = lane_f(qy, jq), r = lane_f(qr, jq);
-            const int minLevel = __builtin_amdgcn_readlane(ql0, jq), maxLevel = __builtin_amdgcn_readlane(ql1, jq);
-            int x0, x1, y0, y1;
-            if (!orbf::window_cells(b, x, y, r, &x0, &x1, &y0, &y1)) continue;
-            x0 = uni(x0); x1 = uni(x1); y0 = uni(y0); y1 = uni(y1);
-            const uint4 qd0 = qdl[2 * jq], qd1 = qdl[2 * jq + 1];
-            uint32_t a1 = KEY_NONE, a2 = KEY_NONE;
-            int any = 0;
-            for (int cx = x0; cx <= x1; cx += 8) {
-                const int col = cx + (lane >> 3);
-                int j = 0, jend = 0;
-                if (col <= x1) {
-                    j = off16[col * ORBF_GRID_ROWS + y0] + (lane & 7);
-                    jend = off16[col * ORBF_GRID_ROWS + y1 + 1];
-                }
-                for (; j < jend; j += 8) {
-                    const uint32_t meta = tmeta[j];
-                    if (!orbf::in_window(tx[j], ty[j], (int)(meta >> 16), x, y, r, minLevel, maxLevel)) continue;
-                    any = 1;
-                    const uint32_t st = state[meta & 0xFFFFu];
-                    if (rule != ORBS_RULE_INIT && st) continue;                         // `if(F.mvpMapPoints[idx]) continue;`
-                    const uint4 t0 = tdesc[2 * j], t1 = tdesc[2 * j + 1];
-                    const uint32_t dist = __popc(t0.x ^ qd0.x) + __popc(t0.y ^ qd0.y) + __popc(t0.z ^ qd0.z) + __popc(t0.w ^ qd0.w) +
-                                          __popc(t1.x ^ qd1.x) + __popc(t1.y ^ qd1.y) + __popc(t1.z ^ qd1.z) + __popc(t1.w ^ qd1.w);
-                    if (rule == ORBS_RULE_INIT && st <= dist) continue;                 // `if(vMatchedDistance[i2]<=dist) continue;`
-                    const uint32_t key = (dist << 16) | (uint32_t)j;
-                    if (key < a1) { a2 = a1; a1 = key; }
-                    else if (key < a2) a2 = key;
+        __syncthreads();
+
+        // ---- (2) commit: wave after wave, rounds inside a wave
+        for (int w = 0; w < GROUP / 64; ++w) {
+            if (wave == w && !(dbg & 2)) {
+                int cursor = 0;
+                for (int round = 0;; ++round) {
+                    // alive = entries still admissible under the current claim state
+                    uint32_t alive = 0;
+                    if (rule == ORBS_RULE_INIT) {
+                        if (e0 != KEY_NONE && state[f0 & 0xFFFFu] > (e0 >> 16)) alive |= 1u;
+                        if (e1 != KEY_NONE && state[f1 & 0xFFFFu] > (e1 >> 16)) alive |= 2u;
+                        if (e2 != KEY_NONE && state[f2 & 0xFFFFu] > (e2 >> 16)) alive |= 4u;
+                        if (e3 != KEY_NONE && state[f3 & 0xFFFFu] > (e3 >> 16)) alive |= 8u;
+                    } else {
+                        if (e0 != KEY_NONE && state[f0 & 0xFFFFu] == 0) alive |= 1u;
+                        if (e1 != KEY_NONE && state[f1 & 0xFFFFu] == 0) alive |= 2u;
+                        if (e2 != KEY_NONE && state[f2 & 0xFFFFu] == 0) alive |= 4u;
+                        if (e3 != KEY_NONE && state[f3 & 0xFFFFu] == 0) alive |= 8u;
+                    }
+                    // current best / second = first two alive entries
+                    const int ib = alive ? (__ffs((int)alive) - 1) : 4;
+                    const uint32_t rest = alive & ~(1u << (ib & 3));
+                    const int is = (alive && rest) ? (__ffs((int)rest) - 1) : 4;
+                    const uint32_t kb = ib == 0 ? e0 : ib == 1 ? e1 : ib == 2 ? e2 : ib == 3 ? e3 : KEY_NONE;
+                    const uint32_t mb = ib == 0 ? f0 : ib == 1 ? f1 : ib == 2 ? f2 : f3;
+                    const uint32_t ks = is == 1 ? e1 : is == 2 ? e2 : is == 3 ? e3 : KEY_NONE;
+                    const uint32_t ms = is == 1 ? f1 : is == 2 ? f2 : f3;
+                    const int vBest = kb != KEY_NONE ? (int)(kb >> 16) : INT_MAX, vBest2 = ks != KEY_NONE ? (int)(ks >> 16) : INT_MAX;
+                    const int vLev = kb != KEY_NONE ? (int)(mb >> 16) : -1, vLev2 = ks != KEY_NONE ? (int)(ms >> 16) : -1;
+                    const bool active = any && lane >= cursor;
+                    const bool dry = full && __popc(alive) < 2;                // list exhausted: the exact answer needs a rescan
+                    const bool vAccept = !dry && accept_rule(prm, vBest, vBest2, vLev, vLev2);
+                    // accepting lanes post their claim; the earliest lane of this round wins the slot
+                    const uint32_t stamp = (uint32_t)((group * (GROUP / 64) + w) * 128 + round + 1);
+                    const uint32_t bIdx = mb & 0xFFFFu, sIdx = ms & 0xFFFFu;
+                    if (active && vAccept) atomicMax(&claim_by[bIdx], (stamp << 6) | (uint32_t)(63 - lane));
+                    bool affected = false;
+                    if (active && kb != KEY_NONE) { const uint32_t c = claim_by[bIdx]; affected |= (c >> 6) == stamp && (int)(63u - (c & 63u)) < lane; }
+                    if (active && ks != KEY_NONE) { const uint32_t c = claim_by[sIdx]; affected |= (c >> 6) == stamp && (int)(63u - (c & 63u)) < lane; }
+                    const unsigned long long stop = __ballot(active && (affected || dry));
+                    const int F = stop ? (__ffsll((long long)stop) - 1) : 64;
+                    // every lane before F is final: record, and commit its own claim
+                    if (active && lane < F) {
+                        my_best = vBest;
+                        my_second = vBest2;
+                        if (vAccept) {
+                            const int q = q0 + w * 64 + lane;
+                            int bin = 255;
+                            if (rot_on) bin = rot_bin(qa, tang[kb & 0xFFFFu]);
+                            if (rule == ORBS_RULE_INIT) {
+                                const int prev = t2q[bIdx];
+                                if (prev >= 0) q2t[prev] = -1;                 // vnMatches12[vnMatches21[bestIdx2]] = -1
+                                state[bIdx] = (uint16_t)vBest;                 // vMatchedDistance[bestIdx2] = bestDist
+                                binv[q] = (uint8_t)bin;                        // rotHist[bin].push_back(i1)
+                            } else {
+                                state[bIdx] = 1;
+                                binv[bIdx] = (uint8_t)bin;                     // rotHist[bin].push_back(bestIdx2)
+                            }
+                            q2t[q] = (int16_t)bIdx;
+                            t2q[bIdx] = (int16_t)q;
+                        }
+                    }
+                    cursor = F;
+                    if (F >= 64) break;
+                    if (__builtin_amdgcn_readlane((int)dry, F)) {
+                        // the whole wave rescans query F under the current state
+                        uint32_t k1, k2;
+                        scan_wave(S, rule, lane, __builtin_amdgcn_readlane(wx0, F), __builtin_amdgcn_readlane(wx1, F), __builtin_amdgcn_readlane(wy0, F),
+                                  __builtin_amdgcn_readlane(wy1, F), lane_f(qx, F), lane_f(qy, F), lane_f(qr, F), __builtin_amdgcn_readlane(ql0, F),
+                                  __builtin_amdgcn_readlane(ql1, F), lane_u4(qd0, F), lane_u4(qd1, F), k1, k2);
+                        const uint32_t m1 = k1 != KEY_NONE ? tmeta[k1 & 0xFFFFu] : 0u, m2 = k2 != KEY_NONE ? tmeta[k2 & 0xFFFFu] : 0u;
+                        const int bestDist = k1 != KEY_NONE ? (int)(k1 >> 16) : INT_MAX, bestDist2 = k2 != KEY_NONE ? (int)(k2 >> 16) : INT_MAX;
+                        const int bestIdx = (int)(m1 & 0xFFFFu);
+                        const bool accept = accept_rule(prm, bestDist, bestDist2, k1 != KEY_NONE ? (int)(m1 >> 16) : -1, k2 != KEY_NONE ? (int)(m2 >> 16) : -1);
+                        if (lane == F) { my_best = bestDist; my_second = bestDist2; }
+                        if (accept) {
+                            const int q = q0 + w * 64 + F;
+                            int bin = 255;
+                            if (rot_on) bin = rot_bin(lane_f(qa, F), tang[k1 & 0xFFFFu]);
+                            if (lane == 0) {
+                                if (rule == ORBS_RULE_INIT) {
+                                    const int prev = t2q[bestIdx];
+                                    if (prev >= 0) q2t[prev] = -1;
+                                    state[bestIdx] = (uint16_t)bestDist;
+                                    binv[q] = (uint8_t)bin;
+                                } else {
+                                    state[bestIdx] = 1;
+                                    binv[bestIdx] = (uint8_t)bin;
+                                }
+                                q2t[q] = (int16_t)bestIdx;
+                                t2q[bestIdx] = (int16_t)q;
+                            }
+                        }
+                        cursor = F + 1;
+                    }
                 }
             }
-            if (__ballot(any) == 0ull) continue;                  // empty window: the reference `continue`s before the scan
-            const uint32_t k1 = wave_min_u32(a1);
-            if (a1 == k1) a1 = a2;
-            const uint32_t k2 = wave_min_u32(a1);
-            int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx = -1, bestLevel = -1, bestLevel2 = -1;
-            if (k1 != KEY_NONE) { const uint32_t mt = tmeta[k1 & 0xFFFFu]; bestDist = (int)(k1 >> 16); bestIdx = (int)(mt & 0xFFFFu); bestLevel = (int)(mt >> 16); }
-            if (k2 != KEY_NONE) { const uint32_t mt = tmeta[k2 & 0xFFFFu]; bestDist2 = (int)(k2 >> 16); bestLevel2 = (int)(mt >> 16); }
-            if (lane == jq) { my_best = bestDist; my_second = bestDist2; }
-            bool accept;
-            if (rule == ORBS_RULE_MAPPOINTS)
-                accept = bestDist <= prm.th && !(bestLevel == bestLevel2 && (float)bestDist > prm.ratio * (float)bestDist2);
-            else if (rule == ORBS_RULE_WINDOW)
-                accept = (float)bestDist <= (float)bestDist2 * prm.ratio && bestDist <= prm.th;
-            else if (rule == ORBS_RULE_BEST)
-                accept = bestDist <= prm.th;
-            else
-                accept = bestDist <= prm.th && (float)bestDist < (float)bestDist2 * prm.ratio;
-            if (!accept) continue;
-            const int q = q0 + jq;
-            int bin = 255;
-            if (rot_on) bin = rot_bin(lane_f(qa, jq), kps[bestIdx].angle);
-            if (lane == 0) {
-                if (rule == ORBS_RULE_INIT) {
-                    const int prev = t2q[bestIdx];
-                    if (prev >= 0) q2t[prev] = -1;                 // vnMatches12[vnMatches21[bestIdx2]] = -1
-                    state[bestIdx] = (uint16_t)bestDist;           // vMatchedDistance[bestIdx2] = bestDist
-                    binv[q] = (uint8_t)bin;                        // rotHist[bin].push_back(i1)
-                } else {
-                    state[bestIdx] = 1;
-                    binv[bestIdx] = (uint8_t)bin;                  // rotHist[bin].push_back(bestIdx2)
-                }
-                q2t[q] = (int16_t)bestIdx;
-                t2q[bestIdx] = (int16_t)q;
-            }
+            __syncthreads();
         }
         if (qi < nq) {
             if (a.best) a.best[qb + qi] = my_best;
             if (a.second) a.second[qb + qi] = my_second;
         }
-        __syncthreads();
     }
 
     // ---- rotation consistency (the rotHist blocks + ComputeThreeMaxima)
     if (rot_on) {
-        for (int i = lane; i < nbin; i += 64) { const int bn = binv[i]; if (bn != 255) atomicAdd(&hist[bn], 1); }
+        for (int i = tid; i < nbin; i += GROUP) { const int bn = binv[i]; if (bn != 255) atomicAdd(&hist[bn], 1); }
         __syncthreads();
         int i1, i2, i3;
         three_maxima(hist, HISTO_LENGTH, i1, i2, i3);
-        for (int i = lane; i < nbin; i += 64) {
+        for (int i = tid; i < nbin; i += GROUP) {
             const int bn = binv[i];
             if (bn == 255 || bn == i1 || bn == i2 || bn == i3) continue;
             if (rule == ORBS_RULE_INIT) {
@@ -267,10 +413,13 @@ __global__ __launch_bounds__(64) void k_window_search(orbf_bounds b, orbs_params
         __syncthreads();
     }
     int cnt = 0;
-    for (int i = lane; i < nq; i += 64) { const int t = q2t[i]; a.q2t[qb + i] = t; cnt += t >= 0; }
-    for (int i = lane; i < nt; i += 64) a.t2q[tb + i] = t2q[i];
+    for (int i = tid; i < nq; i += GROUP) { const int t = q2t[i]; a.q2t[qb + i] = t; cnt += t >= 0; }
+    for (int i = tid; i < nt; i += GROUP) a.t2q[tb + i] = t2q[i];
     for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s, 64);
-    if (lane == 0) a.nmatches[p] = cnt;
+    __syncthreads();
+    if (lane == 0) atomicAdd(&hist[31], cnt);           // hist[31] is never a rotation bin (HISTO_LENGTH = 30): zero since the start
+    __syncthreads();
+    if (tid == 0) a.nmatches[p] = hist[31];
 }
 
 }  // namespace orbs
@@ -306,9 +455,12 @@ int orbs_window_search_batch_device(const orbf_bounds* b, const orbs_params* prm
         if (hipFuncSetAttribute((const void*)orbs::k_window_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ORBX_ERR_DEVICE;
         attr_bytes = lds;
     }
+    orbs_params prm2 = *prm;
+    prm2.check_orientation = prm->check_orientation ? 1 : 0;
+    if (const char* e = getenv("ORBS_DBG")) prm2.check_orientation |= atoi(e) << 8;
     orbs::Args a{d_kps_un, d_desc, d_cell_off, d_cell_feat, d_nt, d_claimed, d_qxyr, d_qlev, d_qdesc, d_qangle, d_qvalid, d_nq,
                  d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap};
-    hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(64), lds, (hipStream_t)stream, *b, *prm, a);
+    hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, *b, prm2, a);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
 

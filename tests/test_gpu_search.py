@@ -16,7 +16,7 @@ def _problem(seed, nt, nq, radius, crowd=False, level_mode="pm1"):
     per feature when crowd), so later queries meet claimed candidates"""
     rng = np.random.default_rng(seed)
     k = np.zeros(nt, dtype=capi.KP_DTYPE)
-    if crowd:
+    if crowd and nt:
         cx, cy = rng.random(40) * 600 + 20, rng.random(40) * 440 + 20
         c = rng.integers(0, 40, nt)
         k["x"] = (cx[c] + rng.normal(0, 6, nt)).astype(np.float32)
@@ -28,7 +28,7 @@ def _problem(seed, nt, nq, radius, crowd=False, level_mode="pm1"):
     k["octave"] = rng.integers(0, 8, nt)
     k["size"], k["class_id"] = 31, -1
     desc = synth.descriptors(nt, seed + 1000)
-    if crowd:
+    if crowd and nt:
         desc[rng.integers(0, nt, nt // 3)] = desc[0]                     # duplicate descriptors: distance ties inside windows
     src = rng.integers(0, max(nt, 1), nq) if nt else np.zeros(nq, np.int64)
     qxyr = np.zeros((nq, 3), np.float32)
