@@ -18,6 +18,8 @@
  *                                      (src/ORBmatcher.cc:87-111, :201-222, :454-474, :629-650, ...)
  *   orbm_match_top2_segments[_device]
  *                                   <- the same scan over a per-query candidate list (window / vocabulary node): "next" row N2
+ *   orbm_distinctive[_device]       <- MapPoint::ComputeDistinctiveDescriptors(): N x N Hamming distances of a map point's observed
+ *                                      descriptors, the one with the least median distance to the rest   src/MapPoint.cc:185-250 ("next" row N4)
  *   orbm_count_accepted             <- accept rule `best<=TH && (float)best < mfNNratio*(float)second` (src/ORBmatcher.cc:224-226)
  *
  * All compute runs in hand-written HIP kernels for gfx950.  There is NO CPU fallback: every
@@ -129,6 +131,14 @@ int orbm_match_top2_segments_device(const uint8_t* dQ, int nq, const uint8_t* dT
                                     const int32_t* d_cand, int32_t* d_best_idx, int32_t* d_best, int32_t* d_second, void* stream);
 /* number of queries passing  best <= th && (float)best < ratio*(float)second  (host arrays) */
 int orbm_count_accepted(const int32_t* best, const int32_t* second, int nq, int th, float ratio);
+
+/* MapPoint::ComputeDistinctiveDescriptors for M map points at once (src/MapPoint.cc:216-244): point p owns the descriptors
+ * [seg_off[p], seg_off[p+1]) of `desc`; best_idx[p] = the index INSIDE its segment of the descriptor whose sorted row of
+ * distances (self included) has the smallest element at position (int)(0.5*(N-1)) — first such row on ties —, best_median[p]
+ * that value; -1 / INT_MAX for an empty segment. */
+int orbm_distinctive(const uint8_t* desc, const int32_t* seg_off, int npoints, int32_t* best_idx, int32_t* best_median, int device);
+int orbm_distinctive_device(const uint8_t* d_desc, const int32_t* d_seg_off, int npoints, int32_t* d_best_idx,
+                            int32_t* d_best_median, void* stream);
 
 /* ---- diagnostics (stage dumps for the parity tests; not part of the drop-in surface) ------------ */
 #define ORBX_DBG_PLANE      0   /* unblurred level plane, tight w*h bytes */

@@ -15,6 +15,7 @@
 // (vpMapPointMatches2[i2] = pMP1 ...).  Candidate windows come from frame_oracle.cpp (Frame::GetFeaturesInArea).
 // PARITY UNPINNED (ORBmatcher.cc cannot be compiled here: Frame / KeyFrame / MapPoint / g2o / Boost).
 // =====================================================================================
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -59,6 +60,31 @@ void orc_three_maxima(const int32_t* sizes, int L, int32_t* ind) {
     int a = -1, b = -1, c = -1;
     ComputeThreeMaxima(h.data(), L, a, b, c);
     ind[0] = a; ind[1] = b; ind[2] = c;
+}
+
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:216-244) for one map point's observed descriptors: returns BestIdx,
+// *best_median = BestMedian; -1 / INT_MAX when there are none (the reference returns before touching mDescriptor).
+int orc_distinctive(const uint8_t* desc, int N, int32_t* best_median) {
+    *best_median = INT_MAX;
+    if (N <= 0) return -1;
+    std::vector<std::vector<float> > Distances(N, std::vector<float>(N));
+    for (int i = 0; i < N; i++) {
+        Distances[i][i] = 0;
+        for (int j = i + 1; j < N; j++) {
+            int distij = orc_hamming256(desc + (size_t)i * 32, desc + (size_t)j * 32);
+            Distances[i][j] = distij;
+            Distances[j][i] = distij;
+        }
+    }
+    int BestMedian = INT_MAX, BestIdx = 0;
+    for (int i = 0; i < N; i++) {
+        std::vector<int> vDists(Distances[i].begin(), Distances[i].end());
+        std::sort(vDists.begin(), vDists.end());
+        int median = vDists[0.5 * (N - 1)];
+        if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+    }
+    *best_median = BestMedian;
+    return BestIdx;
 }
 
 // One search problem.  q2t[nq]: the train feature a query ended up matched to (-1 none); t2q[nt]: the query a train feature

@@ -26,7 +26,7 @@ EXPORTS = [
     "orbx_default_params", "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_scale_factor",
     "orbx_max_keypoints", "orbx_last_error", "orbx_extract", "orbx_extract_batch_device",
     "orbm_hamming256", "orbm_match_top2", "orbm_match_top2_device", "orbm_match_top2_batch_device",
-    "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
+    "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbm_distinctive", "orbm_distinctive_device", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
     "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element", "orbx_debug_geometry",
 ]
 # include/orbf.h (Frame-side steps: undistortion, search grid, window query)
@@ -128,6 +128,8 @@ def lib():
         L.orbm_count_accepted.argtypes = [vp, vp, ci, ci, cf]
         L.orbm_match_top2_segments.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci]
         L.orbm_match_top2_segments_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp]
+        L.orbm_distinctive.argtypes = [vp, vp, ci, vp, vp, ci]
+        L.orbm_distinctive_device.argtypes = [vp, vp, ci, vp, vp, vp]
         L.orbx_debug_set_stop_after.argtypes = [vp, ci]
         L.orbx_debug_level_size.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.orbx_debug_fetch.argtypes = [vp, ci, ci, ci, vp, cl]
@@ -513,3 +515,15 @@ def window_search_batch_device(bounds, rule, th, ratio, check_orientation, d_kps
                                                nproblems, d_q2t, d_t2q, d_best or None, d_second or None, d_nmatches, stream or None)
     if rc != ORBX_OK:
         raise OrbxError(rc, "orbs_window_search_batch_device")
+
+
+def distinctive(desc, seg_off, device=0):
+    """MapPoint::ComputeDistinctiveDescriptors for many map points (CSR of observed descriptors): -> (best_idx, best_median)"""
+    desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+    seg = np.ascontiguousarray(seg_off, dtype=np.int32)
+    M = len(seg) - 1
+    idx = np.empty(max(M, 1), np.int32); med = np.empty(max(M, 1), np.int32)
+    rc = lib().orbm_distinctive(desc.ctypes.data if len(desc) else None, seg.ctypes.data, M, idx.ctypes.data, med.ctypes.data, device)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbm_distinctive")
+    return idx[:M], med[:M]

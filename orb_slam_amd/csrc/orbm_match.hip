@@ -227,6 +227,45 @@ static int ensure_scratch(size_t bytes) {
     return ORBX_OK;
 }
 
+
+// MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:216-244), one wave per map point.  Lane i owns row i of
+// the N x N distance matrix: it never stores the row — the median (element (int)(0.5*(N-1)) of the sorted row) is found by
+// bisection on the value range 0..256, each step counting the row's distances <= mid by recomputing them (8 xor + 8 popcount
+// per pair; the other descriptors arrive by wave-uniform scalar loads).  The winner is the smallest (median << 16 | i).
+__global__ __launch_bounds__(MATCH_BLOCK) void k_distinctive(const uint32_t* __restrict__ desc, const int32_t* __restrict__ seg_off, int npoints,
+                                                            int32_t* __restrict__ best_idx, int32_t* __restrict__ best_median) {
+    const int lane = threadIdx.x & 63;
+    const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (MATCH_BLOCK / 64) + (threadIdx.x >> 6)));
+    if (p >= npoints) return;
+    const int s0 = seg_off[p], N = seg_off[p + 1] - s0;
+    if (N <= 0) { if (lane == 0) { best_idx[p] = -1; best_median[p] = INT_MAX; } return; }
+    const int m = (int)(0.5 * (double)(N - 1));              // `vDists[0.5*(N-1)]`
+    const uint32_t* D = desc + (size_t)s0 * 8;
+    uint32_t bestkey = 0xFFFFFFFFu;
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int i = i0 + lane;
+        uint32_t q[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) q[w] = i < N ? D[(size_t)i * 8 + w] : 0u;
+        int lo = 0, hi = 256;                                // smallest v with #{j : d(i,j) <= v} >= m + 1
+        while (__any(lo < hi)) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < N; j++) {
+                const uint32_t* t = D + (size_t)j * 8;       // wave-uniform address: scalar loads
+                uint32_t d = 0;
+#pragma unroll
+                for (int w = 0; w < 8; w++) d = bcnt_acc(q[w] ^ t[w], d);
+                cnt += (int)d <= mid;
+            }
+            if (lo < hi) { if (cnt >= m + 1) hi = mid; else lo = mid + 1; }
+        }
+        if (i < N) bestkey = min(bestkey, ((uint32_t)lo << 16) | (uint32_t)i);
+    }
+    for (int s = 32; s > 0; s >>= 1) bestkey = min(bestkey, (uint32_t)__shfl_xor((int)bestkey, s, 64));
+    if (lane == 0) { best_idx[p] = (int32_t)(bestkey & 0xFFFFu); best_median[p] = (int32_t)(bestkey >> 16); }
+}
+
 }  // namespace orbx
 
 using namespace orbx;
@@ -348,6 +387,39 @@ int orbm_match_top2(const uint8_t* Q, int nq, const uint8_t* T, int nt, int32_t*
     if (dQ) (void)hipFree(dQ);
     if (dT) (void)hipFree(dT);
     if (dout) (void)hipFree(dout);
+    return rc;
+}
+
+
+int orbm_distinctive_device(const uint8_t* d_desc, const int32_t* d_seg_off, int npoints, int32_t* d_best_idx, int32_t* d_best_median, void* stream) {
+    if (npoints < 0) return ORBX_ERR_ARG;
+    if (npoints == 0) return ORBX_OK;
+    if (!d_desc || !d_seg_off || !d_best_idx || !d_best_median) return ORBX_ERR_ARG;
+    const int per_block = orbx::MATCH_BLOCK / 64;
+    hipLaunchKernelGGL(orbx::k_distinctive, dim3((npoints + per_block - 1) / per_block), dim3(orbx::MATCH_BLOCK), 0, (hipStream_t)stream,
+                       (const uint32_t*)d_desc, d_seg_off, npoints, d_best_idx, d_best_median);
+    return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbm_distinctive(const uint8_t* desc, const int32_t* seg_off, int npoints, int32_t* best_idx, int32_t* best_median, int device) {
+    if (npoints < 0 || (npoints > 0 && (!seg_off || !best_idx || !best_median))) return ORBX_ERR_ARG;
+    if (npoints == 0) return ORBX_OK;
+    const int total = seg_off[npoints];
+    if (total < 0 || total >= 65536 * 64 || (total > 0 && !desc)) return ORBX_ERR_ARG;
+    for (int p = 0; p < npoints; p++) if (seg_off[p + 1] < seg_off[p] || seg_off[p + 1] - seg_off[p] > 65535) return ORBX_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    uint8_t* d = nullptr;
+    const size_t o_seg = (size_t)std::max(total, 1) * 32, o_out = o_seg + ((size_t)npoints + 1) * 4, bytes = o_out + (size_t)npoints * 8;
+    int rc = ORBX_ERR_DEVICE;
+    if (hipMalloc(&d, bytes) == hipSuccess && (total == 0 || hipMemcpy(d, desc, (size_t)total * 32, hipMemcpyHostToDevice) == hipSuccess) &&
+        hipMemcpy(d + o_seg, seg_off, ((size_t)npoints + 1) * 4, hipMemcpyHostToDevice) == hipSuccess) {
+        int32_t* out = (int32_t*)(d + o_out);
+        rc = orbm_distinctive_device(d, (const int32_t*)(d + o_seg), npoints, out, out + npoints, nullptr);
+        if (rc == ORBX_OK && (hipMemcpy(best_idx, out, (size_t)npoints * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                              hipMemcpy(best_median, out + npoints, (size_t)npoints * 4, hipMemcpyDeviceToHost) != hipSuccess))
+            rc = ORBX_ERR_DEVICE;
+    }
+    if (d) (void)hipFree(d);
     return rc;
 }
 

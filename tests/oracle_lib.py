@@ -56,6 +56,7 @@ def lib():
         L.orc_frame_undistort.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
         L.orc_frame_grid.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         L.orc_frame_features_in_area.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int, c_int, c_void_p]
+        L.orc_distinctive.argtypes = [c_void_p, c_int, c_void_p]
         L.orc_three_maxima.argtypes = [c_void_p, c_int, c_void_p]
         L.orc_window_search.argtypes = [c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
@@ -398,3 +399,11 @@ def window_search(bounds, rule, th, ratio, check_orientation, kps_un, desc, cell
                                 qxyr.ctypes.data, qlev.ctypes.data, qdesc.ctypes.data, qa.ctypes.data if qa is not None else None,
                                 qv.ctypes.data if qv is not None else None, nq, q2t.ctypes.data, t2q.ctypes.data, best.ctypes.data, second.ctypes.data)
     return n, q2t[:nq], t2q[:nt], best[:nq], second[:nq]
+
+
+def distinctive(desc):
+    """one map point's observed descriptors -> (BestIdx, BestMedian)"""
+    desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+    med = ctypes.c_int32()
+    idx = lib().orc_distinctive(desc.ctypes.data if len(desc) else None, len(desc), ctypes.byref(med))
+    return idx, med.value

@@ -112,3 +112,29 @@ def test_candidate_lists_equal_dense_when_lists_are_full():
     b = capi.match_top2(Q, T)
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
+
+
+def test_distinctive_descriptors():
+    """MapPoint::ComputeDistinctiveDescriptors batched over map points: least-median row, first on ties"""
+    rng = np.random.default_rng(11)
+    sizes = [1, 2, 3, 4, 5, 7, 8, 16, 33, 63, 64, 65, 100, 130, 0, 257, 2, 2, 6] + list(rng.integers(1, 40, 300))
+    segs, descs = [0], []
+    for i, n in enumerate(sizes):
+        d = synth.descriptors(n, 500 + i) if n else np.zeros((0, 32), np.uint8)
+        if n >= 4 and i % 3 == 0:
+            base = d[0].copy()                       # a tight cluster (observations of one point): few bits apart, many ties
+            for r in range(n):
+                d[r] = base
+                for bit in rng.integers(0, 256, int(rng.integers(0, 12))):
+                    d[r, bit // 8] ^= np.uint8(1 << (bit % 8))
+        if n >= 2 and i % 5 == 1:
+            d[1:] = d[0]                             # all identical: every median 0 -> index 0
+        descs.append(d)
+        segs.append(segs[-1] + n)
+    desc = np.concatenate(descs)
+    gi, gm = capi.distinctive(desc, np.array(segs, np.int32))
+    for p, n in enumerate(sizes):
+        wi, wm = orc.distinctive(desc[segs[p]:segs[p + 1]])
+        assert (gi[p], gm[p]) == (wi, wm), (p, n, gi[p], gm[p], wi, wm)
+    gi, gm = capi.distinctive(np.zeros((0, 32), np.uint8), np.array([0], np.int32))
+    assert len(gi) == 0
