@@ -15,6 +15,9 @@
  *                           (accept best <= th)
  *   ORBS_RULE_INIT       <- int ORBmatcher::SearchForInitialization(Frame&, Frame&, vector<Point2f>&, vector<int>&, int)   :596-716
  *                           (a train feature may be re-matched by a later query with a strictly smaller distance)
+ *   ORBS_RULE_BOW        <- int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                 :155-281
+ *                           (candidates = the features of the same vocabulary node instead of a grid window:
+ *                           orbs_bow_ranges_batch_device + orbs_list_search_batch_device; accept best <= th && best < ratio*second)
  *   rotation filter      <- the rotHist blocks of those functions + ORBmatcher::ComputeThreeMaxima            :1748-1789
  *   candidate windows    <- Frame::GetFeaturesInArea                                                          src/Frame.cc:200-265
  *
@@ -43,6 +46,7 @@ extern "C" {
 #define ORBS_RULE_WINDOW    1
 #define ORBS_RULE_BEST      2
 #define ORBS_RULE_INIT      3
+#define ORBS_RULE_BOW       4
 
 #define ORBS_TH_HIGH 100      /* ORBmatcher::TH_HIGH src/ORBmatcher.cc:40 */
 #define ORBS_TH_LOW  50       /* ORBmatcher::TH_LOW  src/ORBmatcher.cc:41 */
@@ -70,6 +74,27 @@ int orbs_window_search_batch_device(const orbf_bounds* b, const orbs_params* prm
                                     const uint8_t* d_qvalid, const int32_t* d_nq, int qcap, int nproblems,
                                     int32_t* d_q2t, int32_t* d_t2q, int32_t* d_best, int32_t* d_second, int32_t* d_nmatches,
                                     void* stream);
+
+/* The same in-order search over an explicit candidate LIST instead of a grid window: problem p's train features are listed in
+ * d_list + p*cap (d_nlist[p] entries; a feature appears at most once), query q scans the list positions
+ * [d_qrange[2q], d_qrange[2q+1]) in list order.  With the FeatureVector CSR of orbv_transform_batch_device as the list
+ * (d_list = fv_feat, d_nlist = fv_off[n_fv]) and ranges from orbs_bow_ranges_batch_device this is SearchByBoW.
+ * d_qindex (may be NULL): query q takes its descriptor / angle / valid flag from slot d_qindex[q] of the query-side arrays
+ * instead of slot q (so the query frame's own FeatureVector order can be used without gathering).  d_q2t is indexed by query
+ * position q.  Every rule is accepted; ORBS_RULE_BOW is the one the reference uses here. */
+int orbs_list_search_batch_device(const orbs_params* prm, const orbx_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_list,
+                                  const int32_t* d_nlist, const int32_t* d_nt, int cap, const uint8_t* d_claimed,
+                                  const int32_t* d_qrange, const int32_t* d_qindex, const uint8_t* d_qdesc, const float* d_qangle,
+                                  const uint8_t* d_qvalid, const int32_t* d_nq, int qcap, int nproblems,
+                                  int32_t* d_q2t, int32_t* d_t2q, int32_t* d_best, int32_t* d_second, int32_t* d_nmatches, void* stream);
+
+/* SearchByBoW's merge walk (src/ORBmatcher.cc:171-260) as data: for problem p, query position j of the QUERY frame's
+ * FeatureVector CSR (node ids d_fvq_node + p*cap, offsets d_fvq_off + p*(cap+1), d_nfv_q[p] nodes) gets the list range of
+ * the SAME node in the TRAIN frame's FeatureVector (empty when the train frame has no feature under that node).  Also
+ * writes d_nq[p] = the number of query positions (fvq_off[n_fv]). */
+int orbs_bow_ranges_batch_device(const uint32_t* d_fvq_node, const int32_t* d_fvq_off, const int32_t* d_nfv_q,
+                                 const uint32_t* d_fvt_node, const int32_t* d_fvt_off, const int32_t* d_nfv_t, int cap,
+                                 int nproblems, int32_t* d_qrange, int32_t* d_nq, void* stream);
 
 /* ORBmatcher::ComputeThreeMaxima on a histogram of bin sizes (host, re-entrant): ind[3], -1 = none */
 void orbs_three_maxima(const int32_t* sizes, int L, int32_t* ind);

@@ -9,6 +9,7 @@
 //           ORBmatcher::SearchByProjection(Frame&, Frame&, int, vector<MapPoint*>&)       :519-594 (no rotation check)
 //   rule 2  ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, float)      :1508-1619
 //   rule 3  ORBmatcher::SearchForInitialization(Frame&, Frame&, vector<Point2f>&, vector<int>&, int)   :596-716
+//   ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                        :155-281   (orc_search_by_bow)
 //   ORBmatcher::ComputeThreeMaxima                                                        :1748-1789
 // What stays with the caller (pointer-graph work): which queries are valid (pMP != NULL, !isBad(), mbTrackInView, level
 // bounds), their window centres / radii (projection, RadiusByViewingCos, scale factors) and what a match means
@@ -85,6 +86,63 @@ int orc_distinctive(const uint8_t* desc, int N, int32_t* best_median) {
     }
     *best_median = BestMedian;
     return BestIdx;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:155-281) on flattened arrays: the two
+// FeatureVectors as CSR (std::map order = ascending node id), kf_valid[i] = (pMP != NULL && !pMP->isBad()) of key-frame feature i.
+// Outputs: t2q[nF] = the key-frame feature whose map point vpMapPointMatches[iF] ends up holding (-1 none), q2t[nKF] its inverse,
+// best / second[nKF] = the two distances the scan of key-frame feature i left (-1 when it was never visited).
+int orc_search_by_bow(int th, float ratio, int check_orientation,
+                      const uint32_t* kf_node, const int32_t* kf_off, const uint32_t* kf_feat, int kf_nnodes,
+                      const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_valid, int nKF,
+                      const uint32_t* f_node, const int32_t* f_off, const uint32_t* f_feat, int f_nnodes,
+                      const uint8_t* f_desc, const float* f_angle, int nF,
+                      int32_t* q2t, int32_t* t2q, int32_t* best_out, int32_t* second_out) {
+    int nmatches = 0;
+    for (int i = 0; i < nKF; i++) { q2t[i] = -1; best_out[i] = -1; second_out[i] = -1; }
+    for (int i = 0; i < nF; i++) t2q[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int a = 0, b = 0;
+    while (a < kf_nnodes && b < f_nnodes) {
+        if (kf_node[a] == f_node[b]) {
+            for (int iKF = kf_off[a]; iKF < kf_off[a + 1]; iKF++) {
+                const unsigned realIdxKF = kf_feat[iKF];
+                if (!kf_valid[realIdxKF]) continue;
+                int bestDist1 = INT_MAX, bestIdxF = -1, bestDist2 = INT_MAX;
+                for (int iF = f_off[b]; iF < f_off[b + 1]; iF++) {
+                    const unsigned realIdxF = f_feat[iF];
+                    if (t2q[realIdxF] >= 0) continue;                    // `if(vpMapPointMatches[realIdxF]) continue;`
+                    const int dist = orc_hamming256(kf_desc + (size_t)realIdxKF * 32, f_desc + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                best_out[realIdxKF] = bestDist1;
+                second_out[realIdxKF] = bestDist2;
+                if (bestDist1 <= th) {
+                    if ((float)bestDist1 < ratio * (float)bestDist2) {
+                        t2q[bestIdxF] = (int)realIdxKF;
+                        q2t[realIdxKF] = bestIdxF;
+                        if (check_orientation) rotHist[rot_bin(kf_angle[realIdxKF], f_angle[bestIdxF])].push_back(bestIdxF);
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (kf_node[a] < f_node[b]) {
+            while (a < kf_nnodes && kf_node[a] < f_node[b]) a++;        // lower_bound(Fit->first)
+        } else {
+            while (b < f_nnodes && f_node[b] < kf_node[a]) b++;
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { q2t[t2q[rotHist[i][j]]] = -1; t2q[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
 }
 
 // One search problem.  q2t[nq]: the train feature a query ended up matched to (-1 none); t2q[nt]: the query a train feature

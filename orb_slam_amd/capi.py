@@ -35,8 +35,9 @@ EXPORTS_F = [
     "orbf_features_in_area_device",
 ]
 # include/orbs.h (greedy grid-window searches)
-EXPORTS_S = ["orbs_lds_bytes", "orbs_three_maxima", "orbs_window_search_batch_device"]
-RULE_MAPPOINTS, RULE_WINDOW, RULE_BEST, RULE_INIT = 0, 1, 2, 3
+EXPORTS_S = ["orbs_lds_bytes", "orbs_three_maxima", "orbs_window_search_batch_device", "orbs_list_search_batch_device",
+             "orbs_bow_ranges_batch_device"]
+RULE_MAPPOINTS, RULE_WINDOW, RULE_BEST, RULE_INIT, RULE_BOW = 0, 1, 2, 3, 4
 TH_HIGH, TH_LOW = 100, 50
 # include/orbv.h (bag-of-words transform)
 EXPORTS_V = [
@@ -150,6 +151,9 @@ def lib():
         L.orbs_three_maxima.restype = None
         L.orbs_window_search_batch_device.argtypes = [ctypes.POINTER(Bounds), ctypes.POINTER(SearchParams), vp, vp, vp, vp, vp, ci, vp,
                                                       vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.orbs_list_search_batch_device.argtypes = [ctypes.POINTER(SearchParams), vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci,
+                                                    vp, vp, vp, vp, vp, vp]
+        L.orbs_bow_ranges_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]
         L.orbv_create.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, ctypes.POINTER(vp)]
         L.orbv_load_text.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(vp)]
         L.orbv_destroy.argtypes = [vp]
@@ -527,3 +531,20 @@ def distinctive(desc, seg_off, device=0):
     if rc != ORBX_OK:
         raise OrbxError(rc, "orbm_distinctive")
     return idx[:M], med[:M]
+
+
+def list_search_batch_device(rule, th, ratio, check_orientation, d_kps, d_desc, d_list, d_nlist, d_nt, cap, d_claimed, d_qrange, d_qindex, d_qdesc,
+                             d_qangle, d_qvalid, d_nq, qcap, nproblems, d_q2t, d_t2q, d_best, d_second, d_nmatches, stream=0):
+    """the in-order search over explicit candidate lists (SearchByBoW with the FeatureVector CSR as the list)"""
+    prm = SearchParams(rule, th, ratio, 1 if check_orientation else 0)
+    rc = lib().orbs_list_search_batch_device(ctypes.byref(prm), d_kps, d_desc, d_list, d_nlist, d_nt, cap, d_claimed or None, d_qrange, d_qindex or None,
+                                             d_qdesc, d_qangle or None, d_qvalid or None, d_nq, qcap, nproblems, d_q2t, d_t2q, d_best or None,
+                                             d_second or None, d_nmatches, stream or None)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbs_list_search_batch_device")
+
+
+def bow_ranges_batch_device(d_fvq_node, d_fvq_off, d_nfv_q, d_fvt_node, d_fvt_off, d_nfv_t, cap, nproblems, d_qrange, d_nq, stream=0):
+    rc = lib().orbs_bow_ranges_batch_device(d_fvq_node, d_fvq_off, d_nfv_q, d_fvt_node, d_fvt_off, d_nfv_t, cap, nproblems, d_qrange, d_nq, stream or None)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbs_bow_ranges_batch_device")

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -69,6 +70,10 @@ struct Args {
     int32_t* second;
     int32_t* nmatches;
     int cap, qcap;
+    // list mode (orbs_list_search_batch_device): cell_feat is the candidate list, nlist its length, qrange the per-query runs
+    const int32_t* nlist;
+    const int32_t* qrange;
+    const int32_t* qindex;
 };
 
 // minimum over the 64 lanes, returned wave-uniform: 4 DPP steps inside each row of 16, then the 4 rows via readlane
@@ -142,9 +147,18 @@ __device__ __forceinline__ uint32_t candidate_key(const Staged& S, int rule, int
 
 // The whole wave scans ONE query's window (8 grid columns at a time, 8 lanes per column) under the current claim state and
 // reduces to the two smallest keys: the in-order fallback for queries whose speculative result was overtaken by a claim.
-__device__ __forceinline__ void scan_wave(const Staged& S, int rule, int lane, int x0, int x1, int y0, int y1, float x, float y, float r,
+__device__ __forceinline__ void scan_wave(const Staged& S, int rule, bool list_mode, int lane, int x0, int x1, int y0, int y1, float x, float y, float r,
                                           int minLevel, int maxLevel, const uint4& q0, const uint4& q1, uint32_t& k1, uint32_t& k2) {
     uint32_t a1 = KEY_NONE, a2 = KEY_NONE;
+    if (list_mode) {                                   // one explicit run [y0, y1): all 64 lanes stride it
+        for (int j = y0 + lane; j < y1; j += 64) {
+            bool inwin;
+            const uint32_t key = candidate_key(S, rule, j, x, y, r, minLevel, maxLevel, q0, q1, inwin);
+            a2 = min(a2, max(a1, key));
+            a1 = min(a1, key);
+        }
+        x1 = x0 - 1;
+    }
     for (int cx = x0; cx <= x1; cx += 8) {
         const int col = cx + (lane >> 3);
         int j = 0, jend = 0;
@@ -179,7 +193,7 @@ __device__ __forceinline__ bool accept_rule(const orbs_params& prm, int bestDist
         return (float)bestDist <= (float)bestDist2 * prm.ratio && bestDist <= prm.th;
     if (prm.rule == ORBS_RULE_BEST)            // :1583
         return bestDist <= prm.th;
-    return bestDist <= prm.th && (float)bestDist < (float)bestDist2 * prm.ratio;      // :652-654
+    return bestDist <= prm.th && (float)bestDist < prm.ratio * (float)bestDist2;      // :652-654 (INIT), :224-226 (BOW)
 }
 
 // Per group of 256 queries (one per thread, four waves):
@@ -216,13 +230,14 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
     const int nt = min(a.nt[p], a.cap), nq = min(a.nq[p], a.qcap);
     const int rule = prm.rule;
     const size_t tb = (size_t)p * a.cap, qb = (size_t)p * a.qcap;
+    const bool list_mode = a.qrange != nullptr;
     const int32_t* coff = a.cell_off + (size_t)p * (ORBF_GRID_CELLS + 1);
     const int32_t* cfeat = a.cell_feat + tb;
     const orbx_keypoint* kps = a.kps_un + tb;
 
-    // ---- stage the train frame in LDS, in grid order
-    for (int i = tid; i <= ORBF_GRID_CELLS; i += GROUP) off16[i] = (uint16_t)min(coff[i], a.cap);
-    const int m = min(coff[ORBF_GRID_CELLS], a.cap);
+    // ---- stage the train frame in LDS, in grid (or list) order
+    if (!list_mode) for (int i = tid; i <= ORBF_GRID_CELLS; i += GROUP) off16[i] = (uint16_t)min(coff[i], a.cap);
+    const int m = list_mode ? max(min(a.nlist[p], a.cap), 0) : min(coff[ORBF_GRID_CELLS], a.cap);
     for (int j = tid; j < m; j += GROUP) {
         const int f = cfeat[j];
         const orbx_keypoint kp = kps[f];
@@ -255,23 +270,30 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
         int ql0 = 0, ql1 = 0, qv = 0;
         uint4 qd0 = make_uint4(0, 0, 0, 0), qd1 = qd0;
         if (qi < nq) {
-            qx = a.qxyr[(qb + qi) * 3]; qy = a.qxyr[(qb + qi) * 3 + 1]; qr = a.qxyr[(qb + qi) * 3 + 2];
-            ql0 = a.qlev[(qb + qi) * 2]; ql1 = a.qlev[(qb + qi) * 2 + 1];
-            qv = a.qvalid ? (a.qvalid[qb + qi] != 0) : 1;
-            if (a.qangle) qa = a.qangle[qb + qi];
-            const uint4* d = (const uint4*)(a.qdesc + (qb + qi) * 32);
+            const size_t qs = qb + (a.qindex ? (size_t)a.qindex[qb + qi] : (size_t)qi);      // slot of the query-side arrays
+            if (!list_mode) {
+                qx = a.qxyr[(qb + qi) * 3]; qy = a.qxyr[(qb + qi) * 3 + 1]; qr = a.qxyr[(qb + qi) * 3 + 2];
+                ql0 = a.qlev[(qb + qi) * 2]; ql1 = a.qlev[(qb + qi) * 2 + 1];
+            }
+            qv = a.qvalid ? (a.qvalid[qs] != 0) : 1;
+            if (a.qangle) qa = a.qangle[qs];
+            const uint4* d = (const uint4*)(a.qdesc + qs * 32);
             qd0 = d[0];
             qd1 = d[1];
         }
         // ---- (1) speculative scan of the lane's own query: four smallest keys e0 <= e1 <= e2 <= e3
         int wx0 = 0, wx1 = -1, wy0 = 0, wy1 = 0;
-        if (qv && !orbf::window_cells(b, qx, qy, qr, &wx0, &wx1, &wy0, &wy1)) { wx0 = 0; wx1 = -1; }
+        if (list_mode) {
+            // one run of list positions; no geometric test (an infinite box on every level)
+            qr = INFINITY; ql0 = -1; ql1 = -1;
+            if (qi < nq && qv) { wy0 = min(max(a.qrange[(qb + qi) * 2], 0), m); wy1 = min(max(a.qrange[(qb + qi) * 2 + 1], wy0), m); wx1 = 0; }
+        } else if (qv && !orbf::window_cells(b, qx, qy, qr, &wx0, &wx1, &wy0, &wy1)) { wx0 = 0; wx1 = -1; }
         if (!qv || (dbg & 1)) wx1 = -1;
         uint32_t e0 = KEY_NONE, e1 = KEY_NONE, e2 = KEY_NONE, e3 = KEY_NONE;
         bool any = false;
         for (int col = wx0; col <= wx1; ++col) {
-            const int jend = off16[col * ORBF_GRID_ROWS + wy1 + 1];
-            for (int j = off16[col * ORBF_GRID_ROWS + wy0]; j < jend; ++j) {
+            const int jend = list_mode ? wy1 : off16[col * ORBF_GRID_ROWS + wy1 + 1];
+            for (int j = list_mode ? wy0 : off16[col * ORBF_GRID_ROWS + wy0]; j < jend; ++j) {
                 bool inwin;
                 uint32_t t = candidate_key(S, rule, j, qx, qy, qr, ql0, ql1, qd0, qd1, inwin);
                 any |= inwin;
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
                     if (__builtin_amdgcn_readlane((int)dry, F)) {
                         // the whole wave rescans query F under the current state
                         uint32_t k1, k2;
-                        scan_wave(S, rule, lane, __builtin_amdgcn_readlane(wx0, F), __builtin_amdgcn_readlane(wx1, F), __builtin_amdgcn_readlane(wy0, F),
+                        scan_wave(S, rule, list_mode, lane, __builtin_amdgcn_readlane(wx0, F), __builtin_amdgcn_readlane(wx1, F), __builtin_amdgcn_readlane(wy0, F),
                                   __builtin_amdgcn_readlane(wy1, F), lane_f(qx, F), lane_f(qy, F), lane_f(qr, F), __builtin_amdgcn_readlane(ql0, F),
                                   __builtin_amdgcn_readlane(ql1, F), lane_u4(qd0, F), lane_u4(qd1, F), k1, k2);
                         const uint32_t m1 = k1 != KEY_NONE ? tmeta[k1 & 0xFFFFu] : 0u, m2 = k2 != KEY_NONE ? tmeta[k2 & 0xFFFFu] : 0u;
@@ -422,7 +444,39 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
     if (tid == 0) a.nmatches[p] = hist[31];
 }
 
+
+// SearchByBoW's merge walk as data: one thread per node of the query frame's FeatureVector, binary search of the node id in
+// the train frame's (both ascending), then the node's query positions get the train run.
+__global__ __launch_bounds__(256) void k_bow_ranges(const uint32_t* __restrict__ fvq_node, const int32_t* __restrict__ fvq_off, const int32_t* __restrict__ nfv_q,
+                                                   const uint32_t* __restrict__ fvt_node, const int32_t* __restrict__ fvt_off, const int32_t* __restrict__ nfv_t,
+                                                   int cap, int32_t* __restrict__ qrange, int32_t* __restrict__ nq) {
+    const int p = blockIdx.y;
+    const int nn = min(nfv_q[p], cap), nt = min(nfv_t[p], cap);
+    const uint32_t* qn = fvq_node + (size_t)p * cap;
+    const int32_t* qo = fvq_off + (size_t)p * (cap + 1);
+    const uint32_t* tn = fvt_node + (size_t)p * cap;
+    const int32_t* to = fvt_off + (size_t)p * (cap + 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) nq[p] = nn > 0 ? qo[nn] : 0;
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < nn; s += gridDim.x * 256) {
+        const uint32_t node = qn[s];
+        int lo = 0, hi = nt;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (tn[mid] < node) lo = mid + 1; else hi = mid; }
+        int r0 = 0, r1 = 0;
+        if (lo < nt && tn[lo] == node) { r0 = to[lo]; r1 = to[lo + 1]; }
+        for (int j = qo[s]; j < qo[s + 1]; j++) { qrange[((size_t)p * cap + j) * 2] = r0; qrange[((size_t)p * cap + j) * 2 + 1] = r1; }
+    }
+}
+
 }  // namespace orbs
+
+static int orbs_set_lds(size_t lds) {
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
+        if (hipFuncSetAttribute((const void*)orbs::k_window_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ORBX_ERR_DEVICE;
+        attr_bytes = lds;
+    }
+    return ORBX_OK;
+}
 
 extern "C" {
 
@@ -443,24 +497,53 @@ int orbs_window_search_batch_device(const orbf_bounds* b, const orbs_params* prm
                                     const uint8_t* d_qvalid, const int32_t* d_nq, int qcap, int nproblems, int32_t* d_q2t, int32_t* d_t2q,
                                     int32_t* d_best, int32_t* d_second, int32_t* d_nmatches, void* stream) {
     if (!b || !prm || nproblems < 0 || cap < 1 || cap > ORBF_MAX_FEATURES || qcap < 1 || qcap > ORBF_MAX_FEATURES) return ORBX_ERR_ARG;
-    if (prm->rule < ORBS_RULE_MAPPOINTS || prm->rule > ORBS_RULE_INIT) return ORBX_ERR_ARG;
+    if (prm->rule < ORBS_RULE_MAPPOINTS || prm->rule > ORBS_RULE_BOW) return ORBX_ERR_ARG;
     if (nproblems == 0) return ORBX_OK;
     if (!d_kps_un || !d_desc || !d_cell_off || !d_cell_feat || !d_nt || !d_qxyr || !d_qlev || !d_qdesc || !d_nq || !d_q2t || !d_t2q || !d_nmatches)
         return ORBX_ERR_ARG;
     if (prm->check_orientation && prm->rule != ORBS_RULE_MAPPOINTS && !d_qangle) return ORBX_ERR_ARG;
     const size_t lds = orbs::make_layout(cap, qcap).total;
     if (lds > 160 * 1024) return ORBX_ERR_CAPACITY;
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-        if (hipFuncSetAttribute((const void*)orbs::k_window_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ORBX_ERR_DEVICE;
-        attr_bytes = lds;
-    }
+    if (orbs_set_lds(lds) != ORBX_OK) return ORBX_ERR_DEVICE;
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
     if (const char* e = getenv("ORBS_DBG")) prm2.check_orientation |= atoi(e) << 8;
     orbs::Args a{d_kps_un, d_desc, d_cell_off, d_cell_feat, d_nt, d_claimed, d_qxyr, d_qlev, d_qdesc, d_qangle, d_qvalid, d_nq,
-                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap};
+                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, *b, prm2, a);
+    return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+
+int orbs_list_search_batch_device(const orbs_params* prm, const orbx_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_list, const int32_t* d_nlist,
+                                  const int32_t* d_nt, int cap, const uint8_t* d_claimed, const int32_t* d_qrange, const int32_t* d_qindex,
+                                  const uint8_t* d_qdesc, const float* d_qangle, const uint8_t* d_qvalid, const int32_t* d_nq, int qcap, int nproblems,
+                                  int32_t* d_q2t, int32_t* d_t2q, int32_t* d_best, int32_t* d_second, int32_t* d_nmatches, void* stream) {
+    if (!prm || nproblems < 0 || cap < 1 || cap > ORBF_MAX_FEATURES || qcap < 1 || qcap > ORBF_MAX_FEATURES) return ORBX_ERR_ARG;
+    if (prm->rule < ORBS_RULE_MAPPOINTS || prm->rule > ORBS_RULE_BOW) return ORBX_ERR_ARG;
+    if (nproblems == 0) return ORBX_OK;
+    if (!d_kps || !d_desc || !d_list || !d_nlist || !d_nt || !d_qrange || !d_qdesc || !d_nq || !d_q2t || !d_t2q || !d_nmatches) return ORBX_ERR_ARG;
+    if (prm->check_orientation && prm->rule != ORBS_RULE_MAPPOINTS && !d_qangle) return ORBX_ERR_ARG;
+    const size_t lds = orbs::make_layout(cap, qcap).total;
+    if (lds > 160 * 1024) return ORBX_ERR_CAPACITY;
+    if (orbs_set_lds(lds) != ORBX_OK) return ORBX_ERR_DEVICE;
+    orbs_params prm2 = *prm;
+    prm2.check_orientation = prm->check_orientation ? 1 : 0;
+    if (const char* e = getenv("ORBS_DBG")) prm2.check_orientation |= atoi(e) << 8;
+    orbs::Args a{d_kps, d_desc, nullptr, d_list, d_nt, d_claimed, nullptr, nullptr, d_qdesc, d_qangle, d_qvalid, d_nq,
+                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, d_nlist, d_qrange, d_qindex};
+    orbf_bounds nob{};
+    hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, nob, prm2, a);
+    return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbs_bow_ranges_batch_device(const uint32_t* d_fvq_node, const int32_t* d_fvq_off, const int32_t* d_nfv_q, const uint32_t* d_fvt_node,
+                                 const int32_t* d_fvt_off, const int32_t* d_nfv_t, int cap, int nproblems, int32_t* d_qrange, int32_t* d_nq, void* stream) {
+    if (nproblems < 0 || cap < 1 || cap > ORBF_MAX_FEATURES) return ORBX_ERR_ARG;
+    if (nproblems == 0) return ORBX_OK;
+    if (!d_fvq_node || !d_fvq_off || !d_nfv_q || !d_fvt_node || !d_fvt_off || !d_nfv_t || !d_qrange || !d_nq) return ORBX_ERR_ARG;
+    hipLaunchKernelGGL(orbs::k_bow_ranges, dim3(4, nproblems), dim3(256), 0, (hipStream_t)stream, d_fvq_node, d_fvq_off, d_nfv_q, d_fvt_node, d_fvt_off,
+                       d_nfv_t, cap, d_qrange, d_nq);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
 

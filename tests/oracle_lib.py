@@ -56,6 +56,8 @@ def lib():
         L.orc_frame_undistort.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
         L.orc_frame_grid.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         L.orc_frame_features_in_area.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int, c_int, c_void_p]
+        L.orc_search_by_bow.argtypes = [c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
         L.orc_distinctive.argtypes = [c_void_p, c_int, c_void_p]
         L.orc_three_maxima.argtypes = [c_void_p, c_int, c_void_p]
         L.orc_window_search.argtypes = [c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
@@ -407,3 +409,19 @@ def distinctive(desc):
     med = ctypes.c_int32()
     idx = lib().orc_distinctive(desc.ctypes.data if len(desc) else None, len(desc), ctypes.byref(med))
     return idx, med.value
+
+
+def search_by_bow(th, ratio, check_orientation, kf_fv, kf_desc, kf_angle, kf_valid, f_fv, f_desc, f_angle):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) on flattened arrays; *_fv = (nodes, off, feat) FeatureVector CSR.
+    -> (nmatches, q2t[nKF], t2q[nF], best[nKF], second[nKF])"""
+    kn, ko, kf = (np.ascontiguousarray(kf_fv[0], dtype=np.uint32), np.ascontiguousarray(kf_fv[1], dtype=np.int32), np.ascontiguousarray(kf_fv[2], dtype=np.uint32))
+    fn, fo, ff = (np.ascontiguousarray(f_fv[0], dtype=np.uint32), np.ascontiguousarray(f_fv[1], dtype=np.int32), np.ascontiguousarray(f_fv[2], dtype=np.uint32))
+    kd = np.ascontiguousarray(kf_desc, dtype=np.uint8).reshape(-1, 32); fd = np.ascontiguousarray(f_desc, dtype=np.uint8).reshape(-1, 32)
+    ka = np.ascontiguousarray(kf_angle, dtype=np.float32); fa = np.ascontiguousarray(f_angle, dtype=np.float32)
+    kv = np.ascontiguousarray(kf_valid, dtype=np.uint8)
+    nK, nF = len(kd), len(fd)
+    q2t = np.zeros(max(nK, 1), np.int32); t2q = np.zeros(max(nF, 1), np.int32); best = np.zeros(max(nK, 1), np.int32); second = np.zeros(max(nK, 1), np.int32)
+    n = lib().orc_search_by_bow(th, ratio, 1 if check_orientation else 0, kn.ctypes.data, ko.ctypes.data, kf.ctypes.data, len(kn), kd.ctypes.data,
+                                ka.ctypes.data, kv.ctypes.data, nK, fn.ctypes.data, fo.ctypes.data, ff.ctypes.data, len(fn), fd.ctypes.data, fa.ctypes.data, nF,
+                                q2t.ctypes.data, t2q.ctypes.data, best.ctypes.data, second.ctypes.data)
+    return n, q2t[:nK], t2q[:nF], best[:nK], second[:nK]

@@ -166,3 +166,91 @@ def test_large_frames_and_capacity():
                                         z.data_ptr(), 8192, 0, z.data_ptr(), z.data_ptr(), z.data_ptr(), 0, 0, z.data_ptr(), 8192, 1, z.data_ptr(),
                                         z.data_ptr(), 0, 0, z.data_ptr())
     assert e.value.code == capi.ORBX_ERR_CAPACITY
+
+
+@pytest.mark.parametrize("check", [True, False], ids=["rot", "norot"])
+def test_search_by_bow_pipeline(check):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) end to end on the device: both FeatureVectors from the BoW transform,
+    the merge walk as per-query list ranges, then the in-order list search with the TH_LOW / strict-ratio rule."""
+    torch = pytest.importorskip("torch")
+    P, cap = 5, 1000
+    voc = synth.vocabulary(10, 4, seed=6)
+    V = capi.ORBVocabulary.from_nodes(10, 4, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    OV = ol.OracleVocabulary(voc=voc)
+    rng = np.random.default_rng(9)
+    nK = np.array([1000, 1000, 600, 1, 0], np.int32)
+    nF = np.array([1000, 800, 1000, 1000, 10], np.int32)
+    KD = np.stack([synth.descriptors(cap, 700 + i) for i in range(P)])
+    FD = np.stack([synth.descriptors(cap, 800 + i) for i in range(P)])
+    KA = (rng.random((P, cap)) * 360).astype(np.float32)
+    FA = (rng.random((P, cap)) * 360).astype(np.float32)
+    for i in range(P):                           # frame features = noisy copies of key-frame features (several per feature → contention)
+        src = rng.integers(0, max(nK[i], 1), cap)
+        keep = rng.random(cap) < 0.8
+        noisy = KD[i, src].copy()
+        bits = rng.integers(0, 256, (cap, 3))
+        for j in range(3):
+            noisy[np.arange(cap), bits[:, j] // 8] ^= (1 << (bits[:, j] % 8)).astype(np.uint8)
+        if nK[i]:
+            FD[i, keep] = noisy[keep]
+            FA[i, keep] = ((KA[i, src] + rng.normal(10, 6, cap).astype(np.float32)) % np.float32(360))[keep]
+    KV = (rng.random((P, cap)) < 0.85).astype(np.uint8)
+    st = torch.cuda.current_stream().cuda_stream
+    i32, u8, f64 = torch.int32, torch.uint8, torch.float64
+
+    def transform(D, n):
+        dD, dn = torch.from_numpy(D).cuda(), torch.from_numpy(n).cuda()
+        o = dict(bid=torch.zeros((P, cap), dtype=i32, device="cuda"), bval=torch.zeros((P, cap), dtype=f64, device="cuda"),
+                 node=torch.zeros((P, cap), dtype=i32, device="cuda"), off=torch.zeros((P, cap + 1), dtype=i32, device="cuda"),
+                 feat=torch.zeros((P, cap), dtype=i32, device="cuda"), cnt=torch.zeros((2, P), dtype=i32, device="cuda"), D=dD, n=dn)
+        V.transform_batch_device(dD.data_ptr(), dn.data_ptr(), P, cap, 2, o["bid"].data_ptr(), o["bval"].data_ptr(), o["cnt"][0].data_ptr(),
+                                 o["node"].data_ptr(), o["off"].data_ptr(), o["feat"].data_ptr(), o["cnt"][1].data_ptr(), st)
+        return o
+
+    K, F = transform(KD, nK), transform(FD, nF)
+    qrange = torch.zeros((P, cap, 2), dtype=i32, device="cuda")
+    nq = torch.zeros(P, dtype=i32, device="cuda")
+    capi.bow_ranges_batch_device(K["node"].data_ptr(), K["off"].data_ptr(), K["cnt"][1].data_ptr(), F["node"].data_ptr(), F["off"].data_ptr(),
+                                 F["cnt"][1].data_ptr(), cap, P, qrange.data_ptr(), nq.data_ptr(), st)
+    # the frame's list length = number of its features with a (non-stopped) word
+    torch.cuda.synchronize()
+    f_off = F["off"].cpu().numpy(); f_cnt = F["cnt"].cpu().numpy()
+    nlist = torch.from_numpy(np.array([f_off[i, f_cnt[1, i]] for i in range(P)], np.int32)).cuda()
+    fkps = np.zeros((P, cap), dtype=capi.KP_DTYPE)
+    fkps["angle"] = FA
+    dFK = torch.from_numpy(fkps.view(np.uint8).reshape(P, cap, 28)).cuda()
+    dKA, dKV = torch.from_numpy(KA).cuda(), torch.from_numpy(KV).cuda()
+    q2t = torch.full((P, cap), -9, dtype=i32, device="cuda"); t2q = torch.full((P, cap), -9, dtype=i32, device="cuda")
+    best = torch.full((P, cap), -9, dtype=i32, device="cuda"); second = torch.full((P, cap), -9, dtype=i32, device="cuda")
+    nm = torch.zeros(P, dtype=i32, device="cuda")
+    capi.list_search_batch_device(capi.RULE_BOW, capi.TH_LOW, 0.75, check, dFK.data_ptr(), F["D"].data_ptr(), F["feat"].data_ptr(), nlist.data_ptr(),
+                                  F["n"].data_ptr(), cap, 0, qrange.data_ptr(), K["feat"].data_ptr(), K["D"].data_ptr(), dKA.data_ptr(), dKV.data_ptr(),
+                                  nq.data_ptr(), cap, P, q2t.data_ptr(), t2q.data_ptr(), best.data_ptr(), second.data_ptr(), nm.data_ptr(), st)
+    torch.cuda.synchronize()
+    k_node, k_off, k_feat, k_cnt = (K[x].cpu().numpy() for x in ("node", "off", "feat", "cnt"))
+    f_node, f_feat = F["node"].cpu().numpy(), F["feat"].cpu().numpy()
+    q2t, t2q, best, second, nm, nqh = (x.cpu().numpy() for x in (q2t, t2q, best, second, nm, nq))
+    total = 0
+    for i in range(P):
+        kfv = (k_node[i, :k_cnt[1, i]].view(np.uint32), k_off[i, :k_cnt[1, i] + 1], k_feat[i, :k_off[i, k_cnt[1, i]]].view(np.uint32))
+        ffv = (f_node[i, :f_cnt[1, i]].view(np.uint32), f_off[i, :f_cnt[1, i] + 1], f_feat[i, :f_off[i, f_cnt[1, i]]].view(np.uint32))
+        # the device FeatureVectors are the oracle's (already covered by test_gpu_bow; re-checked here on the way)
+        want_fv = OV.transform(KD[i, :nK[i]], 2)
+        assert np.array_equal(kfv[0], want_fv[2]) and np.array_equal(kfv[1], want_fv[3]) and np.array_equal(kfv[2], want_fv[4])
+        w = ol.search_by_bow(capi.TH_LOW, 0.75, check, kfv, KD[i, :nK[i]], KA[i, :nK[i]], KV[i, :nK[i]], ffv, FD[i, :nF[i]], FA[i, :nF[i]])
+        assert nm[i] == w[0], (i, nm[i], w[0])
+        nqi = nqh[i]
+        assert nqi == len(kfv[2])
+        # device results are per query POSITION (key-frame FeatureVector order); map to key-frame feature indices
+        pos_feat = kfv[2].astype(np.int64)
+        got_q2t = np.full(nK[i], -1, np.int32); got_best = np.full(nK[i], -1, np.int32); got_second = np.full(nK[i], -1, np.int32)
+        got_q2t[pos_feat] = q2t[i, :nqi]; got_best[pos_feat] = best[i, :nqi]; got_second[pos_feat] = second[i, :nqi]
+        np.testing.assert_array_equal(got_q2t, w[1])
+        got_t2q = t2q[i, :nF[i]].copy()
+        m = got_t2q >= 0
+        got_t2q[m] = pos_feat[got_t2q[m]]
+        np.testing.assert_array_equal(got_t2q, w[2])
+        np.testing.assert_array_equal(got_best, w[3])
+        np.testing.assert_array_equal(got_second, w[4])
+        total += w[0]
+    assert total > 250
