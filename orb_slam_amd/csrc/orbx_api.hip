@@ -376,7 +376,10 @@ int orbx_debug_geometry(const orbx_params* p, int w, int hgt, int32_t* out, int 
     HostGeom hg;
     std::string err;
     const int rc = build_geometry(*p, w, hgt, hg, err);
-    if (rc != ORBX_OK) return rc;
+    if (rc != ORBX_OK) {
+        if (getenv("ORBX_DBG_GEOM")) fprintf(stderr, "orbx geometry: %s\n", err.c_str());
+        return rc;
+    }
     if (cap_levels < hg.g.nlevels) return ORBX_ERR_CAPACITY;
     for (int l = 0; l < hg.g.nlevels; l++) {
         const LevelGeom& L = hg.g.lv[l];

@@ -134,7 +134,7 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
         L.cellH = (int)std::ceil((float)H / levelRows);
         L.ncells = levelRows * levelCols;
         L.nfeat_cell = (int)std::ceil((float)L.ndesired / L.ncells);
-        if (L.ncells > 1024) { err = "more than 1024 grid cells on a level"; return ORBX_ERR_GEOMETRY; }   // k_quota LDS arrays
+        if (L.ncells > 1024) { err = "more than 1024 grid cells on a level"; return ORBX_ERR_CAPACITY; }   // k_quota LDS arrays
         // every cell but the last of a row/column keeps its full cellW+6 view: it must fit the level
         if ((levelCols - 1) * L.cellW > W || (levelRows - 1) * L.cellH > H) {
             err = "level " + std::to_string(l) + ": degenerate cell grid (cell views leave the image in the reference)";
@@ -236,16 +236,16 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
             const int cw = c.x1 - c.x0 + 1, ch = c.ey1 - c.ey0 + 1;
             if (cw <= 0 || ch <= 0) continue;
             max_px = std::max(max_px, cw * ch);
-            if (cw > 1000) { err = "grid cell wider than 1000 pixels"; return ORBX_ERR_GEOMETRY; }   // k_fast_cells: a round must span > 1 row
-            if (((cw / 4 + 2) * ch + 511) / 512 > 32) { err = "grid cell band needs more than 32 k_fast_cells rounds"; return ORBX_ERR_GEOMETRY; }
+            if (cw > 1000) { err = "grid cell wider than 1000 pixels"; return ORBX_ERR_CAPACITY; }   // k_fast_cells: a round must span > 1 row
+            if (((cw / 4 + 2) * ch + 511) / 512 > 32) { err = "grid cell band needs more than 32 k_fast_cells rounds"; return ORBX_ERR_CAPACITY; }
             const int nd = (3 + cw + 6 + 3) / 4;
             max_img = std::max(max_img, nd * 4 * (ch + 6));
         }
-        if (max_px > 65535) { err = "grid cell larger than 65535 pixels"; return ORBX_ERR_GEOMETRY; }
+        if (max_px > 65535) { err = "grid cell larger than 65535 pixels"; return ORBX_ERR_CAPACITY; }
         g.fast_max_px = align_up(std::max(max_px, 16), 16);
         g.fast_max_chunks = align_up((max_px + 63) / 64 + 1, 4);
         g.fast_lds_bytes = 272 /*sizeof(FastLds)*/ + g.fast_max_chunks * 12 + 3 * 3072 * 2 /*three u16 queues of FAST_QCAP*/ + g.fast_max_px + align_up(max_img, 16) + 16;
-        if (g.fast_lds_bytes > 160 * 1024) { err = "grid cell does not fit the 160 KiB LDS"; return ORBX_ERR_GEOMETRY; }
+        if (g.fast_lds_bytes > 160 * 1024) { err = "grid cell does not fit the 160 KiB LDS"; return ORBX_ERR_CAPACITY; }
     }
     {
         int max_cell = 1, max_level = 1;
@@ -256,7 +256,7 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
         g.sel_lds_entries = std::min(std::max(max_cell, max_level), 2048);
         g.sel_lds_cell = align_up(g.sel_lds_entries * ((int)sizeof(Cand) + 4), 16);
         g.sel_lds_level = g.sel_lds_cell;
-        if (g.sel_lds_cell > 160 * 1024 || g.sel_lds_level > 160 * 1024) { err = "keypoint list does not fit the 160 KiB LDS"; return ORBX_ERR_GEOMETRY; }
+        if (g.sel_lds_cell > 160 * 1024 || g.sel_lds_level > 160 * 1024) { err = "keypoint list does not fit the 160 KiB LDS"; return ORBX_ERR_CAPACITY; }
     }
     for (int l = 0; l < MAX_LEVELS; l++) {
         const bool live = l < nl;

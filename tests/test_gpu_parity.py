@@ -258,3 +258,14 @@ def test_capacity_and_argument_errors(gpu_extractor_factory):
     with pytest.raises(capi.OrbxError) as e:     # row stride smaller than the width
         ex.extract_batch_device(img.data_ptr(), 1, 640, 480, 600, 640 * 480, out.data_ptr(), out.data_ptr(), out.data_ptr(), 1000)
     assert e.value.code == capi.ORBX_ERR_ARG
+
+
+def test_randomised_configurations():
+    """a slice of tools/fuzz_parity.py: random sizes / constructor arguments / families, byte-exact or a documented rejection"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "60", "7"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["mismatches"] == [] and out["bit_exact"] >= 30
+    assert out["bit_exact"] + out["geometry_the_reference_cannot_process"] + out["implementation_limit"] == 60

@@ -53,3 +53,16 @@ def test_geometry_errors():
     with pytest.raises(capi.OrbxError) as e:
         capi.geometry(640, 480, nlevels=40)
     assert e.value.code == capi.ORBX_ERR_ARG
+
+
+def test_rejections_are_classified():
+    """ORBX_ERR_GEOMETRY only for inputs the reference itself cannot process; implementation limits are ORBX_ERR_CAPACITY"""
+    for args in [dict(w=640, h=480, nfeatures=50, nlevels=8),          # level quota 3..11 -> levelCols = 0: the reference divides by zero
+                 dict(w=100, h=80, nfeatures=500, nlevels=8),          # level 7 is 28x22: cell views with negative extent
+                 dict(w=320, h=240, nfeatures=1000, scaleFactor=2.0, nlevels=5)]:
+        with pytest.raises(capi.OrbxError) as e:
+            capi.geometry(**args)
+        assert e.value.code == capi.ORBX_ERR_GEOMETRY, args
+    with pytest.raises(capi.OrbxError) as e:
+        capi.geometry(w=1380, h=900, nfeatures=50, nlevels=1)           # one cell 1348 px wide: fine for the reference, not for k_fast_cells
+    assert e.value.code == capi.ORBX_ERR_CAPACITY
