@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "orbf_math.h"
 #include "orbs.h"
@@ -469,13 +470,14 @@ __global__ __launch_bounds__(256) void k_bow_ranges(const uint32_t* __restrict__
 
 }  // namespace orbs
 
-static int orbs_set_lds(size_t lds) {
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-        if (hipFuncSetAttribute((const void*)orbs::k_window_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ORBX_ERR_DEVICE;
-        attr_bytes = lds;
-    }
-    return ORBX_OK;
+// the kernel may use up to the whole 160 KiB of LDS: raise the dynamic-LDS limit once per process (per device context)
+static int orbs_set_lds(size_t) {
+    static std::once_flag once;
+    static int rc = ORBX_OK;
+    std::call_once(once, [] {
+        if (hipFuncSetAttribute((const void*)orbs::k_window_search, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) rc = ORBX_ERR_DEVICE;
+    });
+    return rc;
 }
 
 extern "C" {

@@ -103,4 +103,31 @@ out = {"metric": "frontend_frames_per_s", "value": round(B / (total_ms * 1e-3), 
        "stage_ms_per_step": {k: round(v / a.steps, 4) for k, v in acc.items()},
        "mean_keypoints": round(float(S[0]["n"].float().mean().item()), 1), "mean_window_matches": round(float(nm.float().mean().item()), 1),
        "mean_bow_words": round(float(cnt[0].float().mean().item()), 1)}
+# the same chain on one host core through the CPU oracle (test infrastructure), a bounded sample of frames
+if os.environ.get("FRONTEND_CPU", "1") != "0":
+    import time
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import oracle_lib as ol
+    oe = ol.OracleExtractor(a.nfeatures)
+    ov = ol.OracleVocabulary(voc=voc)
+    ns = 4
+    t = {k: 0.0 for k in ("extract", "undistort_grid", "bow", "window_search", "dense_match")}
+    prev = None
+    for f in range(ns + 1):
+        t0 = time.perf_counter(); k, d = oe(frames[f]); t1 = time.perf_counter()
+        un = ol.frame_undistort(cam, k); off, feat = ol.frame_grid(bounds, un); t2 = time.perf_counter()
+        ov.transform(d, 4); t3 = time.perf_counter()
+        if prev is not None:
+            pk, pd, pun = prev
+            qx = np.stack([pun["x"], pun["y"], np.full(len(pun), a.window, np.float32)], -1)
+            ql = np.stack([pun["octave"], pun["octave"]], -1).astype(np.int32)
+            t4 = time.perf_counter()
+            ol.window_search(bounds, capi.RULE_WINDOW, capi.TH_HIGH, 0.8, True, un, d, off, feat, None, qx, ql, pd, pun["angle"], None)
+            t5 = time.perf_counter()
+            ol.match_top2(d, pd)
+            t6 = time.perf_counter()
+            t["extract"] += t1 - t0; t["undistort_grid"] += t2 - t1; t["bow"] += t3 - t2; t["window_search"] += t5 - t4; t["dense_match"] += t6 - t5
+        prev = (k, d, un)
+    out["cpu_oracle"] = {"frames_per_s": round(ns / sum(t.values()), 2), "cores": 1, "sample": "%d frames" % ns,
+                         "stage_ms_per_frame": {k: round(v / ns * 1e3, 3) for k, v in t.items()}}
 print(json.dumps(out))
