@@ -181,6 +181,23 @@ def test_fast_definition(family, th):
     assert all(k["size"] == 7 and k["angle"] == -1 and k["octave"] == 0 and k["class_id"] == -1 for k in kps)
 
 
+def test_fast_corner_set_equals_scikit_image():
+    """third-party voice (neither this repository nor OpenCV): scikit-image 0.18.3's corner_fast(n=9) marks exactly the pixels
+    the oracle's cv::FAST restatement scores before non-maximum suppression (fixture: tests/golden/make_fast_skimage.py)"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fast_skimage.npz"))
+    total = 0
+    for name in ("blocks", "noise", "lowtex"):
+        h, w, fam, idx = (int(v) for v in z[name + "_shape"])
+        img = synth.frame(w, h, fam, idx)
+        for t in (20, 7):
+            want = np.unpackbits(z["%s_t%d" % (name, t)])[: h * w].reshape(h, w).astype(bool)
+            _, sc = orc.fast(img, t, want_scores=True)
+            assert np.array_equal(sc > 0, want), (name, t)
+            total += int(want.sum())
+    assert total > 10000
+
+
 def test_fast_score_is_threshold_independent():
     """corner@t <=> score >= t, and survivors@20 = survivors@7 restricted to score >= 20 (one pass serves both)."""
     img = synth.frame(160, 120, synth.NOISE, 4)
