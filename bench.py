@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--family", type=int, default=1, help="0 noise, 1 blocks (default), 3 lowtex")
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE configs[1] verbatim)")
+    ap.add_argument("--match-stream", choices=["side", "same"], default="side",
+                    help="side: the match of step i runs on a second stream while step i+1 is extracted (default); same: one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo")
@@ -110,29 +112,46 @@ def main():
     ex = capi.ORBextractor(nfeatures=a.nfeatures, device=local_rank, max_batch=B)
     cap = ex.max_keypoints
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
-    d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)   # slot 0 = last frame of the previous step
-    d_n = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    # two generations of outputs: the match of step i (side stream) runs while step i+1 is being extracted (main stream)
+    d_desc = torch.zeros((2, B + 1, cap, 32), dtype=torch.uint8, device=dev)   # slot 0 = last frame of the previous step
+    d_n = torch.zeros((2, B + 1), dtype=torch.int32, device=dev)
     d_status = torch.zeros(B, dtype=torch.int32, device=dev)
     d_match = torch.zeros((3, B, cap), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    main = torch.cuda.current_stream(dev)
+    stream = main.cuda_stream
+    side = torch.cuda.Stream(dev) if a.match_stream == "side" else main
     do_match = not a.no_match
     match_events = []
+    ev_extract = [None, None]      # extraction of the generation finished
+    ev_match = [None, None]        # its match finished (the generation may be overwritten)
 
     def step(i, timed):
+        # generation g holds this step's outputs in slots 1..B and the previous step's last frame in slot 0.
+        # main stream: extract(i) -> [wait match(i-1)] -> hand slot B over to the other generation's slot 0.
+        # side stream: match(i) as soon as extract(i) is done, i.e. concurrently with extract(i+1).
         f0 = (i * B) % ring
+        g = i & 1
         ex.extract_batch_device(d_img.data_ptr() + f0 * w * h, B, w, h, w, w * h, d_kps.data_ptr(),
-                                d_desc.data_ptr() + cap * 32, d_n.data_ptr() + 4, cap, d_status.data_ptr(), stream)
+                                d_desc[g, 1].data_ptr(), d_n[g, 1:].data_ptr(), cap, d_status.data_ptr(), stream)
         if do_match:
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            capi.match_top2_batch_device(d_desc.data_ptr() + cap * 32, d_n.data_ptr() + 4, d_desc.data_ptr(), d_n.data_ptr(),
-                                         B, cap, d_match[0].data_ptr(), d_match[1].data_ptr(), d_match[2].data_ptr(), stream)
-            if timed:
-                e1.record()
-                match_events.append((e0, e1))
-            d_desc[0].copy_(d_desc[B], non_blocking=True)
-            d_n[0:1].copy_(d_n[B:B + 1], non_blocking=True)
+            ev_extract[g] = torch.cuda.Event()
+            ev_extract[g].record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_extract[g])
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(side)
+                capi.match_top2_batch_device(d_desc[g, 1].data_ptr(), d_n[g, 1:].data_ptr(), d_desc[g, 0].data_ptr(), d_n[g].data_ptr(),
+                                             B, cap, d_match[0].data_ptr(), d_match[1].data_ptr(), d_match[2].data_ptr(), side.cuda_stream)
+                if timed:
+                    e1.record(side)
+                    match_events.append((e0, e1))
+                ev_match[g] = torch.cuda.Event()
+                ev_match[g].record(side)
+            if ev_match[g ^ 1] is not None:
+                main.wait_event(ev_match[g ^ 1])          # the other generation is free again (its match has finished)
+            d_desc[g ^ 1, 0].copy_(d_desc[g, B], non_blocking=True)
+            d_n[g ^ 1, 0:1].copy_(d_n[g, B:B + 1], non_blocking=True)
 
     for i in range(a.warmup):
         step(i, False)
@@ -153,13 +172,14 @@ def main():
     stage = ex.stage_times()
     ex.stage_timing(0)
     match_ms = sum(e0.elapsed_time(e1) for e0, e1 in match_events) / max(len(match_events), 1)
-    kp_mean = float(d_n[1:].float().mean().item())
+    last = (a.warmup + a.steps - 1) & 1
+    kp_mean = float(d_n[last, 1:].float().mean().item())
     bad_status = int((d_status != 0).sum().item())
     accepted = -1
     if do_match:
         best = d_match[1, B - 1, :cap].cpu().numpy()
         sec = d_match[2, B - 1, :cap].cpu().numpy()
-        nq = int(d_n[B].item())
+        nq = int(d_n[last, B].item())
         accepted = capi.count_accepted(best[:nq], sec[:nq], 50, 0.6)
 
     # RCCL: the only collectives of the run (MAX of the timing, all-gather of the counters)
