@@ -227,6 +227,23 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
                 e.b1 = sat16(fy * 2048);
                 out.taby.push_back(e);
             }
+            // LDS tile of k_resize: the source rectangle of every 256 x 16 output tile (tables are monotone)
+            {
+                const ResizeX* tx = out.tabx.data() + L.tabx_off;
+                const ResizeY* ty = out.taby.data() + L.taby_off;
+                int nd_max = 1, nr_max = 1;
+                for (int bx0 = 0; bx0 < dw; bx0 += 256) {
+                    const int bx1 = std::min(bx0 + 255, dw - 1);
+                    nd_max = std::max(nd_max, ((tx[bx1].sx1 - (tx[bx0].sx & ~3)) >> 2) + 1);
+                }
+                for (int by0 = 0; by0 < dh; by0 += 16) {
+                    const int by1 = std::min(by0 + 15, dh - 1);
+                    nr_max = std::max(nr_max, ty[by1].sy1 - ty[by0].sy0 + 1);
+                }
+                L.rz_pitch = 4 * nd_max;
+                L.rz_rows = nr_max;
+                if (L.rz_pitch * L.rz_rows > 64 * 1024) { err = "resize tile does not fit the LDS"; return ORBX_ERR_CAPACITY; }
+            }
         }
     }
     // LDS carve of k_fast_cells, sized by the largest cell

@@ -38,6 +38,7 @@ struct LevelGeom {
     int sel_base, sel_cap; // selected-keypoint list of this level in one frame's sel block
     int slot_base;         // prefix of ndesired over levels (descriptor-kernel slot -> level map)
     int tabx_off, taby_off;// offsets into the ResizeX / ResizeY tables (level >= 1)
+    int rz_pitch, rz_rows; // k_resize: LDS source tile of one 256x16 output tile (bytes per row, rows), maxima over the level's tiles
     int btile_base, btiles_x, btiles_y;// blur wave tasks: 248-px strips x 32-row bands of the whole plane
     int blur_wvec;         // columns x < blur_wvec round ties-to-even (SSE2 emulation), others half-up
     int blur_sel_last, blur_sel_halo;   // v_perm selectors building the reflect-101 bytes of the last / right-halo dword of a row

@@ -68,14 +68,15 @@ __device__ __forceinline__ void split_px(int p, int cw, float inv_cw, int& y, in
 // reads its 16 taps as LDS bytes, produces 4 horizontally adjacent output pixels and stores one dword.
 // (Byte gathers straight from global memory made this kernel texture-addresser bound.)
 constexpr int RZ_ROWS = 16;        // output rows per workgroup (4 per wave): a tall tile amortises the table -> source -> LDS latency chain
-constexpr int RZ_SRC_ROWS = 44;    // >= RZ_ROWS * max scale + 2 (scale_factor <= 2.5 is checked on the host)
-constexpr int RZ_SRC_W = 704;      // >= 256 * max scale + 8, multiple of 4
+// LDS source tile: L.rz_rows x L.rz_pitch bytes, the exact maximum over the level's tiles (7 KB at scale 1.2; a fixed
+// worst-case array for scale 2.5 was 31 KB and capped the kernel at 5 workgroups per CU)
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[RZ_SRC_ROWS * RZ_SRC_W];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
     const DevGeom& g = b.g;
     const LevelGeom& L = g.lv[level];
+    const int RZ_SRC_W = L.rz_pitch;
     const LevelGeom& P = g.lv[level - 1];
     const int frame = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
@@ -1002,8 +1003,9 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
             const LevelGeom& L = g.lv[l];
             dim3 grid((L.w + 255) / 256, (L.h + RZ_ROWS - 1) / RZ_ROWS, F);
             const bool al = l > 1 || (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
-            if (al) hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), 0, stream, b, l);
-            else hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), 0, stream, b, l);
+            const size_t lds = (size_t)L.rz_pitch * L.rz_rows;
+            if (al) hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), lds, stream, b, l);
+            else hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), lds, stream, b, l);
             ORBX_LAUNCH_CHECK();
         }
     }
