@@ -209,7 +209,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "frames/s ORB extract+match @640x480, 1000 kp" if do_match else "frames/s ORB extract @640x480, 1000 kp",
+            "metric": "frames/s ORB %s @%dx%d, %d kp" % ("extract+match" if do_match else "extract", w, h, a.nfeatures),
             "value": round(total_frames / tmax, 1),
             "unit": "frames/s",
             "n_gpus": world,
