@@ -381,6 +381,9 @@ int orbx_debug_geometry(const orbx_params* p, int w, int hgt, int32_t* out, int 
         return rc;
     }
     if (cap_levels < hg.g.nlevels) return ORBX_ERR_CAPACITY;
+    if (getenv("ORBX_DBG_GEOM"))
+        fprintf(stderr, "orbx geometry: fast_lds_bytes %d (max_px %d, chunks %d), sel_lds %d, bands %d, cells %d\n", hg.g.fast_lds_bytes, hg.g.fast_max_px,
+                hg.g.fast_max_chunks, hg.g.sel_lds_cell, (int)hg.bands.size(), (int)hg.cells.size());
     for (int l = 0; l < hg.g.nlevels; l++) {
         const LevelGeom& L = hg.g.lv[l];
         int nb = 0;

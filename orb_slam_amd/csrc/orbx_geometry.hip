@@ -24,7 +24,7 @@ static inline int16_t sat16(float v) {   // saturate_cast<short>(float)
 }
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
-int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::string& err) {
+static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out, std::string& err, const int band_px) {
     const int nl = p.nlevels;
     if (nl < 1 || nl > MAX_LEVELS) { err = "nlevels out of range [1,16]"; return ORBX_ERR_ARG; }
     if (p.nfeatures < 1) { err = "nfeatures must be >= 1"; return ORBX_ERR_ARG; }
@@ -157,7 +157,7 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
                 const int cw = std::max(0, c.x1 - c.x0 + 1), ch = std::max(0, c.y1 - c.y0 + 1);
                 c.cand_off = cand_off;
                 c.band0 = (int)out.bands.size();
-                const int nb = std::max(1, (cw * ch + BAND_PX - 1) / BAND_PX);
+                const int nb = std::max(1, (cw * ch + band_px - 1) / band_px);
                 const int rb = std::max(1, (ch + nb - 1) / nb);
                 c.nbands = 0;
                 c.cand_cap = 0;
@@ -289,6 +289,26 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
     g.frame_cands = cand_base;
     g.frame_sel = sel_base;
     return ORBX_OK;
+}
+
+
+// k_fast_cells keeps 4 workgroups (32 waves) on a CU only while one work item needs <= 40 KB of LDS.  The default band of
+// BAND_PX pixels gives exactly that for VGA-class grids; where the cell shape pushes it over (1080p: 42.4 KB -> 3 workgroups),
+// slightly smaller bands restore the fourth workgroup.
+int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::string& err) {
+    constexpr int LDS_FOR_FOUR = (160 * 1024) / 4 - 64;
+    int rc = build_geometry_band(p, w, h, out, err, BAND_PX);
+    if (rc != ORBX_OK || out.g.fast_lds_bytes <= LDS_FOR_FOUR) return rc;
+    for (int band = BAND_PX - 512; band >= 8192; band -= 512) {
+        HostGeom trial;
+        std::string e2;
+        if (build_geometry_band(p, w, h, trial, e2, band) == ORBX_OK && trial.g.fast_lds_bytes <= LDS_FOR_FOUR) {
+            out = trial;
+            err.clear();
+            return ORBX_OK;
+        }
+    }
+    return rc;
 }
 
 }  // namespace orbx
