@@ -138,3 +138,25 @@ def test_distinctive_descriptors():
         assert (gi[p], gm[p]) == (wi, wm), (p, n, gi[p], gm[p], wi, wm)
     gi, gm = capi.distinctive(np.zeros((0, 32), np.uint8), np.array([0], np.int32))
     assert len(gi) == 0
+
+
+def test_top2_property_hypothesis():
+    """for ANY query / train multiset (hypothesis explores tiny alphabets, duplicates, empty sets) the GPU top-2 equals
+    the sequential-scan semantics: two smallest distances with multiplicity, first index on ties"""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    palette = np.concatenate([np.zeros((1, 32), np.uint8), np.full((1, 32), 255, np.uint8), synth.descriptors(6, 3)])
+    palette[3] = palette[2]; palette[3, 0] ^= 1          # distance-1 neighbours
+    palette[5] = palette[4]; palette[5, 31] ^= 0x81
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(st.integers(0, 7), min_size=0, max_size=40), st.lists(st.integers(0, 7), min_size=0, max_size=70))
+    def prop(qi, ti):
+        Q = palette[np.array(qi, dtype=np.int64)] if qi else np.zeros((0, 32), np.uint8)
+        T = palette[np.array(ti, dtype=np.int64)] if ti else np.zeros((0, 32), np.uint8)
+        gi, gb, gs = capi.match_top2(Q, T)
+        ri, rb, rs = orc.match_top2(Q, T)
+        assert np.array_equal(gi, ri) and np.array_equal(gb, rb) and np.array_equal(gs, rs)
+
+    prop()
