@@ -18,6 +18,11 @@
  *   ORBS_RULE_BOW        <- int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                 :155-281
  *                           (candidates = the features of the same vocabulary node instead of a grid window:
  *                           orbs_bow_ranges_batch_device + orbs_list_search_batch_device; accept best <= th && best < ratio*second)
+ *   ORBS_RULE_FREE       <- the searches WITHOUT the "already matched" masking, every query independent: the scan of
+ *                           int ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, float th)                       :1000-1135
+ *                           int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, ..., int th)             :283-400
+ *                           (window + level range, best distance only, accept best <= th; several queries may end on the same
+ *                           feature, so d_t2q is not produced (all -1) and there is no rotation check)
  *   rotation filter      <- the rotHist blocks of those functions + ORBmatcher::ComputeThreeMaxima            :1748-1789
  *   candidate windows    <- Frame::GetFeaturesInArea                                                          src/Frame.cc:200-265
  *
@@ -47,6 +52,7 @@ extern "C" {
 #define ORBS_RULE_BEST      2
 #define ORBS_RULE_INIT      3
 #define ORBS_RULE_BOW       4
+#define ORBS_RULE_FREE      5
 
 #define ORBS_TH_HIGH 100      /* ORBmatcher::TH_HIGH src/ORBmatcher.cc:40 */
 #define ORBS_TH_LOW  50       /* ORBmatcher::TH_LOW  src/ORBmatcher.cc:41 */

@@ -9,6 +9,7 @@
 //           ORBmatcher::SearchByProjection(Frame&, Frame&, int, vector<MapPoint*>&)       :519-594 (no rotation check)
 //   rule 2  ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, float)      :1508-1619
 //   rule 3  ORBmatcher::SearchForInitialization(Frame&, Frame&, vector<Point2f>&, vector<int>&, int)   :596-716
+//   rule 5  the scans of ORBmatcher::Fuse :1000-1135 and SearchByProjection(KeyFrame*, Scw, ...) :283-400 (no claims)
 //   ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                        :155-281   (orc_search_by_bow)
 //   ORBmatcher::ComputeThreeMaxima                                                        :1748-1789
 // What stays with the caller (pointer-graph work): which queries are valid (pMP != NULL, !isBad(), mbTrackInView, level
@@ -169,7 +170,7 @@ int orc_window_search(const void* bounds, int rule, int th, float ratio, int che
         int bestDist = INT_MAX, bestLevel = -1, bestDist2 = INT_MAX, bestLevel2 = -1, bestIdx = -1;
         for (int c = 0; c < nn; c++) {
             const int idx = near[c];
-            if (rule != 3 && claimed[idx]) continue;
+            if (rule != 3 && rule != 5 && claimed[idx]) continue;
             const int dist = orc_hamming256(qdesc + (size_t)q * 32, desc + (size_t)idx * 32);
             if (rule == 3 && vMatchedDistance[idx] <= dist) continue;
             if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kps_un[idx].octave; bestIdx = idx; }
@@ -182,7 +183,7 @@ int orc_window_search(const void* bounds, int rule, int th, float ratio, int che
             if (bestDist <= th) accept = !(bestLevel == bestLevel2 && bestDist > ratio * bestDist2);
         } else if (rule == 1) {             // :476 / :585
             accept = bestDist <= bestDist2 * ratio && bestDist <= th;
-        } else if (rule == 2) {             // :1583
+        } else if (rule == 2 || rule == 5) { // :1583; rule 5: Fuse :1113 / SearchByProjection(KeyFrame*, Scw, ...) :391 — no claims
             accept = bestDist <= th;
         } else {                            // :652-654
             accept = bestDist <= th && bestDist < (float)bestDist2 * ratio;
@@ -192,12 +193,14 @@ int orc_window_search(const void* bounds, int rule, int th, float ratio, int che
             if (t2q[bestIdx] >= 0) { q2t[t2q[bestIdx]] = -1; nmatches--; }
             q2t[q] = bestIdx; t2q[bestIdx] = q; vMatchedDistance[bestIdx] = bestDist; nmatches++;
             if (check_orientation) rotHist[rot_bin(qangle[q], kps_un[bestIdx].angle)].push_back(q);
+        } else if (rule == 5) {
+            q2t[q] = bestIdx; nmatches++;                        // independent queries: nothing is claimed, t2q stays -1
         } else {
             claimed[bestIdx] = 1; q2t[q] = bestIdx; t2q[bestIdx] = q; nmatches++;
-            if (check_orientation && rule != 0) rotHist[rot_bin(qangle[q], kps_un[bestIdx].angle)].push_back(bestIdx);
+            if (check_orientation && rule != 0 && rule != 5) rotHist[rot_bin(qangle[q], kps_un[bestIdx].angle)].push_back(bestIdx);
         }
     }
-    if (check_orientation && rule != 0) {
+    if (check_orientation && rule != 0 && rule != 5) {
         int ind1 = -1, ind2 = -1, ind3 = -1;
         ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
         for (int i = 0; i < HISTO_LENGTH; i++) {

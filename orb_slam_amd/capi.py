@@ -37,7 +37,7 @@ EXPORTS_F = [
 # include/orbs.h (greedy grid-window searches)
 EXPORTS_S = ["orbs_lds_bytes", "orbs_three_maxima", "orbs_window_search_batch_device", "orbs_list_search_batch_device",
              "orbs_bow_ranges_batch_device"]
-RULE_MAPPOINTS, RULE_WINDOW, RULE_BEST, RULE_INIT, RULE_BOW = 0, 1, 2, 3, 4
+RULE_MAPPOINTS, RULE_WINDOW, RULE_BEST, RULE_INIT, RULE_BOW, RULE_FREE = 0, 1, 2, 3, 4, 5
 TH_HIGH, TH_LOW = 100, 50
 # include/orbv.h (bag-of-words transform)
 EXPORTS_V = [

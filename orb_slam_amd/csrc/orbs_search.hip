@@ -192,7 +192,7 @@ __device__ __forceinline__ bool accept_rule(const orbs_params& prm, int bestDist
         return bestDist <= prm.th && !(bestLevel == bestLevel2 && (float)bestDist > prm.ratio * (float)bestDist2);
     if (prm.rule == ORBS_RULE_WINDOW)          // :476, :585
         return (float)bestDist <= (float)bestDist2 * prm.ratio && bestDist <= prm.th;
-    if (prm.rule == ORBS_RULE_BEST)            // :1583
+    if (prm.rule == ORBS_RULE_BEST || prm.rule == ORBS_RULE_FREE)            // :1583, :1113
         return bestDist <= prm.th;
     return bestDist <= prm.th && (float)bestDist < prm.ratio * (float)bestDist2;      // :652-654 (INIT), :224-226 (BOW)
 }
@@ -261,7 +261,8 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
     if (tid < 32) hist[tid] = 0;
     __syncthreads();
 
-    const bool rot_on = (prm.check_orientation & 1) != 0 && rule != ORBS_RULE_MAPPOINTS;
+    const bool rot_on = (prm.check_orientation & 1) != 0 && rule != ORBS_RULE_MAPPOINTS && rule != ORBS_RULE_FREE;
+    const bool claims = rule != ORBS_RULE_FREE;              // FREE: every query independent, nothing is ever claimed
     const int dbg = prm.check_orientation >> 8;            // development switches (ORBS_DBG): 1 = no speculative scan, 2 = no commit
 
     for (int q0 = 0, group = 0; q0 < nq; q0 += GROUP, ++group) {
@@ -346,10 +347,10 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
                     // accepting lanes post their claim; the earliest lane of this round wins the slot
                     const uint32_t stamp = (uint32_t)((group * (GROUP / 64) + w) * 128 + round + 1);
                     const uint32_t bIdx = mb & 0xFFFFu, sIdx = ms & 0xFFFFu;
-                    if (active && vAccept) atomicMax(&claim_by[bIdx], (stamp << 6) | (uint32_t)(63 - lane));
+                    if (claims && active && vAccept) atomicMax(&claim_by[bIdx], (stamp << 6) | (uint32_t)(63 - lane));
                     bool affected = false;
-                    if (active && kb != KEY_NONE) { const uint32_t c = claim_by[bIdx]; affected |= (c >> 6) == stamp && (int)(63u - (c & 63u)) < lane; }
-                    if (active && ks != KEY_NONE) { const uint32_t c = claim_by[sIdx]; affected |= (c >> 6) == stamp && (int)(63u - (c & 63u)) < lane; }
+                    if (claims && active && kb != KEY_NONE) { const uint32_t c = claim_by[bIdx]; affected |= (c >> 6) == stamp && (int)(63u - (c & 63u)) < lane; }
+                    if (claims && active && ks != KEY_NONE) { const uint32_t c = claim_by[sIdx]; affected |= (c >> 6) == stamp && (int)(63u - (c & 63u)) < lane; }
                     const unsigned long long stop = __ballot(active && (affected || dry));
                     const int F = stop ? (__ffsll((long long)stop) - 1) : 64;
                     // every lane before F is final: record, and commit its own claim
@@ -365,12 +366,12 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
                                 if (prev >= 0) q2t[prev] = -1;                 // vnMatches12[vnMatches21[bestIdx2]] = -1
                                 state[bIdx] = (uint16_t)vBest;                 // vMatchedDistance[bestIdx2] = bestDist
                                 binv[q] = (uint8_t)bin;                        // rotHist[bin].push_back(i1)
-                            } else {
+                            } else if (claims) {
                                 state[bIdx] = 1;
                                 binv[bIdx] = (uint8_t)bin;                     // rotHist[bin].push_back(bestIdx2)
                             }
                             q2t[q] = (int16_t)bIdx;
-                            t2q[bIdx] = (int16_t)q;
+                            if (claims) t2q[bIdx] = (int16_t)q;
                         }
                     }
                     cursor = F;
@@ -499,7 +500,7 @@ int orbs_window_search_batch_device(const orbf_bounds* b, const orbs_params* prm
                                     const uint8_t* d_qvalid, const int32_t* d_nq, int qcap, int nproblems, int32_t* d_q2t, int32_t* d_t2q,
                                     int32_t* d_best, int32_t* d_second, int32_t* d_nmatches, void* stream) {
     if (!b || !prm || nproblems < 0 || cap < 1 || cap > ORBF_MAX_FEATURES || qcap < 1 || qcap > ORBF_MAX_FEATURES) return ORBX_ERR_ARG;
-    if (prm->rule < ORBS_RULE_MAPPOINTS || prm->rule > ORBS_RULE_BOW) return ORBX_ERR_ARG;
+    if (prm->rule < ORBS_RULE_MAPPOINTS || prm->rule > ORBS_RULE_FREE) return ORBX_ERR_ARG;
     if (nproblems == 0) return ORBX_OK;
     if (!d_kps_un || !d_desc || !d_cell_off || !d_cell_feat || !d_nt || !d_qxyr || !d_qlev || !d_qdesc || !d_nq || !d_q2t || !d_t2q || !d_nmatches)
         return ORBX_ERR_ARG;
@@ -522,7 +523,7 @@ int orbs_list_search_batch_device(const orbs_params* prm, const orbx_keypoint* d
                                   const uint8_t* d_qdesc, const float* d_qangle, const uint8_t* d_qvalid, const int32_t* d_nq, int qcap, int nproblems,
                                   int32_t* d_q2t, int32_t* d_t2q, int32_t* d_best, int32_t* d_second, int32_t* d_nmatches, void* stream) {
     if (!prm || nproblems < 0 || cap < 1 || cap > ORBF_MAX_FEATURES || qcap < 1 || qcap > ORBF_MAX_FEATURES) return ORBX_ERR_ARG;
-    if (prm->rule < ORBS_RULE_MAPPOINTS || prm->rule > ORBS_RULE_BOW) return ORBX_ERR_ARG;
+    if (prm->rule < ORBS_RULE_MAPPOINTS || prm->rule > ORBS_RULE_FREE) return ORBX_ERR_ARG;
     if (nproblems == 0) return ORBX_OK;
     if (!d_kps || !d_desc || !d_list || !d_nlist || !d_nt || !d_qrange || !d_qdesc || !d_nq || !d_q2t || !d_t2q || !d_nmatches) return ORBX_ERR_ARG;
     if (prm->check_orientation && prm->rule != ORBS_RULE_MAPPOINTS && !d_qangle) return ORBX_ERR_ARG;

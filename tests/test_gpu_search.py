@@ -124,7 +124,10 @@ SCALE = np.float32(1.2) ** np.arange(8, dtype=np.float32)
     (capi.RULE_BEST, capi.TH_HIGH, 0.9, False, "all", 30.0),
     (capi.RULE_INIT, capi.TH_LOW, 0.9, True, "same", 100.0),                    # Tracking.cc:353 SearchForInitialization(..., 100)
     (capi.RULE_INIT, capi.TH_HIGH, 0.9, False, "all", 40.0),
-], ids=["mappoints_r4", "mappoints_r20", "window100_rot", "window200_rot", "window15", "best15_rot", "best30_all", "init100_rot", "init40_all"])
+    (capi.RULE_FREE, capi.TH_LOW, 0.9, False, "below", 3.0 * SCALE),            # LocalMapping.cc Fuse(pKF, mapPoints, th = 3)
+    (capi.RULE_FREE, capi.TH_HIGH, 0.9, True, "below", 10.0 * SCALE),           # LoopClosing.cc:370 SearchByProjection(pKF, Scw, points, matched, 10)
+], ids=["mappoints_r4", "mappoints_r20", "window100_rot", "window200_rot", "window15", "best15_rot", "best30_all", "init100_rot", "init40_all",
+        "free_fuse3", "free_sim10"])
 def test_rules_against_oracle(rule, th, ratio, check, level_mode, radius):
     cap = qcap = 1000
     problems = [_problem(10 + i, nt, nq, radius, crowd=(i % 2 == 1), level_mode=level_mode)
