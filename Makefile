@@ -8,7 +8,7 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -ffp-contract=off -Wal
 ORBX_SRCS  := $(wildcard orb_slam_amd/csrc/*.hip)
 ORBX_HDRS  := $(wildcard orb_slam_amd/csrc/*.h orb_slam_amd/csrc/*.inc include/*.h)
 
-all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so oracle_ref orb_slam_amd/cpp/example_frame
+all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so oracle_ref orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline
 
 orb_slam_amd/liborbx.so: $(ORBX_SRCS) $(ORBX_HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared $(ORBX_SRCS) -o $@
@@ -28,8 +28,12 @@ oracle_ref: oracle/liborb_oracle.so
 orb_slam_amd/cpp/example_frame: orb_slam_amd/cpp/example_frame.cpp orb_slam_amd/cpp/ORBextractor.h orb_slam_amd/cpp/ORBmatcher.h orb_slam_amd/cpp/ORBVocabulary.h orb_slam_amd/cpp/cvcompat.h include/orbx.h include/orbv.h orb_slam_amd/liborbx.so
 	$(CXX) -O2 -std=c++14 -Iinclude -Iorb_slam_amd/cpp $< -o $@ -Lorb_slam_amd -lorbx -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
 
+# the device-resident front-end driven from plain C++ through the C ABI (no HIP headers on the host side)
+orb_slam_amd/cpp/example_pipeline: orb_slam_amd/cpp/example_pipeline.cpp include/orbx.h include/orbf.h include/orbv.h include/orbs.h orb_slam_amd/liborbx.so
+	$(CXX) -O2 -std=c++14 -Iinclude $< -o $@ -Lorb_slam_amd -lorbx -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
+
 clean:
-	rm -f orb_slam_amd/cpp/example_frame orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
+	rm -f orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
 	rm -rf oracle/_ref
 
 .PHONY: all clean oracle_ref

@@ -133,6 +133,14 @@ int orbm_match_top2_segments_device(const uint8_t* dQ, int nq, const uint8_t* dT
 /* number of queries passing  best <= th && (float)best < ratio*(float)second  (host arrays) */
 int orbm_count_accepted(const int32_t* best, const int32_t* second, int nq, int th, float ratio);
 
+/* Device-memory helpers for hosts that do not want to include the HIP headers (a C or C++ translation unit of ORB_SLAM can
+ * keep frames, keypoints, descriptors and the search structures resident on the GPU with these four calls and chain the
+ * *_device entry points of orbx.h / orbf.h / orbv.h / orbs.h; see orb_slam_amd/cpp/example_pipeline.cpp).  Synchronous. */
+int orbx_device_alloc(int device, size_t bytes, void** d_ptr);       /* zero-initialised */
+int orbx_device_free(int device, void* d_ptr);
+int orbx_device_upload(int device, void* d_dst, const void* src, size_t bytes);
+int orbx_device_download(int device, void* dst, const void* d_src, size_t bytes);      /* waits for all queued work of the device */
+
 /* MapPoint::ComputeDistinctiveDescriptors for M map points at once (src/MapPoint.cc:216-244): point p owns the descriptors
  * [seg_off[p], seg_off[p+1]) of `desc`; best_idx[p] = the index INSIDE its segment of the descriptor whose sorted row of
  * distances (self included) has the smallest element at position (int)(0.5*(N-1)) — first such row on ties —, best_median[p]

@@ -26,7 +26,8 @@ EXPORTS = [
     "orbx_default_params", "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_scale_factor",
     "orbx_max_keypoints", "orbx_last_error", "orbx_extract", "orbx_extract_batch_device",
     "orbm_hamming256", "orbm_match_top2", "orbm_match_top2_device", "orbm_match_top2_batch_device",
-    "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbm_distinctive", "orbm_distinctive_device", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
+    "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbm_distinctive", "orbm_distinctive_device",
+    "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_device_download", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
     "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element", "orbx_debug_geometry",
 ]
 # include/orbf.h (Frame-side steps: undistortion, search grid, window query)
@@ -129,6 +130,10 @@ def lib():
         L.orbm_count_accepted.argtypes = [vp, vp, ci, ci, cf]
         L.orbm_match_top2_segments.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci]
         L.orbm_match_top2_segments_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp]
+        L.orbx_device_alloc.argtypes = [ci, ctypes.c_size_t, ctypes.POINTER(vp)]
+        L.orbx_device_free.argtypes = [ci, vp]
+        L.orbx_device_upload.argtypes = [ci, vp, vp, ctypes.c_size_t]
+        L.orbx_device_download.argtypes = [ci, vp, vp, ctypes.c_size_t]
         L.orbm_distinctive.argtypes = [vp, vp, ci, vp, vp, ci]
         L.orbm_distinctive_device.argtypes = [vp, vp, ci, vp, vp, vp]
         L.orbx_debug_set_stop_after.argtypes = [vp, ci]

@@ -427,4 +427,35 @@ int orbx_debug_eval_math(int kind, const float* in0, const float* in1, float* ou
     return rc;
 }
 
+
+int orbx_device_alloc(int device, size_t bytes, void** d_ptr) {
+    if (!d_ptr || bytes == 0) return ORBX_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return ORBX_ERR_DEVICE;
+    if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return ORBX_ERR_DEVICE; }
+    *d_ptr = p;
+    return ORBX_OK;
+}
+
+int orbx_device_free(int device, void* d_ptr) {
+    if (!d_ptr) return ORBX_OK;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    return hipFree(d_ptr) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbx_device_upload(int device, void* d_dst, const void* src, size_t bytes) {
+    if (bytes == 0) return ORBX_OK;
+    if (!d_dst || !src) return ORBX_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    return hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbx_device_download(int device, void* dst, const void* d_src, size_t bytes) {
+    if (bytes == 0) return ORBX_OK;
+    if (!dst || !d_src) return ORBX_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return ORBX_ERR_DEVICE;
+    return hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
 }  // extern "C"

@@ -269,3 +269,44 @@ def test_randomised_configurations():
     out = json.loads(res.stdout.strip().splitlines()[-1])
     assert out["mismatches"] == [] and out["bit_exact"] >= 30
     assert out["bit_exact"] + out["geometry_the_reference_cannot_process"] + out["implementation_limit"] == 60
+
+
+def test_cpp_device_resident_pipeline(tmp_path):
+    """orb_slam_amd/cpp/example_pipeline.cpp: extract -> undistort/grid -> bag of words -> WindowSearch(last, current) chained on the
+    device from plain C++ through the C ABI (device buffers via orbx_device_alloc), compared with the oracle chain"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "orb_slam_amd", "cpp", "example_pipeline")
+    assert os.path.exists(exe), "run make"
+    A, B = synth.frame(640, 480, synth.BLOCKS, 30), synth.frame(640, 480, synth.BLOCKS, 31)
+    pa, pb, out = tmp_path / "a.raw", tmp_path / "b.raw", tmp_path / "out.bin"
+    pa.write_bytes(A.tobytes()); pb.write_bytes(B.tobytes())
+    voc = os.path.join(root, "tests", "golden", "voc_k6_L3.txt")
+    res = subprocess.run([exe, "640", "480", str(pa), str(pb), voc, str(out)], capture_output=True, text=True, timeout=180)
+    assert res.returncode == 0, res.stdout + res.stderr
+    # oracle chain
+    oe = orc.OracleExtractor()
+    ka, da = oe(A)
+    kb, db = oe(B)
+    cam = capi.Camera.make(517.3, 516.5, 318.6, 255.3, (0.2624, -0.9531, -0.0054, 0.0026), 640, 480)
+    bnd = orc.frame_bounds(cam, capi.Bounds)
+    una, unb = orc.frame_undistort(cam, ka), orc.frame_undistort(cam, kb)
+    off, feat = orc.frame_grid(bnd, unb)
+    wid, wval = orc.OracleVocabulary(path=voc).transform(db, 4)[:2]
+    qx = np.stack([una["x"], una["y"], np.full(len(una), 100.0, np.float32)], -1)
+    ql = np.stack([una["octave"], una["octave"]], -1).astype(np.int32)
+    nm, q2t, _, _, _ = orc.window_search(bnd, capi.RULE_WINDOW, capi.TH_HIGH, 0.8, True, unb, db, off, feat, None, qx, ql, da, una["angle"], None)
+    # parse the C++ output
+    blob = out.read_bytes()
+    pos = 0
+    nB = int(np.frombuffer(blob[pos:pos + 4], np.int32)[0]); pos += 4
+    g_un = np.frombuffer(blob[pos:pos + 28 * nB], capi.KP_DTYPE); pos += 28 * nB
+    g_off = np.frombuffer(blob[pos:pos + 4 * 3073], np.int32); pos += 4 * 3073
+    nbow = int(np.frombuffer(blob[pos:pos + 4], np.int32)[0]); pos += 4
+    rec = np.frombuffer(blob[pos:pos + 12 * nbow], np.dtype([("w", "<u4"), ("v", "<f8")])); pos += 12 * nbow
+    g_nm, nA = (int(v) for v in np.frombuffer(blob[pos:pos + 8], np.int32)); pos += 8
+    g_q2t = np.frombuffer(blob[pos:pos + 4 * nA], np.int32)
+    assert nB == len(kb) and g_un.tobytes() == unb.tobytes() and np.array_equal(g_off, off)
+    assert nbow == len(wid) and np.array_equal(rec["w"], wid) and rec["v"].tobytes() == wval.tobytes()
+    assert nA == len(ka) and g_nm == nm and np.array_equal(g_q2t, q2t)
+    assert "window_matches=%d" % nm in res.stdout
