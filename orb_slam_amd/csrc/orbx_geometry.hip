@@ -261,6 +261,7 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
         if (max_px > 65535) { err = "grid cell larger than 65535 pixels"; return ORBX_ERR_CAPACITY; }
         g.fast_max_px = align_up(std::max(max_px, 16), 16);
         g.fast_max_chunks = align_up((max_px + 63) / 64 + 1, 4);
+        if (g.fast_max_chunks > 512) { err = "k_fast_cells work item above 32768 pixels"; return ORBX_ERR_CAPACITY; }   // list output: one lane per 64-pixel chunk
         g.fast_lds_bytes = 272 /*sizeof(FastLds)*/ + g.fast_max_chunks * 12 + 3 * 3072 * 2 /*three u16 queues of FAST_QCAP*/ + g.fast_max_px + align_up(max_img, 16) + 16;
         if (g.fast_lds_bytes > 160 * 1024) { err = "grid cell does not fit the 160 KiB LDS"; return ORBX_ERR_CAPACITY; }
     }

@@ -271,16 +271,24 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
                                  (uint32_t)row[imin(4 * d + 3, xm)] << 24;
                 }
             }
+            if (i0 == 0) {
+                // the clears of the other LDS regions ride on the latency of the loads just issued
+                for (int i = tid; i < (g.fast_max_px >> 4); i += FAST_THREADS) reinterpret_cast<uint4*>(s_sc)[i] = make_uint4(0, 0, 0, 0);
+                for (int i = tid; i < (int)(sizeof(FastLds) / 4); i += FAST_THREADS) reinterpret_cast<int*>(hdr)[i] = 0;
+                for (int i = tid; i < nchunks; i += FAST_THREADS) cmask[i] = 0ull;
+            }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int i = i0 + k * FAST_THREADS + tid;
                 if (i < total) reinterpret_cast<uint32_t*>(s_img)[i] = v4[k];   // row r, dword d  ==  r*nd + d  (S = 4*nd)
             }
         }
+        if (b.dbg & 8) {   // development switch "no image staging": the clears still have to happen
+            for (int i = tid; i < (g.fast_max_px >> 4); i += FAST_THREADS) reinterpret_cast<uint4*>(s_sc)[i] = make_uint4(0, 0, 0, 0);
+            for (int i = tid; i < (int)(sizeof(FastLds) / 4); i += FAST_THREADS) reinterpret_cast<int*>(hdr)[i] = 0;
+            for (int i = tid; i < nchunks; i += FAST_THREADS) cmask[i] = 0ull;
+        }
     }
-    for (int i = tid; i < (g.fast_max_px >> 4); i += FAST_THREADS) reinterpret_cast<uint4*>(s_sc)[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < (int)(sizeof(FastLds) / 4); i += FAST_THREADS) reinterpret_cast<int*>(hdr)[i] = 0;
-    for (int i = tid; i < nchunks; i += FAST_THREADS) cmask[i] = 0ull;
     __syncthreads();
 
     const float inv_cw = 1.0f / (float)cw;
@@ -407,44 +415,38 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
     if (b.dbg & 16) return;
     if (batch > 0) nms_round(q2 + ((batch - 1) & 1) * FAST_QCAP, hdr->n2[batch - 1]);
     __syncthreads();
-    // exclusive scan of the per-chunk survivor counts (wave 0): lane-local run, wave scan, lane-local fix-up
-    if (wave == 0) {
-        const int per = (nchunks + 63) >> 6;
-        const int c0 = lane * per, c1 = imin(c0 + per, nchunks);
-        int sum = 0;
-        for (int ci = c0; ci < c1; ci++) sum += __popcll(cmask[ci]);
-        int incl = sum;
+    // The cell's keypoint list in raster order (cv::FAST's order): one LANE per 64-pixel chunk of the survivor bitmask.
+    // Block-wide exclusive scan of the chunk popcounts (wave scan + per-wave totals), then every lane walks the few set bits
+    // of its own chunk.  (A wave-per-chunk loop spent most of its time on empty chunks: 18 dependent LDS reads per wave.)
+    int* wsum = coffs;                                  // reuse: FAST_THREADS / 64 wave totals
+    unsigned long long m = 0ull;
+    if (tid < nchunks) m = cmask[tid];
+    int cnt = __popcll(m), incl = cnt;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        int run = incl - sum;
-        for (int ci = c0; ci < c1; ci++) { coffs[ci] = run; run += __popcll(cmask[ci]); }
-        if (lane == 63) hdr->n_all = incl;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
     }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    // the cell's keypoint list in raster order (cv::FAST's order)
+    int run = incl - cnt, total = 0;
+#pragma unroll
+    for (int wv = 0; wv < FAST_THREADS / 64; wv++) { const int t = wsum[wv]; if (wv < wave) run += t; total += t; }
     Cand* out = b.cand + (long long)frame * g.frame_cands + L.cand_base + bg.cand_off;
-    for (int ci = wave; ci < nchunks; ci += FAST_THREADS / 64) {
-        // the mask word is the same for the whole wave: keep it in SGPRs so that empty chunks cost a scalar branch
-        const uint32_t* mw = reinterpret_cast<const uint32_t*>(cmask + ci);
-        const uint32_t mlo = __builtin_amdgcn_readfirstlane(mw[0]), mhi = __builtin_amdgcn_readfirstlane(mw[1]);
-        if ((mlo | mhi) == 0) continue;
-        const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-        if ((m >> lane) & 1ull) {
-            const int p = ci * 64 + lane;
-            int y, x;
-            split_px(p, cw, inv_cw, y, x);
-            Cand e;
-            e.pos = (uint32_t)(cg.x0 + x) | ((uint32_t)(cg.y0 + y) << 16);
-            e.resp = (float)s_sc[p];
-            out[coffs[ci] + __popcll(m & lt)] = e;
-        }
+    while (m) {
+        const int bit = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int p = tid * 64 + bit;
+        int y, x;
+        split_px(p, cw, inv_cw, y, x);
+        Cand e;
+        e.pos = (uint32_t)(cg.x0 + x) | ((uint32_t)(cg.y0 + y) << 16);
+        e.resp = (float)s_sc[p];
+        out[run++] = e;
     }
     if (tid == 0) {
         CellState st;
-        st.n_all = hdr->n_all; st.n_hi = hdr->n_hi; st.n_lo = hdr->n_lo;
+        st.n_all = total; st.n_hi = hdr->n_hi; st.n_lo = hdr->n_lo;
         *cst = st;
     }
 }
