@@ -882,32 +882,35 @@ __global__ __launch_bounds__(256) void k_describe(Batch b) {
     // HALF_PATCH_SIZE = 15, so it is a constant: nibble v of UMAX_NIBBLES (the host checks it against the computed table).
     int m10 = 0, m01 = 0;
     {
-        // the circular patch is symmetric under (u,v) -> (v,u) (the reference builds umax[] that way, :503-510; the host
-        // re-checks it), so "|u| <= umax[|v|]" is the same as "|v| <= umax[|u|]": one per-lane constant, one compare per row
-        const int u = (lane & 31) - HALF_PATCH;
-        const int au = u < 0 ? -u : u;
-        const int vm = au <= HALF_PATCH ? (int)((UMAX_NIBBLES >> (4 * (au & 15))) & 15ull) : -1;
-        // loads are unconditional (addresses clamped into the 31x31 box, always inside the image: the keypoint is >= 16 px
-        // from every edge) and masked afterwards: 16 independent loads in flight, no divergent branches
-        const int uc = u > HALF_PATCH ? HALF_PATCH : u;
-        const uint8_t* col = plain + (unsigned)(x + uc);
-        int Iv[16];
+        // The 31 x 31 box is cut into 31 rows x 8 dwords (u = -15 .. 16; the 32nd byte is masked off): 248 slots, 4 per lane.
+        // Per slot ONE (unaligned) dword load, the circle mask as a byte mask, and two v_dot4_u32_u8: sum of (u + 15) * I and
+        // sum of I — m10 = sum((u + 15) I) - 15 sum(I), m01 = sum(v * rowsum(I)).  The masks and weights depend only on the lane.
+        int a_su = 0, a_si = 0, a_v = 0;
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            int r = it * 2 + (int)(lane >> 5);
-            r = r > 2 * HALF_PATCH ? 2 * HALF_PATCH : r;
-            Iv[it] = col[__umul24((unsigned)(y - HALF_PATCH + r), pstride)];
-        }
+        for (int i = 0; i < 4; i++) {
+            const int sl = lane + 64 * i;
+            const int r = sl >> 3, c = sl & 7;                   // row 0..30 (31 = idle), dword column
+            const int v = r - HALF_PATCH, av = v < 0 ? -v : v;
+            const int um = r < 31 ? (int)((UMAX_NIBBLES >> (4 * (av & 15))) & 15ull) : -1;
+            uint32_t mask = 0, uw = 0;
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int v = it * 2 + (int)(lane >> 5) - HALF_PATCH;
-            const int av = v < 0 ? -v : v;
-            const int I = av <= vm ? Iv[it] : 0;
-            m10 += u * I;
-            m01 += v * I;
+            for (int k = 0; k < 4; k++) {
+                const int u = 4 * c + k - HALF_PATCH;
+                const int au = u < 0 ? -u : u;
+                if (au <= um) mask |= 0xFFu << (8 * k);
+                uw |= (uint32_t)(4 * c + k) << (8 * k);          // u + 15
+            }
+            const int rr = r < 31 ? r : 30;                       // idle slots re-read the last row (mask = 0)
+            uint32_t I;
+            __builtin_memcpy(&I, plain + (unsigned)(x + 4 * c - HALF_PATCH) + __umul24((unsigned)(y - HALF_PATCH + rr), pstride), 4);
+            I &= mask;
+            const int si = (int)__builtin_amdgcn_udot4(I, 0x01010101u, 0u, false);
+            a_su = (int)__builtin_amdgcn_udot4(I, uw, (uint32_t)a_su, false);
+            a_si += si;
+            a_v += v * si;
         }
-        m10 = wave_sum(m10);
-        m01 = wave_sum(m01);
+        m10 = wave_sum(a_su - HALF_PATCH * a_si);
+        m01 = wave_sum(a_v);
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
