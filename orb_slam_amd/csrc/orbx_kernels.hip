@@ -167,6 +167,9 @@ constexpr int FAST_ROUND = FAST_THREADS * FAST_PPT;   // pixels per round
 constexpr int FAST_QCAP = FAST_ROUND + 1024;   // queue capacity: a batch is flushed once it holds more than FAST_QCAP - FAST_ROUND survivors
 constexpr int FAST_MAX_ROUNDS = 32;   // cells hold < 65536 pixels (checked on the host)
 
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2v as_us2v(uint32_t v) { return __builtin_bit_cast(us2v, v); }
+
 struct FastLds {
     int n1[FAST_MAX_ROUNDS];   // per round: pixels that passed the compass test
     int n2[FAST_MAX_ROUNDS];   // per round: pixels that passed the opposite-pair test (get an exact score)
@@ -796,7 +799,8 @@ __global__ __launch_bounds__(256) void k_blur(Batch b) {
     const int te = x < L.blur_wvec;                            // blur_wvec is a multiple of 4
     const uint32_t WA = 0x37312212u;                           // taps 18,34,49,55 (little-endian bytes)
     const uint32_t WB = 0x00122231u;                           // taps 49,34,18,0
-    uint32_t rs[7][4];
+    uint32_t pp[6][4];            // pp[r % 6] = (row r-1 | row r << 16) of the lane's 4 pixels
+    uint32_t prev[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < BLUR_ROWS + 6; r++) {
         const int yy = reflect101(y0 + r - 3, h);
@@ -821,22 +825,33 @@ __global__ __launch_bounds__(256) void k_blur(Batch b) {
                        wa2 = __builtin_amdgcn_alignbyte(C, Lw, 3), wa3 = C;
         const uint32_t wb0 = __builtin_amdgcn_alignbyte(R, C, 1), wb1 = __builtin_amdgcn_alignbyte(R, C, 2),
                        wb2 = __builtin_amdgcn_alignbyte(R, C, 3), wb3 = R;
-        uint32_t* cur = rs[r % 7];
+        uint32_t cur[4];
         cur[0] = __builtin_amdgcn_udot4(wa0, WA, __builtin_amdgcn_udot4(wb0, WB, 0u, false), false);
         cur[1] = __builtin_amdgcn_udot4(wa1, WA, __builtin_amdgcn_udot4(wb1, WB, 0u, false), false);
         cur[2] = __builtin_amdgcn_udot4(wa2, WA, __builtin_amdgcn_udot4(wb2, WB, 0u, false), false);
         cur[3] = __builtin_amdgcn_udot4(wa3, WA, __builtin_amdgcn_udot4(wb3, WB, 0u, false), false);
+        // Vertical pass.  A row sum is at most 255 * 257 = 65535, so two consecutive rows of one pixel fit one dword and
+        // v_dot2_u32_u16 takes two taps per instruction: with pair(r) = (row r-1 | row r << 16) the output of rows r-6 .. r is
+        //   dot2(pair(r-5), 18|34) + dot2(pair(r-3), 49|55) + dot2(pair(r-1), 49|34) + 18 * row r        (4 ops + 1 pack per pixel)
+        if (r >= 1) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) pp[r % 6][i] = prev[i] | (cur[i] << 16);
+        }
         if (r >= 6) {
             const int oy = y0 + r - 6;
             uint32_t packed = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int sum = blur_taps7((int)rs[(r - 6) % 7][i], (int)rs[(r - 5) % 7][i], (int)rs[(r - 4) % 7][i], (int)rs[(r - 3) % 7][i],
-                                           (int)rs[(r - 2) % 7][i], (int)rs[(r - 1) % 7][i], (int)rs[r % 7][i]);
-                packed |= (uint32_t)blur_round(sum, te) << (8 * i);
+                uint32_t sum = cur[i] * (uint32_t)ORBX_G0;
+                sum = __builtin_amdgcn_udot2(as_us2v(pp[(r - 5) % 6][i]), as_us2v((uint32_t)ORBX_G0 | ((uint32_t)ORBX_G1 << 16)), sum, false);
+                sum = __builtin_amdgcn_udot2(as_us2v(pp[(r - 3) % 6][i]), as_us2v((uint32_t)ORBX_G2 | ((uint32_t)ORBX_G3 << 16)), sum, false);
+                sum = __builtin_amdgcn_udot2(as_us2v(pp[(r - 1) % 6][i]), as_us2v((uint32_t)ORBX_G2 | ((uint32_t)ORBX_G1 << 16)), sum, false);
+                packed |= (uint32_t)blur_round((int)sum, te) << (8 * i);
             }
             if (writer && oy < h) *reinterpret_cast<uint32_t*>(dst + (long long)oy * L.stride + x) = packed;
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++) prev[i] = cur[i];
     }
 }
 
