@@ -253,7 +253,7 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
             const int cw = c.x1 - c.x0 + 1, ch = c.ey1 - c.ey0 + 1;
             if (cw <= 0 || ch <= 0) continue;
             max_px = std::max(max_px, cw * ch);
-            if (cw > 1000) { err = "grid cell wider than 1000 pixels"; return ORBX_ERR_CAPACITY; }   // k_fast_cells: a round must span > 1 row
+            if (cw > 2000) { err = "grid cell wider than 2000 pixels"; return ORBX_ERR_CAPACITY; }   // k_fast_cells: the NMS lags one batch (>= 2048 px): a pixel row must be shorter than that
             if (((cw / 4 + 2) * ch + 511) / 512 > 32) { err = "grid cell band needs more than 32 k_fast_cells rounds"; return ORBX_ERR_CAPACITY; }
             const int nd = (3 + cw + 6 + 3) / 4;
             max_img = std::max(max_img, nd * 4 * (ch + 6));

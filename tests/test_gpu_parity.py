@@ -310,3 +310,14 @@ def test_cpp_device_resident_pipeline(tmp_path):
     assert nbow == len(wid) and np.array_equal(rec["w"], wid) and rec["v"].tobytes() == wval.tobytes()
     assert nA == len(ka) and g_nm == nm and np.array_equal(g_q2t, q2t)
     assert "window_matches=%d" % nm in res.stdout
+
+
+@pytest.mark.parametrize("w,h,nf,nl,sf", [(1380, 900, 10, 1, 1.2), (1990, 1200, 30, 1, 1.2), (1700, 1000, 40, 2, 1.3)])
+def test_wide_grid_cells(gpu_extractor_factory, w, h, nf, nl, sf):
+    """few features on a wide image: grid cells 1300-1960 px wide (one pixel row of a cell is most of a 2048-pixel NMS batch)"""
+    for fam, th in ((synth.NOISE, 20), (synth.BLOCKS, 7), (synth.LOWTEX, 7)):
+        img = synth.frame(w, h, fam, 5)
+        ok, od = orc.OracleExtractor(nf, sf, nl, 1, th)(img)
+        gk, gd = gpu_extractor_factory(nfeatures=nf, scaleFactor=sf, nlevels=nl, fastTh=th)(img)
+        _assert_kps_equal(gk, ok)
+        np.testing.assert_array_equal(gd, od)

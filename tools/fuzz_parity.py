@@ -36,7 +36,7 @@ for c in range(cases):
             geo += 1            # geometry the reference itself cannot process (documented deviation): nothing to compare
             continue
         if e.code == capi.ORBX_ERR_CAPACITY:
-            lim += 1            # implementation limit (e.g. one grid cell wider than 1000 px: 50 features on a 1300-px image)
+            lim += 1            # implementation limit (e.g. one grid cell wider than 2000 px: a handful of features on a 2100-px-wide image)
             continue
         bad.append(dict(case=c, w=w, h=h, nf=nf, sf=sf, nl=nl, st=st, th=th, fam=fam, err=e.code))
         continue
