@@ -64,5 +64,5 @@ def test_rejections_are_classified():
             capi.geometry(**args)
         assert e.value.code == capi.ORBX_ERR_GEOMETRY, args
     with pytest.raises(capi.OrbxError) as e:
-        capi.geometry(w=2100, h=900, nfeatures=10, nlevels=1)           # one cell 2068 px wide: fine for the reference, not for k_fast_cells
+        capi.geometry(w=4200, h=900, nfeatures=40, nlevels=1)           # cells 2084 px wide: fine for the reference, not for k_fast_cells
     assert e.value.code == capi.ORBX_ERR_CAPACITY
