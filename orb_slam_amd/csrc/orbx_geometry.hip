@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "orbx_internal.h"
@@ -24,7 +25,7 @@ static inline int16_t sat16(float v) {   // saturate_cast<short>(float)
 }
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
-static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out, std::string& err, const int band_px) {
+static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out, std::string& err, const int band_px, const int threads) {
     const int nl = p.nlevels;
     if (nl < 1 || nl > MAX_LEVELS) { err = "nlevels out of range [1,16]"; return ORBX_ERR_ARG; }
     if (p.nfeatures < 1) { err = "nfeatures must be >= 1"; return ORBX_ERR_ARG; }
@@ -254,15 +255,15 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
             if (cw <= 0 || ch <= 0) continue;
             max_px = std::max(max_px, cw * ch);
             if (cw > 2000) { err = "grid cell wider than 2000 pixels"; return ORBX_ERR_CAPACITY; }   // k_fast_cells: the NMS lags one batch (>= 2048 px): a pixel row must be shorter than that
-            if (((cw / 4 + 2) * ch + 511) / 512 > 32) { err = "grid cell band needs more than 32 k_fast_cells rounds"; return ORBX_ERR_CAPACITY; }
+            if (((cw / 4 + 2) * ch + threads - 1) / threads > 32) { err = "grid cell band needs more than 32 k_fast_cells rounds"; return ORBX_ERR_CAPACITY; }
             const int nd = (3 + cw + 6 + 3) / 4;
             max_img = std::max(max_img, nd * 4 * (ch + 6));
         }
         if (max_px > 65535) { err = "grid cell larger than 65535 pixels"; return ORBX_ERR_CAPACITY; }
         g.fast_max_px = align_up(std::max(max_px, 16), 16);
         g.fast_max_chunks = align_up((max_px + 63) / 64 + 1, 4);
-        if (g.fast_max_chunks > 512) { err = "k_fast_cells work item above 32768 pixels"; return ORBX_ERR_CAPACITY; }   // list output: one lane per 64-pixel chunk
-        g.fast_lds_bytes = 272 /*sizeof(FastLds)*/ + g.fast_max_chunks * 12 + 3 * 3072 * 2 /*three u16 queues of FAST_QCAP*/ + g.fast_max_px + align_up(max_img, 16) + 16;
+        if (g.fast_max_chunks > threads) { err = "k_fast_cells work item above 32768 pixels"; return ORBX_ERR_CAPACITY; }   // list output: one lane per 64-pixel chunk
+        g.fast_lds_bytes = 272 /*sizeof(FastLds)*/ + g.fast_max_chunks * 12 + 3 * fast_qcap(threads) * 2 /*three u16 queues*/ + g.fast_max_px + align_up(max_img, 16) + 16;
         if (g.fast_lds_bytes > 160 * 1024) { err = "grid cell does not fit the 160 KiB LDS"; return ORBX_ERR_CAPACITY; }
     }
     {
@@ -293,18 +294,34 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
 }
 
 
-// k_fast_cells keeps 4 workgroups (32 waves) on a CU only while one work item needs <= 40 KB of LDS.  The default band of
-// BAND_PX pixels gives exactly that for VGA-class grids; where the cell shape pushes it over (1080p: 42.4 KB -> 3 workgroups),
-// slightly smaller bands restore the fourth workgroup.
+// Shape of k_fast_cells.  Default: 512 threads per work item, bands of BAND_PX pixels; 4 work items (32 waves) fit a CU only
+// while one needs <= 40 KB of LDS, so where the cell shape pushes it over (1080p: 42.4 KB -> 3 per CU) slightly smaller bands
+// restore the fourth.  VGA-class grids (largest cell view <= 12288 px) run faster as 256-thread items over 8192-pixel bands
+// (5 items per CU: more independent latency chains; measured 0.90 -> 0.86 ms per 512 VGA frames, while 720p / 1080p lose 2-7 %).
 int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::string& err) {
     constexpr int LDS_FOR_FOUR = (160 * 1024) / 4 - 64;
-    int rc = build_geometry_band(p, w, h, out, err, BAND_PX);
-    if (rc != ORBX_OK || out.g.fast_lds_bytes <= LDS_FOR_FOUR) return rc;
+    int rc = build_geometry_band(p, w, h, out, err, BAND_PX, 512);
+    if (rc != ORBX_OK) return rc;
+    out.g.fast_threads = 512;
+    int max_cell_px = 0;
+    for (const CellGeom& c : out.cells) max_cell_px = std::max(max_cell_px, (c.x1 - c.x0 + 1) * (c.y1 - c.y0 + 1));
+    if (max_cell_px <= 12288 && !getenv("ORBX_FAST512")) {
+        HostGeom trial;
+        std::string e2;
+        if (build_geometry_band(p, w, h, trial, e2, BAND_PX_SMALL, 256) == ORBX_OK) {
+            out = trial;
+            out.g.fast_threads = 256;
+            err.clear();
+            return ORBX_OK;
+        }
+    }
+    if (out.g.fast_lds_bytes <= LDS_FOR_FOUR) return rc;
     for (int band = BAND_PX - 512; band >= 8192; band -= 512) {
         HostGeom trial;
         std::string e2;
-        if (build_geometry_band(p, w, h, trial, e2, band) == ORBX_OK && trial.g.fast_lds_bytes <= LDS_FOR_FOUR) {
+        if (build_geometry_band(p, w, h, trial, e2, band, 512) == ORBX_OK && trial.g.fast_lds_bytes <= LDS_FOR_FOUR) {
             out = trial;
+            out.g.fast_threads = 512;
             err.clear();
             return ORBX_OK;
         }

@@ -56,7 +56,10 @@ struct CellGeom {
 
 // One k_fast_cells work item: a band of rows of a grid cell.  Cells above BAND_PX pixels (1080p grids) are cut into
 // row bands so that a work item's LDS footprint stays ~35 KB (4 workgroups per CU); bands concatenate in raster order.
-constexpr int BAND_PX = 10240;
+constexpr int BAND_PX = 10240;          // default band of the 512-thread shape
+constexpr int BAND_PX_SMALL = 8192;     // band of the 256-thread shape (VGA-class grids)
+constexpr int FAST_PPT = 4;             // k_fast_cells: pixels per lane per round
+constexpr int fast_qcap(int threads) { return threads * FAST_PPT + 1024; }   // queue capacity: a batch is flushed once it holds more than 1024 survivors
 struct BandGeom {
     int16_t x0, x1;           // the cell's column range (inclusive)
     int16_t y0, y1;           // rows this band owns (inclusive)
@@ -81,6 +84,7 @@ struct DevGeom {
     int frame_sel;           // sel slots per frame
     int sel_lds_cell, sel_lds_level, sel_lds_entries;   // LDS bytes of k_cell_select / k_level_select and the list entries they stage
     int fast_max_px, fast_max_chunks, fast_lds_bytes;   // k_fast_cells LDS carve (largest cell of any level)
+    int fast_threads;        // k_fast_cells workgroup size chosen for this geometry (256 or 512)
     int umax[HALF_PATCH + 1];
     // per-level bases as compact arrays: one scalar load each, so a wave finds its level in a single round trip
     // (walking lv[l].xxx_base level by level was a chain of up to nlevels dependent scalar loads, ~1.5 us per wave)

@@ -161,10 +161,6 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
 //          survivors of the band's own rows set their bit in an LDS bitmask;
 //   3. a wave-level scan over the bitmask popcounts gives list offsets and the keypoint list comes out in cv::FAST's
 //      raster order together with its counts at fastTh and at 7.
-constexpr int FAST_THREADS = 512;     // 8 waves per cell: more work between barriers, full CU occupancy at ~35 KB LDS per cell
-constexpr int FAST_PPT = 4;           // pixels per lane per round
-constexpr int FAST_ROUND = FAST_THREADS * FAST_PPT;   // pixels per round
-constexpr int FAST_QCAP = FAST_ROUND + 1024;   // queue capacity: a batch is flushed once it holds more than FAST_QCAP - FAST_ROUND survivors
 constexpr int FAST_MAX_ROUNDS = 32;   // cells hold < 65536 pixels (checked on the host)
 
 typedef unsigned short us2v __attribute__((ext_vector_type(2)));
@@ -217,8 +213,12 @@ __device__ __forceinline__ void queue_push(uint16_t* q, int* counter, int pass, 
     }
 }
 
-template <bool ALIGNED>
+// FAST_THREADS: 512 (8 waves: 1080p-class grids, ~40 KB LDS per work item, 4 items per CU) or 256 (VGA-class grids: smaller bands,
+// ~28 KB, 5 items per CU — more independent latency chains in flight)
+template <bool ALIGNED, int FAST_THREADS>
 __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t* smem) {
+    constexpr int FAST_ROUND = FAST_THREADS * FAST_PPT;   // pixels per round
+    constexpr int FAST_QCAP = fast_qcap(FAST_THREADS);
     const DevGeom& g = b.g;
     const int frame = task / g.nbands_total;
     const int item = task - frame * g.nbands_total;
@@ -456,10 +456,10 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
 
 // One workgroup per (frame, cell).  (A persistent variant — 4 workgroups per CU walking the cells with a static stride —
 // measured 35 % slower: the hardware dispatcher balances the very uneven cell sizes better than a static schedule.)
-template <bool ALIGNED>
+template <bool ALIGNED, int FAST_THREADS>
 __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    fast_cell_task<ALIGNED>(b, blockIdx.x, smem);
+    fast_cell_task<ALIGNED, FAST_THREADS>(b, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------ quotas
@@ -1044,13 +1044,12 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         StageScope sc(timer, stream, ST_FAST_CELLS);
         const bool aligned = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
         const size_t lds = (size_t)g.fast_lds_bytes;
-        if (lds > 64 * 1024) {   // opt in to > 64 KiB dynamic LDS (big cells, e.g. 1080p)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        }
-        const int nblk = F * g.nbands_total;
-        if (aligned) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nblk), dim3(FAST_THREADS), lds, stream, b);
-        else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nblk), dim3(FAST_THREADS), lds, stream, b);
+        auto launch = [&](auto kern, int threads) {
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(F * g.nbands_total), dim3(threads), lds, stream, b);
+        };
+        if (g.fast_threads == 256) { if (aligned) launch(k_fast_cells<true, 256>, 256); else launch(k_fast_cells<false, 256>, 256); }
+        else { if (aligned) launch(k_fast_cells<true, 512>, 512); else launch(k_fast_cells<false, 512>, 512); }
         ORBX_LAUNCH_CHECK();
     }
     if (stop_after == ST_FAST_CELLS) return ORBX_OK;

@@ -13,7 +13,8 @@ def test_vga_geometry_matches_survey():
     assert [l["quota"] for l in g] == [217, 181, 151, 126, 105, 87, 73, 60]
     assert [(l["grid_cols"], l["grid_rows"]) for l in g] == [(5, 6), (5, 6), (4, 5), (4, 5), (3, 4), (3, 4), (3, 4), (3, 4)]
     assert [(l["cell_w"], l["cell_h"]) for l in g] == [(122, 75), (101, 62), (103, 61), (85, 50), (93, 50), (75, 41), (61, 33), (49, 26)]
-    assert all(l["n_bands"] == l["grid_cols"] * l["grid_rows"] for l in g)       # VGA cells are single-band
+    # VGA-class grids use the 256-thread shape with 8192-pixel bands: only level 0 (128 x 81 = 10368-pixel cell views) is cut in two
+    assert [l["n_bands"] for l in g] == [60, 30, 20, 20, 12, 12, 12, 12]
 
 
 def test_hd_and_init_extractor_geometry():
