@@ -192,7 +192,7 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
 
         // blur work items
         L.btiles_x = (L.w + 247) / 248;        // blur: 248-px column strips x 32-row bands, one wave each
-        L.btiles_y = (L.h + 31) / 32;
+        L.btiles_y = (L.h + BLUR_ROWS - 1) / BLUR_ROWS;
         L.btile_base = btile_base;
         btile_base += L.btiles_x * L.btiles_y;
 
@@ -237,8 +237,8 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
                     const int bx1 = std::min(bx0 + 255, dw - 1);
                     nd_max = std::max(nd_max, ((tx[bx1].sx1 - (tx[bx0].sx & ~3)) >> 2) + 1);
                 }
-                for (int by0 = 0; by0 < dh; by0 += 16) {
-                    const int by1 = std::min(by0 + 15, dh - 1);
+                for (int by0 = 0; by0 < dh; by0 += RZ_ROWS) {
+                    const int by1 = std::min(by0 + RZ_ROWS - 1, dh - 1);
                     nr_max = std::max(nr_max, ty[by1].sy1 - ty[by0].sy0 + 1);
                 }
                 L.rz_pitch = 4 * nd_max;

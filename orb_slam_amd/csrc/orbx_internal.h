@@ -56,6 +56,14 @@ struct CellGeom {
 
 // One k_fast_cells work item: a band of rows of a grid cell.  Cells above BAND_PX pixels (1080p grids) are cut into
 // row bands so that a work item's LDS footprint stays ~35 KB (4 workgroups per CU); bands concatenate in raster order.
+#ifndef ORBX_BLUR_ROWS
+#define ORBX_BLUR_ROWS 32
+#endif
+#ifndef ORBX_RZ_ROWS
+#define ORBX_RZ_ROWS 48
+#endif
+constexpr int BLUR_ROWS = ORBX_BLUR_ROWS;   // k_blur: output rows per wave strip
+constexpr int RZ_ROWS = ORBX_RZ_ROWS;       // k_resize: output rows per workgroup (a tall tile amortises the table -> source -> LDS latency chain)
 constexpr int BAND_PX = 10240;          // default band of the 512-thread shape
 constexpr int BAND_PX_SMALL = 8192;     // band of the 256-thread shape (VGA-class grids)
 constexpr int FAST_PPT = 4;             // k_fast_cells: pixels per lane per round

@@ -67,7 +67,6 @@ __device__ __forceinline__ void split_px(int p, int cw, float inv_cw, int& y, in
 // rectangle it needs (<= 7 rows x ~310 px) is staged in LDS with coalesced dword loads, each lane then
 // reads its 16 taps as LDS bytes, produces 4 horizontally adjacent output pixels and stores one dword.
 // (Byte gathers straight from global memory made this kernel texture-addresser bound.)
-constexpr int RZ_ROWS = 16;        // output rows per workgroup (4 per wave): a tall tile amortises the table -> source -> LDS latency chain
 // LDS source tile: L.rz_rows x L.rz_pitch bytes, the exact maximum over the level's tiles (7 KB at scale 1.2; a fixed
 // worst-case array for scale 2.5 was 31 KB and capped the kernel at 5 workgroups per CU)
 
@@ -763,7 +762,6 @@ int launch_debug_nth(const float* d_resp, int n, int nth, int* d_out) {
 // so the column pass is 7 multiply-adds per pixel; each lane stores its 4 output pixels as one dword.
 // Reads the UNBLURRED plane and writes a separate blurred plane, which is what the reference's in-place
 // filter computes (its border taps read the unblurred reflect-101 border; here: reflect-101 index math).
-constexpr int BLUR_ROWS = 32;
 constexpr int BLUR_STRIP_DW = 62;   // useful dwords per wave (lanes 1..62; lanes 0 and 63 are halo)
 
 __device__ __forceinline__ uint32_t load_px4_reflect(const uint8_t* row, int x, int w) {
