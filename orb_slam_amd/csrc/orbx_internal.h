@@ -56,6 +56,14 @@ struct CellGeom {
 
 // One k_fast_cells work item: a band of rows of a grid cell.  Cells above BAND_PX pixels (1080p grids) are cut into
 // row bands so that a work item's LDS footprint stays ~35 KB (4 workgroups per CU); bands concatenate in raster order.
+#ifndef ORBX_BLUR_WAVES
+#define ORBX_BLUR_WAVES 2
+#endif
+#ifndef ORBX_DESC_WAVES
+#define ORBX_DESC_WAVES 4
+#endif
+constexpr int BLUR_WAVES = ORBX_BLUR_WAVES;   // k_blur: strips (waves) per workgroup
+constexpr int DESC_WAVES = ORBX_DESC_WAVES;   // k_describe: keypoints (waves) per workgroup
 #ifndef ORBX_BLUR_ROWS
 #define ORBX_BLUR_ROWS 32
 #endif

@@ -772,9 +772,9 @@ __device__ __forceinline__ uint32_t load_px4_reflect(const uint8_t* row, int x, 
 }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(256) void k_blur(Batch b) {
+__global__ __launch_bounds__(BLUR_WAVES * 64) void k_blur(Batch b) {
     const DevGeom& g = b.g;
-    const int task_all = blockIdx.x * 4 + wave_id();
+    const int task_all = blockIdx.x * BLUR_WAVES + wave_id();
     const int frame = task_all / g.nbtiles_total;
     if (frame >= b.nframes) return;
     const int t = task_all - frame * g.nbtiles_total;
@@ -857,10 +857,10 @@ __global__ __launch_bounds__(256) void k_blur(Batch b) {
 // One wave per output keypoint.  IC_Angle: 2 patch rows per step, lanes over u; wave reduction of the
 // integer moments.  Descriptor: lane i evaluates tests i, i+64, i+128, i+192; each __ballot is 8
 // descriptor bytes (test t is bit t%8 of byte t/8, LSB first — the reference's packing).
-__global__ __launch_bounds__(256) void k_describe(Batch b) {
+__global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
     const DevGeom& g = b.g;
     const int frame = blockIdx.y;
-    const int slot = blockIdx.x * 4 + wave_id();
+    const int slot = blockIdx.x * DESC_WAVES + wave_id();
     const int lane = threadIdx.x & 63;
     const int32_t* counts = b.level_count + frame * MAX_LEVELS;
     if (slot == 0 && lane == 0) {
@@ -1031,9 +1031,9 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     auto launch_blur = [&](hipStream_t st) -> int {
         StageScope sc(timer, st, ST_BLUR);
         const bool aligned = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
-        const int nblk = (F * g.nbtiles_total + 3) / 4;
-        if (aligned) hipLaunchKernelGGL(k_blur<true>, dim3(nblk), dim3(256), 0, st, b);
-        else hipLaunchKernelGGL(k_blur<false>, dim3(nblk), dim3(256), 0, st, b);
+        const int nblk = (F * g.nbtiles_total + BLUR_WAVES - 1) / BLUR_WAVES;
+        if (aligned) hipLaunchKernelGGL(k_blur<true>, dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);
+        else hipLaunchKernelGGL(k_blur<false>, dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);
         ORBX_LAUNCH_CHECK();
         return ORBX_OK;
     };
@@ -1088,7 +1088,7 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     if (stop_after == ST_BLUR) return ORBX_OK;
     {
         StageScope sc(timer, stream, ST_DESCRIBE);
-        hipLaunchKernelGGL(k_describe, dim3((g.nslots + 3) / 4, F), dim3(256), 0, stream, b);
+        hipLaunchKernelGGL(k_describe, dim3((g.nslots + DESC_WAVES - 1) / DESC_WAVES, F), dim3(DESC_WAVES * 64), 0, stream, b);
         ORBX_LAUNCH_CHECK();
     }
     return ORBX_OK;
