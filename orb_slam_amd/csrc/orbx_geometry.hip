@@ -25,7 +25,8 @@ static inline int16_t sat16(float v) {   // saturate_cast<short>(float)
 }
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
-static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out, std::string& err, const int band_px, const int threads) {
+static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out, std::string& err, const int band_px, const FastShape& shape) {
+    const int threads = shape.threads;
     const int nl = p.nlevels;
     if (nl < 1 || nl > MAX_LEVELS) { err = "nlevels out of range [1,16]"; return ORBX_ERR_ARG; }
     if (p.nfeatures < 1) { err = "nfeatures must be >= 1"; return ORBX_ERR_ARG; }
@@ -254,8 +255,8 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
             const int cw = c.x1 - c.x0 + 1, ch = c.ey1 - c.ey0 + 1;
             if (cw <= 0 || ch <= 0) continue;
             max_px = std::max(max_px, cw * ch);
-            if (cw > 2000) { err = "grid cell wider than 2000 pixels"; return ORBX_ERR_CAPACITY; }   // k_fast_cells: the NMS lags one batch (>= 2048 px): a pixel row must be shorter than that
-            if (((cw / 4 + 2) * ch + threads - 1) / threads > 32) { err = "grid cell band needs more than 32 k_fast_cells rounds"; return ORBX_ERR_CAPACITY; }
+            if (cw > shape.max_cw) { err = "grid cell wider than " + std::to_string(shape.max_cw) + " pixels"; return ORBX_ERR_CAPACITY; }   // k_fast_cells: the NMS lags one batch (>= 2048 px): a pixel row must be shorter than that
+            if ((cw * ch + threads * shape.ppt - 1) / (threads * shape.ppt) > 32) { err = "grid cell band needs more than 32 k_fast_cells rounds"; return ORBX_ERR_CAPACITY; }   // FastLds::n1[]
             const int nd = (3 + cw + 6 + 3) / 4;
             max_img = std::max(max_img, nd * 4 * (ch + 6));
         }
@@ -263,7 +264,7 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
         g.fast_max_px = align_up(std::max(max_px, 16), 16);
         g.fast_max_chunks = align_up((max_px + 63) / 64 + 1, 4);
         if (g.fast_max_chunks > threads) { err = "k_fast_cells work item above 32768 pixels"; return ORBX_ERR_CAPACITY; }   // list output: one lane per 64-pixel chunk
-        g.fast_lds_bytes = 272 /*sizeof(FastLds)*/ + g.fast_max_chunks * 12 + 3 * fast_qcap(threads) * 2 /*three u16 queues*/ + g.fast_max_px + align_up(max_img, 16) + 16;
+        g.fast_lds_bytes = 272 /*sizeof(FastLds)*/ + g.fast_max_chunks * 12 + 3 * fast_qcap(shape) * 2 /*three u16 queues*/ + g.fast_max_px + align_up(max_img, 16) + 16;
         if (g.fast_lds_bytes > 160 * 1024) { err = "grid cell does not fit the 160 KiB LDS"; return ORBX_ERR_CAPACITY; }
     }
     {
@@ -294,34 +295,37 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
 }
 
 
-// Shape of k_fast_cells.  Default: 512 threads per work item, bands of BAND_PX pixels; 4 work items (32 waves) fit a CU only
-// while one needs <= 40 KB of LDS, so where the cell shape pushes it over (1080p: 42.4 KB -> 3 per CU) slightly smaller bands
-// restore the fourth.  VGA-class grids (largest cell view <= 12288 px) run faster as 256-thread items over 8192-pixel bands
-// (5 items per CU: more independent latency chains; measured 0.90 -> 0.86 ms per 512 VGA frames, while 720p / 1080p lose 2-7 %).
+// Shape of k_fast_cells (orbx_internal.h: FAST_SMALL / FAST_LARGE).  VGA-class grids (largest cell view <= 12288 px and at most
+// 500 px wide) take the small shape: 256 threads over 8192-pixel bands with short queues — ~20 KB of LDS, 8 independent work
+// items per CU (0.907 -> 0.79 ms per 512 VGA frames; 720p / 1080p lose 2-7 % with it).  Everything else takes the large shape:
+// 512 threads over 10240-pixel bands, 4 work items per CU as long as one needs <= 40 KB; where the cell shape pushes it over,
+// slightly smaller bands restore the fourth.
 int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::string& err) {
     constexpr int LDS_FOR_FOUR = (160 * 1024) / 4 - 64;
-    int rc = build_geometry_band(p, w, h, out, err, BAND_PX, 512);
-    if (rc != ORBX_OK) return rc;
-    out.g.fast_threads = 512;
-    int max_cell_px = 0;
-    for (const CellGeom& c : out.cells) max_cell_px = std::max(max_cell_px, (c.x1 - c.x0 + 1) * (c.y1 - c.y0 + 1));
-    if (max_cell_px <= 12288 && !getenv("ORBX_FAST512")) {
+    if (!getenv("ORBX_FAST512")) {
         HostGeom trial;
         std::string e2;
-        if (build_geometry_band(p, w, h, trial, e2, BAND_PX_SMALL, 256) == ORBX_OK) {
-            out = trial;
-            out.g.fast_threads = 256;
-            err.clear();
-            return ORBX_OK;
+        if (build_geometry_band(p, w, h, trial, e2, FAST_SMALL.band_px, FAST_SMALL) == ORBX_OK) {
+            int max_cell_px = 0;
+            for (const CellGeom& c : trial.cells) max_cell_px = std::max(max_cell_px, (c.x1 - c.x0 + 1) * (c.y1 - c.y0 + 1));
+            if (max_cell_px <= 12288) {
+                out = trial;
+                out.g.fast_threads = FAST_SMALL.threads;
+                err.clear();
+                return ORBX_OK;
+            }
         }
     }
+    int rc = build_geometry_band(p, w, h, out, err, FAST_LARGE.band_px, FAST_LARGE);
+    if (rc != ORBX_OK) return rc;
+    out.g.fast_threads = FAST_LARGE.threads;
     if (out.g.fast_lds_bytes <= LDS_FOR_FOUR) return rc;
-    for (int band = BAND_PX - 512; band >= 8192; band -= 512) {
+    for (int band = FAST_LARGE.band_px - 512; band >= 8192; band -= 512) {
         HostGeom trial;
         std::string e2;
-        if (build_geometry_band(p, w, h, trial, e2, band, 512) == ORBX_OK && trial.g.fast_lds_bytes <= LDS_FOR_FOUR) {
+        if (build_geometry_band(p, w, h, trial, e2, band, FAST_LARGE) == ORBX_OK && trial.g.fast_lds_bytes <= LDS_FOR_FOUR) {
             out = trial;
-            out.g.fast_threads = 512;
+            out.g.fast_threads = FAST_LARGE.threads;
             err.clear();
             return ORBX_OK;
         }

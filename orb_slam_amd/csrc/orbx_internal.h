@@ -72,10 +72,14 @@ constexpr int DESC_WAVES = ORBX_DESC_WAVES;   // k_describe: keypoints (waves) p
 #endif
 constexpr int BLUR_ROWS = ORBX_BLUR_ROWS;   // k_blur: output rows per wave strip
 constexpr int RZ_ROWS = ORBX_RZ_ROWS;       // k_resize: output rows per workgroup (a tall tile amortises the table -> source -> LDS latency chain)
-constexpr int BAND_PX = 10240;          // default band of the 512-thread shape
-constexpr int BAND_PX_SMALL = 8192;     // band of the 256-thread shape (VGA-class grids)
-constexpr int FAST_PPT = 4;             // k_fast_cells: pixels per lane per round
-constexpr int fast_qcap(int threads) { return threads * FAST_PPT + 1024; }   // queue capacity: a batch is flushed once it holds more than 1024 survivors
+// The two launch shapes of k_fast_cells (threads per work item, pixels per lane per round, queue slack).  A round scans
+// threads * ppt pixels; the compass queue holds one round plus `slack` entries and a batch of rounds is flushed through the
+// later phases once it holds more than `slack` survivors.  Because the NMS lags one batch, a pixel row of the cell view must
+// be shorter than a round (checked on the host: FastShape::max_cw).
+struct FastShape { int threads, ppt, slack, band_px, max_cw; };
+constexpr FastShape FAST_SMALL = {256, 2, 256, 8192, 500};     // VGA-class grids: ~20 KB of LDS, 8 work items per CU
+constexpr FastShape FAST_LARGE = {512, 4, 512, 10240, 2000};   // 720p / 1080p-class grids: ~38 KB, 4 work items per CU
+constexpr int fast_qcap(const FastShape& f) { return f.threads * f.ppt + f.slack; }
 struct BandGeom {
     int16_t x0, x1;           // the cell's column range (inclusive)
     int16_t y0, y1;           // rows this band owns (inclusive)

@@ -214,10 +214,10 @@ __device__ __forceinline__ void queue_push(uint16_t* q, int* counter, int pass, 
 
 // FAST_THREADS: 512 (8 waves: 1080p-class grids, ~40 KB LDS per work item, 4 items per CU) or 256 (VGA-class grids: smaller bands,
 // ~28 KB, 5 items per CU — more independent latency chains in flight)
-template <bool ALIGNED, int FAST_THREADS>
+template <bool ALIGNED, int FAST_THREADS, int FAST_PPT, int FAST_SLACK>
 __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t* smem) {
     constexpr int FAST_ROUND = FAST_THREADS * FAST_PPT;   // pixels per round
-    constexpr int FAST_QCAP = fast_qcap(FAST_THREADS);
+    constexpr int FAST_QCAP = FAST_ROUND + FAST_SLACK;
     const DevGeom& g = b.g;
     const int frame = task / g.nbands_total;
     const int item = task - frame * g.nbands_total;
@@ -455,10 +455,10 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
 
 // One workgroup per (frame, cell).  (A persistent variant — 4 workgroups per CU walking the cells with a static stride —
 // measured 35 % slower: the hardware dispatcher balances the very uneven cell sizes better than a static schedule.)
-template <bool ALIGNED, int FAST_THREADS>
+template <bool ALIGNED, int FAST_THREADS, int FAST_PPT, int FAST_SLACK>
 __global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    fast_cell_task<ALIGNED, FAST_THREADS>(b, blockIdx.x, smem);
+    fast_cell_task<ALIGNED, FAST_THREADS, FAST_PPT, FAST_SLACK>(b, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------ quotas
@@ -1046,8 +1046,12 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
             if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, dim3(F * g.nbands_total), dim3(threads), lds, stream, b);
         };
-        if (g.fast_threads == 256) { if (aligned) launch(k_fast_cells<true, 256>, 256); else launch(k_fast_cells<false, 256>, 256); }
-        else { if (aligned) launch(k_fast_cells<true, 512>, 512); else launch(k_fast_cells<false, 512>, 512); }
+        constexpr FastShape A = FAST_SMALL, B = FAST_LARGE;
+        if (g.fast_threads == A.threads) {
+            if (aligned) launch(k_fast_cells<true, A.threads, A.ppt, A.slack>, A.threads); else launch(k_fast_cells<false, A.threads, A.ppt, A.slack>, A.threads);
+        } else {
+            if (aligned) launch(k_fast_cells<true, B.threads, B.ppt, B.slack>, B.threads); else launch(k_fast_cells<false, B.threads, B.ppt, B.slack>, B.threads);
+        }
         ORBX_LAUNCH_CHECK();
     }
     if (stop_after == ST_FAST_CELLS) return ORBX_OK;
