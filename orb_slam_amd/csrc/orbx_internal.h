@@ -77,8 +77,14 @@ constexpr int RZ_ROWS = ORBX_RZ_ROWS;       // k_resize: output rows per workgro
 // later phases once it holds more than `slack` survivors.  Because the NMS lags one batch, a pixel row of the cell view must
 // be shorter than a round (checked on the host: FastShape::max_cw).
 struct FastShape { int threads, ppt, slack, band_px, max_cw; };
-constexpr FastShape FAST_SMALL = {256, 2, 256, 8192, 500};     // VGA-class grids: ~20 KB of LDS, 8 work items per CU
-constexpr FastShape FAST_LARGE = {512, 4, 512, 10240, 2000};   // 720p / 1080p-class grids: ~38 KB, 4 work items per CU
+#ifndef ORBX_FS
+#define ORBX_FS 256, 2, 256, 8192, 500
+#endif
+constexpr FastShape FAST_SMALL = {ORBX_FS};     // VGA-class grids: ~20 KB of LDS, 8 work items per CU
+#ifndef ORBX_FL
+#define ORBX_FL 512, 4, 512, 10240, 2000
+#endif
+constexpr FastShape FAST_LARGE = {ORBX_FL};   // 720p / 1080p-class grids: ~38 KB, 4 work items per CU
 constexpr int fast_qcap(const FastShape& f) { return f.threads * f.ppt + f.slack; }
 struct BandGeom {
     int16_t x0, x1;           // the cell's column range (inclusive)
