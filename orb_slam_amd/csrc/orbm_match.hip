@@ -22,7 +22,10 @@ namespace orbx {
 
 constexpr int KEY_SHIFT = 22;                       // index bits; distance (<=256) sits above
 constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
-constexpr int MATCH_BLOCK = 256;
+#ifndef ORBX_MATCH_BLOCK
+#define ORBX_MATCH_BLOCK 256
+#endif
+constexpr int MATCH_BLOCK = ORBX_MATCH_BLOCK;
 
 // k1 <= k2 are the two smallest keys so far: the new second-smallest is the median of (k1, k2, key)
 __device__ __forceinline__ void top2_update(uint32_t& k1, uint32_t& k2, uint32_t key) {
@@ -317,7 +320,11 @@ int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const u
     if (nbatch == 0) return ORBX_OK;
     if (((uintptr_t)dQ & 15) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
     // frame-sized problems (~1000 x 1000): 1 query per lane so that a batch of 256 still fills the chip (4 waves per SIMD)
-    hipLaunchKernelGGL(k_match_batch<1>, dim3((cap + MATCH_BLOCK - 1) / MATCH_BLOCK, nbatch), dim3(MATCH_BLOCK), 0, stream, (const uint32_t*)dQ,
+#ifndef ORBX_MATCH_QPL
+#define ORBX_MATCH_QPL 1
+#endif
+    constexpr int BQPL = ORBX_MATCH_QPL;
+    hipLaunchKernelGGL(k_match_batch<BQPL>, dim3((cap + MATCH_BLOCK * BQPL - 1) / (MATCH_BLOCK * BQPL), nbatch), dim3(MATCH_BLOCK), 0, stream, (const uint32_t*)dQ,
                        d_nq, (const uint32_t*)dT, d_nt, cap, d_best_idx, d_best, d_second);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
