@@ -18,11 +18,20 @@
  *   ORBS_RULE_BOW        <- int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                 :155-281
  *                           (candidates = the features of the same vocabulary node instead of a grid window:
  *                           orbs_bow_ranges_batch_device + orbs_list_search_batch_device; accept best <= th && best < ratio*second)
+ *                           int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&)              :718-850
+ *                           (the same with d_claimed = "pMP2 is NULL or bad" and th = TH_LOW - 1: that function tests `bestDist1<TH_LOW`)
+ *   ORBS_RULE_TRIANGULATION <- int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, ...)  :852-1014
+ *                           with ORBmatcher::CheckDistEpipolarLine :136-153 (orbs_triangulation_search_batch_device: candidates of the
+ *                           same vocabulary node with distance <= th, sorted by (distance, index); the first one within
+ *                           2 x the best distance that lies on the query's epipolar line is taken)
  *   ORBS_RULE_FREE       <- the searches WITHOUT the "already matched" masking, every query independent: the scan of
  *                           int ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, float th)                       :1000-1135
  *                           int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, ..., int th)             :283-400
  *                           (window + level range, best distance only, accept best <= th; several queries may end on the same
  *                           feature, so d_t2q is not produced (all -1) and there is no rotation check)
+ *   orbs_agreement_batch_device <- the two scans of int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, vector<MapPoint*>&, s12, R12, t12, th)
+ *                           :1258-1506 are two ORBS_RULE_FREE searches (window + levels [predicted-1, predicted], best <= TH_HIGH);
+ *                           this is its "check agreement" tail :1487-1503
  *   rotation filter      <- the rotHist blocks of those functions + ORBmatcher::ComputeThreeMaxima            :1748-1789
  *   candidate windows    <- Frame::GetFeaturesInArea                                                          src/Frame.cc:200-265
  *
@@ -53,6 +62,9 @@ extern "C" {
 #define ORBS_RULE_INIT      3
 #define ORBS_RULE_BOW       4
 #define ORBS_RULE_FREE      5
+#define ORBS_RULE_TRIANGULATION 6
+
+#define ORBS_MAX_LEVELS 16    /* pyramid levels the epipolar test of ORBS_RULE_TRIANGULATION can address */
 
 #define ORBS_TH_HIGH 100      /* ORBmatcher::TH_HIGH src/ORBmatcher.cc:40 */
 #define ORBS_TH_LOW  50       /* ORBmatcher::TH_LOW  src/ORBmatcher.cc:41 */
@@ -93,6 +105,27 @@ int orbs_list_search_batch_device(const orbs_params* prm, const orbx_keypoint* d
                                   const int32_t* d_qrange, const int32_t* d_qindex, const uint8_t* d_qdesc, const float* d_qangle,
                                   const uint8_t* d_qvalid, const int32_t* d_nq, int qcap, int nproblems,
                                   int32_t* d_q2t, int32_t* d_t2q, int32_t* d_best, int32_t* d_second, int32_t* d_nmatches, void* stream);
+
+/* SearchForTriangulation over the same list form (train = pKF2 staged in its FeatureVector order, query ranges from
+ * orbs_bow_ranges_batch_device, d_qindex = pKF1's fv_feat).  prm->rule must be ORBS_RULE_TRIANGULATION, prm->th = TH_LOW,
+ * prm->ratio unused.  d_F12: 9 floats per problem (row major, `F12.at<float>(r,c)`); level_sigma2: HOST pointer to pKF2's
+ * mvLevelSigma2 (nlevels <= ORBS_MAX_LEVELS).  d_kps1 / d_qdesc / d_qvalid are pKF1's undistorted keypoints, descriptors and
+ * "has no MapPoint yet" flags in feature order (query q uses slot d_qindex[q]); d_claimed marks pKF2's features that already
+ * hold a MapPoint.  Outputs as in orbs_list_search_batch_device: d_q2t[q] = vMatches12[idx1] for query position q; d_best = the
+ * BestDist of the query's candidate list (INT_MAX when empty), d_second = the distance of the match taken (INT_MAX none). */
+int orbs_triangulation_search_batch_device(const orbs_params* prm, const float* d_F12, const float* level_sigma2, int nlevels,
+                                           const orbx_keypoint* d_kps2, const uint8_t* d_desc2, const int32_t* d_list, const int32_t* d_nlist,
+                                           const int32_t* d_nt, int cap, const uint8_t* d_claimed, const int32_t* d_qrange, const int32_t* d_qindex,
+                                           const orbx_keypoint* d_kps1, const uint8_t* d_qdesc, const uint8_t* d_qvalid, const int32_t* d_nq, int qcap,
+                                           int nproblems, int32_t* d_q2t, int32_t* d_t2q, int32_t* d_best, int32_t* d_second, int32_t* d_nmatches,
+                                           void* stream);
+/* The float bound the kernel compares CheckDistEpipolarLine's dsqr with: the smallest float >= 3.84 * (double)sigma2 (host). */
+float orbs_epipolar_bound(float sigma2);
+
+/* SearchBySim3's agreement check: d_out12[i1] = d_match12[i1] when d_match21[d_match12[i1]] == i1, else -1; d_nfound[p] = the
+ * function's return value.  Problem p: d_match12 + p*cap1 (d_n1[p] entries), d_match21 + p*cap2 (d_n2[p] entries). */
+int orbs_agreement_batch_device(const int32_t* d_match12, const int32_t* d_n1, int cap1, const int32_t* d_match21, const int32_t* d_n2, int cap2,
+                                int nproblems, int32_t* d_out12, int32_t* d_nfound, void* stream);
 
 /* SearchByBoW's merge walk (src/ORBmatcher.cc:171-260) as data: for problem p, query position j of the QUERY frame's
  * FeatureVector CSR (node ids d_fvq_node + p*cap, offsets d_fvq_off + p*(cap+1), d_nfv_q[p] nodes) gets the list range of

@@ -11,6 +11,10 @@
 //   rule 3  ORBmatcher::SearchForInitialization(Frame&, Frame&, vector<Point2f>&, vector<int>&, int)   :596-716
 //   rule 5  the scans of ORBmatcher::Fuse :1000-1135 and SearchByProjection(KeyFrame*, Scw, ...) :283-400 (no claims)
 //   ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                        :155-281   (orc_search_by_bow)
+//   ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&)                      :718-850   (orc_search_by_bow_kf)
+//   ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, ...)             :852-1014  (orc_search_for_triangulation)
+//   ORBmatcher::CheckDistEpipolarLine                                                     :136-153   (orc_check_dist_epipolar_line)
+//   ORBmatcher::SearchBySim3 "check agreement"                                            :1487-1503 (orc_sim3_agreement)
 //   ORBmatcher::ComputeThreeMaxima                                                        :1748-1789
 // What stays with the caller (pointer-graph work): which queries are valid (pMP != NULL, !isBad(), mbTrackInView, level
 // bounds), their window centres / radii (projection, RadiusByViewingCos, scale factors) and what a match means
@@ -144,6 +148,157 @@ int orc_search_by_bow(int th, float ratio, int check_orientation,
         }
     }
     return nmatches;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:718-850).
+// valid1[i] / valid2[i] = (pMP != NULL && !pMP->isBad()).  q2t[n1]: the pKF2 feature whose map point vpMatches12[idx1] holds.
+int orc_search_by_bow_kf(int th_low, float ratio, int check_orientation,
+                         const uint32_t* node1, const int32_t* off1, const uint32_t* feat1, int nnodes1,
+                         const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
+                         const uint32_t* node2, const int32_t* off2, const uint32_t* feat2, int nnodes2,
+                         const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2, int32_t* q2t, int32_t* t2q) {
+    for (int i = 0; i < n1; i++) q2t[i] = -1;
+    for (int i = 0; i < n2; i++) t2q[i] = -1;
+    std::vector<char> vbMatched2(n2, 0);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int nmatches = 0, a = 0, b = 0;
+    while (a < nnodes1 && b < nnodes2) {
+        if (node1[a] == node2[b]) {
+            for (int i1 = off1[a]; i1 < off1[a + 1]; i1++) {
+                const unsigned idx1 = feat1[i1];
+                if (!valid1[idx1]) continue;
+                int bestDist1 = INT_MAX, bestIdx2 = -1, bestDist2 = INT_MAX;
+                for (int i2 = off2[b]; i2 < off2[b + 1]; i2++) {
+                    const unsigned idx2 = feat2[i2];
+                    if (vbMatched2[idx2] || !valid2[idx2]) continue;
+                    const int dist = orc_hamming256(desc1 + (size_t)idx1 * 32, desc2 + (size_t)idx2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < th_low) {                                             // strict here (:793)
+                    if ((float)bestDist1 < ratio * (float)bestDist2) {
+                        q2t[idx1] = bestIdx2;
+                        t2q[bestIdx2] = (int)idx1;
+                        vbMatched2[bestIdx2] = 1;
+                        if (check_orientation) rotHist[rot_bin(angle1[idx1], angle2[bestIdx2])].push_back(idx1);
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (node1[a] < node2[b]) {
+            while (a < nnodes1 && node1[a] < node2[b]) a++;
+        } else {
+            while (b < nnodes2 && node2[b] < node1[a]) b++;
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { t2q[q2t[rotHist[i][j]]] = -1; q2t[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+// ORBmatcher::CheckDistEpipolarLine (src/ORBmatcher.cc:136-153); F12 row major 3x3 floats, sigma2 = pKF2->GetSigma2(kp2.octave)
+int orc_check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float* F12, float sigma2) {
+    const float a = x1 * F12[0] + y1 * F12[3] + F12[6];
+    const float b = x1 * F12[1] + y1 * F12[4] + F12[7];
+    const float c = x1 * F12[2] + y1 * F12[5] + F12[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2;
+}
+
+// ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:852-1014) up to vMatches12 (the three output vectors are its compaction).
+// has_mp1 / has_mp2[i] = (vpMapPoints[i] != NULL).  q2t[n1] = vMatches12, t2q[n2] its inverse; best[n1] = BestDist of the
+// query's vDistIndex (INT_MAX empty, -1 never visited), second[n1] = the distance of the match taken (INT_MAX none).
+int orc_search_for_triangulation(int th_low, int check_orientation, const float* F12, const float* level_sigma2,
+                                 const uint32_t* node1, const int32_t* off1, const uint32_t* feat1, int nnodes1,
+                                 const void* kps1_, const uint8_t* desc1, const uint8_t* has_mp1, int n1,
+                                 const uint32_t* node2, const int32_t* off2, const uint32_t* feat2, int nnodes2,
+                                 const void* kps2_, const uint8_t* desc2, const uint8_t* has_mp2, int n2,
+                                 int32_t* q2t, int32_t* t2q, int32_t* best_out, int32_t* second_out) {
+    const KeyPoint* vKeysUn1 = (const KeyPoint*)kps1_;
+    const KeyPoint* vKeysUn2 = (const KeyPoint*)kps2_;
+    int nmatches = 0;
+    std::vector<char> vbMatched2(n2, 0);
+    for (int i = 0; i < n1; i++) { q2t[i] = -1; best_out[i] = -1; second_out[i] = -1; }
+    for (int i = 0; i < n2; i++) t2q[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int a = 0, b = 0;
+    while (a < nnodes1 && b < nnodes2) {
+        if (node1[a] == node2[b]) {
+            for (int i1 = off1[a]; i1 < off1[a + 1]; i1++) {
+                const unsigned idx1 = feat1[i1];
+                if (has_mp1[idx1]) continue;                                          // "If there is already a MapPoint skip"
+                const KeyPoint& kp1 = vKeysUn1[idx1];
+                std::vector<std::pair<int, size_t> > vDistIndex;
+                for (int i2 = off2[b]; i2 < off2[b + 1]; i2++) {
+                    const unsigned idx2 = feat2[i2];
+                    if (vbMatched2[idx2] || has_mp2[idx2]) continue;
+                    const int dist = orc_hamming256(desc1 + (size_t)idx1 * 32, desc2 + (size_t)idx2 * 32);
+                    if (dist > th_low) continue;
+                    vDistIndex.push_back(std::make_pair(dist, (size_t)idx2));
+                }
+                best_out[idx1] = INT_MAX;
+                second_out[idx1] = INT_MAX;
+                if (vDistIndex.empty()) continue;
+                std::sort(vDistIndex.begin(), vDistIndex.end());
+                const int BestDist = vDistIndex.front().first;
+                const int DistTh = (int)round(2 * BestDist);
+                best_out[idx1] = BestDist;
+                for (size_t id = 0; id < vDistIndex.size(); id++) {
+                    if (vDistIndex[id].first > DistTh) break;
+                    const int currentIdx2 = (int)vDistIndex[id].second;
+                    const KeyPoint& kp2 = vKeysUn2[currentIdx2];
+                    if (orc_check_dist_epipolar_line(kp1.x, kp1.y, kp2.x, kp2.y, F12, level_sigma2[kp2.octave])) {
+                        vbMatched2[currentIdx2] = 1;
+                        q2t[idx1] = currentIdx2;
+                        t2q[currentIdx2] = (int)idx1;
+                        second_out[idx1] = vDistIndex[id].first;
+                        nmatches++;
+                        if (check_orientation) rotHist[rot_bin(kp1.angle, kp2.angle)].push_back(idx1);
+                        break;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (node1[a] < node2[b]) {
+            while (a < nnodes1 && node1[a] < node2[b]) a++;
+        } else {
+            while (b < nnodes2 && node2[b] < node1[a]) b++;
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { t2q[q2t[rotHist[i][j]]] = -1; q2t[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+// ORBmatcher::SearchBySim3's agreement check (src/ORBmatcher.cc:1487-1503)
+int orc_sim3_agreement(const int32_t* vnMatch1, int N1, const int32_t* vnMatch2, int N2, int32_t* out12) {
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {
+        out12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            const int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) { out12[i1] = idx2; nFound++; }
+        }
+    }
+    (void)N2;
+    return nFound;
 }
 
 // One search problem.  q2t[nq]: the train feature a query ended up matched to (-1 none); t2q[nt]: the query a train feature

@@ -37,8 +37,8 @@ EXPORTS_F = [
 ]
 # include/orbs.h (greedy grid-window searches)
 EXPORTS_S = ["orbs_lds_bytes", "orbs_three_maxima", "orbs_window_search_batch_device", "orbs_list_search_batch_device",
-             "orbs_bow_ranges_batch_device"]
-RULE_MAPPOINTS, RULE_WINDOW, RULE_BEST, RULE_INIT, RULE_BOW, RULE_FREE = 0, 1, 2, 3, 4, 5
+             "orbs_bow_ranges_batch_device", "orbs_triangulation_search_batch_device", "orbs_epipolar_bound", "orbs_agreement_batch_device"]
+RULE_MAPPOINTS, RULE_WINDOW, RULE_BEST, RULE_INIT, RULE_BOW, RULE_FREE, RULE_TRIANGULATION = 0, 1, 2, 3, 4, 5, 6
 TH_HIGH, TH_LOW = 100, 50
 # include/orbv.h (bag-of-words transform)
 EXPORTS_V = [
@@ -159,6 +159,11 @@ def lib():
         L.orbs_list_search_batch_device.argtypes = [ctypes.POINTER(SearchParams), vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci,
                                                     vp, vp, vp, vp, vp, vp]
         L.orbs_bow_ranges_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]
+        L.orbs_triangulation_search_batch_device.argtypes = [ctypes.POINTER(SearchParams), vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp,
+                                                             vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.orbs_epipolar_bound.argtypes = [ctypes.c_float]
+        L.orbs_epipolar_bound.restype = ctypes.c_float
+        L.orbs_agreement_batch_device.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp]
         L.orbv_create.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, ctypes.POINTER(vp)]
         L.orbv_load_text.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(vp)]
         L.orbv_destroy.argtypes = [vp]
@@ -547,6 +552,29 @@ def list_search_batch_device(rule, th, ratio, check_orientation, d_kps, d_desc, 
                                              d_second or None, d_nmatches, stream or None)
     if rc != ORBX_OK:
         raise OrbxError(rc, "orbs_list_search_batch_device")
+
+
+def triangulation_search_batch_device(th, check_orientation, d_F12, level_sigma2, d_kps2, d_desc2, d_list, d_nlist, d_nt, cap, d_claimed, d_qrange,
+                                      d_qindex, d_kps1, d_qdesc, d_qvalid, d_nq, qcap, nproblems, d_q2t, d_t2q, d_best, d_second, d_nmatches, stream=0):
+    """ORBmatcher::SearchForTriangulation over FeatureVector lists (level_sigma2: host float array = mvLevelSigma2 of pKF2)"""
+    prm = SearchParams(RULE_TRIANGULATION, th, 0.0, 1 if check_orientation else 0)
+    s2 = np.ascontiguousarray(level_sigma2, dtype=np.float32)
+    rc = lib().orbs_triangulation_search_batch_device(ctypes.byref(prm), d_F12, s2.ctypes.data, len(s2), d_kps2, d_desc2, d_list, d_nlist, d_nt, cap,
+                                                      d_claimed or None, d_qrange, d_qindex or None, d_kps1, d_qdesc, d_qvalid or None, d_nq, qcap,
+                                                      nproblems, d_q2t, d_t2q, d_best or None, d_second or None, d_nmatches, stream or None)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbs_triangulation_search_batch_device")
+
+
+def epipolar_bound(sigma2):
+    return float(lib().orbs_epipolar_bound(ctypes.c_float(sigma2)))
+
+
+def agreement_batch_device(d_match12, d_n1, cap1, d_match21, d_n2, cap2, nproblems, d_out12, d_nfound, stream=0):
+    """the "check agreement" tail of ORBmatcher::SearchBySim3"""
+    rc = lib().orbs_agreement_batch_device(d_match12, d_n1, cap1, d_match21, d_n2, cap2, nproblems, d_out12, d_nfound, stream or None)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbs_agreement_batch_device")
 
 
 def bow_ranges_batch_device(d_fvq_node, d_fvq_off, d_nfv_q, d_fvt_node, d_fvt_off, d_nfv_t, cap, nproblems, d_qrange, d_nq, stream=0):

@@ -30,7 +30,7 @@ namespace orbs {
 constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 constexpr int HISTO_LENGTH = 30;             // src/ORBmatcher.cc:42
 
-struct Layout { uint32_t off16, tx, ty, tang, tmeta, tdesc, state, claim, t2q, q2t, binv, hist, total; };
+struct Layout { uint32_t off16, tx, ty, tang, tmeta, tdesc, state, claim, t2q, q2t, binv, hist, epi, total; };
 
 __host__ __device__ inline Layout make_layout(int cap, int qcap) {
     auto al = [](uint32_t x) { return (x + 15u) & ~15u; };
@@ -48,6 +48,7 @@ __host__ __device__ inline Layout make_layout(int cap, int qcap) {
     L.q2t = o; o += al((uint32_t)qcap * 2);
     L.binv = o; o += al((uint32_t)(cap > qcap ? cap : qcap));
     L.hist = o; o += 32 * 4;
+    L.epi = o; o += ORBS_MAX_LEVELS * 4;
     L.total = o;
     return L;
 }
@@ -75,6 +76,10 @@ struct Args {
     const int32_t* nlist;
     const int32_t* qrange;
     const int32_t* qindex;
+    // ORBS_RULE_TRIANGULATION: query keypoints (slot-indexed like qdesc), F12 per problem, the per-octave bound on dsqr
+    const orbx_keypoint* qkps;
+    const float* F12;
+    float epi_thr[ORBS_MAX_LEVELS];
 };
 
 // minimum over the 64 lanes, returned wave-uniform: 4 DPP steps inside each row of 16, then the 4 rows via readlane
@@ -125,7 +130,29 @@ struct Staged {
     const uint32_t* tmeta;
     const uint4* tdesc;
     const uint16_t* state;
+    const float* epi_thr;
 };
+
+// ORBmatcher::CheckDistEpipolarLine (src/ORBmatcher.cc:136-153) split in two: the query's line l = x1' F12 once per query ...
+struct EpiLine { float a, b, c, den; int th; };
+
+__device__ __forceinline__ EpiLine epi_line(float x, float y, const float* F, int th) {
+    EpiLine e;          // every product and sum rounded on its own, as the reference's float expressions are (no fma)
+    e.a = __fadd_rn(__fadd_rn(__fmul_rn(x, F[0]), __fmul_rn(y, F[3])), F[6]);
+    e.b = __fadd_rn(__fadd_rn(__fmul_rn(x, F[1]), __fmul_rn(y, F[4])), F[7]);
+    e.c = __fadd_rn(__fadd_rn(__fmul_rn(x, F[2]), __fmul_rn(y, F[5])), F[8]);
+    e.den = __fadd_rn(__fmul_rn(e.a, e.a), __fmul_rn(e.b, e.b));
+    e.th = th;
+    return e;
+}
+// ... and the distance test per candidate.  thr = the smallest float t with (double)t >= 3.84 * sigma2(octave), so that
+// `dsqr < thr` in float IS the reference's `(double)dsqr < 3.84*sigma2` (host: epi_bound()).
+__device__ __forceinline__ bool epi_ok(const EpiLine& e, float x2, float y2, float thr) {
+    const float num = __fadd_rn(__fadd_rn(__fmul_rn(e.a, x2), __fmul_rn(e.b, y2)), e.c);
+    if (e.den == 0.0f) return false;
+    const float dsqr = __fdiv_rn(__fmul_rn(num, num), e.den);
+    return dsqr < thr;
+}
 
 __device__ __forceinline__ uint32_t hamming_key(const uint4& t0, const uint4& t1, const uint4& q0, const uint4& q1) {
     return __popc(t0.x ^ q0.x) + __popc(t0.y ^ q0.y) + __popc(t0.z ^ q0.z) + __popc(t0.w ^ q0.w) +
@@ -134,9 +161,19 @@ __device__ __forceinline__ uint32_t hamming_key(const uint4& t0, const uint4& t1
 
 // One candidate of a window: its key (distance << 16 | CSR position) when it is admissible under the current claim state,
 // KEY_NONE when it is in the window but claimed; `inwin` says whether it was in the window at all.
+// ORBS_RULE_TRIANGULATION: admissible = unclaimed && distance <= th; bit 15 of the key says whether the candidate also lies on
+// the query's epipolar line (list positions stay below 2^15: the staged frame has to fit the LDS).
 __device__ __forceinline__ uint32_t candidate_key(const Staged& S, int rule, int j, float x, float y, float r, int minLevel, int maxLevel,
-                                                  const uint4& q0, const uint4& q1, bool& inwin) {
+                                                  const uint4& q0, const uint4& q1, const EpiLine& E, bool& inwin) {
     const uint32_t meta = S.tmeta[j];
+    if (rule == ORBS_RULE_TRIANGULATION) {
+        inwin = true;
+        if (S.state[meta & 0xFFFFu]) return KEY_NONE;                               // `if(vbMatched2[idx2] || pMP2) continue;`
+        const uint32_t dist = hamming_key(S.tdesc[2 * j], S.tdesc[2 * j + 1], q0, q1);
+        if ((int)dist > E.th) return KEY_NONE;                                      // `if(dist>TH_LOW) continue;`
+        const uint32_t on_line = epi_ok(E, S.tx[j], S.ty[j], S.epi_thr[min((int)(meta >> 16), ORBS_MAX_LEVELS - 1)]) ? 0x8000u : 0u;
+        return (dist << 16) | on_line | (uint32_t)j;
+    }
     inwin = orbf::in_window(S.tx[j], S.ty[j], (int)(meta >> 16), x, y, r, minLevel, maxLevel);
     if (!inwin) return KEY_NONE;
     const uint32_t st = S.state[meta & 0xFFFFu];
@@ -149,13 +186,14 @@ __device__ __forceinline__ uint32_t candidate_key(const Staged& S, int rule, int
 // The whole wave scans ONE query's window (8 grid columns at a time, 8 lanes per column) under the current claim state and
 // reduces to the two smallest keys: the in-order fallback for queries whose speculative result was overtaken by a claim.
 __device__ __forceinline__ void scan_wave(const Staged& S, int rule, bool list_mode, int lane, int x0, int x1, int y0, int y1, float x, float y, float r,
-                                          int minLevel, int maxLevel, const uint4& q0, const uint4& q1, uint32_t& k1, uint32_t& k2) {
+                                          int minLevel, int maxLevel, const uint4& q0, const uint4& q1, const EpiLine& E, uint32_t& k1, uint32_t& k2) {
     uint32_t a1 = KEY_NONE, a2 = KEY_NONE;
     if (list_mode) {                                   // one explicit run [y0, y1): all 64 lanes stride it
         for (int j = y0 + lane; j < y1; j += 64) {
             bool inwin;
-            const uint32_t key = candidate_key(S, rule, j, x, y, r, minLevel, maxLevel, q0, q1, inwin);
-            a2 = min(a2, max(a1, key));
+            const uint32_t key = candidate_key(S, rule, j, x, y, r, minLevel, maxLevel, q0, q1, E, inwin);
+            if (rule == ORBS_RULE_TRIANGULATION) a2 = min(a2, (key & 0x8000u) ? key : KEY_NONE);      // a2 = best candidate ON the line
+            else a2 = min(a2, max(a1, key));
             a1 = min(a1, key);
         }
         x1 = x0 - 1;
@@ -169,12 +207,13 @@ __device__ __forceinline__ void scan_wave(const Staged& S, int rule, bool list_m
         }
         for (; j < jend; j += 8) {
             bool inwin;
-            const uint32_t key = candidate_key(S, rule, j, x, y, r, minLevel, maxLevel, q0, q1, inwin);
+            const uint32_t key = candidate_key(S, rule, j, x, y, r, minLevel, maxLevel, q0, q1, E, inwin);
             a2 = min(a2, max(a1, key));          // branch-free two-smallest update (a1 <= a2)
             a1 = min(a1, key);
         }
     }
     k1 = wave_min_u32(a1);
+    if (rule == ORBS_RULE_TRIANGULATION) { k2 = wave_min_u32(a2); return; }
     if (a1 == k1) a1 = a2;
     k2 = wave_min_u32(a1);
 }
@@ -188,6 +227,8 @@ __device__ __forceinline__ uint4 lane_u4(const uint4& v, int l) {
 
 // accept rule of the four searches (wave-uniform or per lane alike)
 __device__ __forceinline__ bool accept_rule(const orbs_params& prm, int bestDist, int bestDist2, int bestLevel, int bestLevel2) {
+    if (prm.rule == ORBS_RULE_TRIANGULATION)   // src/ORBmatcher.cc:927-936: bestDist2 = the best candidate ON the epipolar line (INT_MAX none),
+        return bestDist2 != INT_MAX && bestDist2 <= 2 * bestDist;      // taken when it is within DistTh = round(2*BestDist)
     if (prm.rule == ORBS_RULE_MAPPOINTS)       // src/ORBmatcher.cc:114-121
         return bestDist <= prm.th && !(bestLevel == bestLevel2 && (float)bestDist > prm.ratio * (float)bestDist2);
     if (prm.rule == ORBS_RULE_WINDOW)          // :476, :585
@@ -225,7 +266,8 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
     int16_t* q2t = (int16_t*)(lds + L.q2t);
     uint8_t* binv = lds + L.binv;
     int* hist = (int*)(lds + L.hist);
-    const Staged S{off16, tx, ty, tmeta, tdesc, state};
+    float* epi_thr = (float*)(lds + L.epi);
+    const Staged S{off16, tx, ty, tmeta, tdesc, state, epi_thr};
 
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int nt = min(a.nt[p], a.cap), nq = min(a.nq[p], a.qcap);
@@ -256,9 +298,16 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
         claim_by[i] = 0;
     }
     for (int i = tid; i < nq; i += GROUP) q2t[i] = -1;
-    const int nbin = rule == ORBS_RULE_INIT ? nq : nt;
+    const bool tri = rule == ORBS_RULE_TRIANGULATION;
+    const bool bin_by_query = rule == ORBS_RULE_INIT || tri;       // rotHist holds i1 / idx1 there, the train index elsewhere
+    const uint32_t pos_mask = tri ? 0x7FFFu : 0xFFFFu;             // list position inside a key
+    const int nbin = bin_by_query ? nq : nt;
     for (int i = tid; i < nbin; i += GROUP) binv[i] = 255;
     if (tid < 32) hist[tid] = 0;
+#pragma unroll
+    for (int i = 0; i < ORBS_MAX_LEVELS; ++i) if (tid == i) epi_thr[i] = a.epi_thr[i];
+    float F[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (tri) for (int i = 0; i < 9; ++i) F[i] = a.F12[(size_t)p * 9 + i];
     __syncthreads();
 
     const bool rot_on = (prm.check_orientation & 1) != 0 && rule != ORBS_RULE_MAPPOINTS && rule != ORBS_RULE_FREE;
@@ -279,12 +328,14 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
             }
             qv = a.qvalid ? (a.qvalid[qs] != 0) : 1;
             if (a.qangle) qa = a.qangle[qs];
+            if (tri) { const orbx_keypoint kp1 = a.qkps[qs]; qx = kp1.x; qy = kp1.y; qa = kp1.angle; }
             const uint4* d = (const uint4*)(a.qdesc + qs * 32);
             qd0 = d[0];
             qd1 = d[1];
         }
         // ---- (1) speculative scan of the lane's own query: four smallest keys e0 <= e1 <= e2 <= e3
         int wx0 = 0, wx1 = -1, wy0 = 0, wy1 = 0;
+        const EpiLine E = epi_line(qx, qy, F, prm.th);
         if (list_mode) {
             // one run of list positions; no geometric test (an infinite box on every level)
             qr = INFINITY; ql0 = -1; ql1 = -1;
@@ -297,7 +348,7 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
             const int jend = list_mode ? wy1 : off16[col * ORBF_GRID_ROWS + wy1 + 1];
             for (int j = list_mode ? wy0 : off16[col * ORBF_GRID_ROWS + wy0]; j < jend; ++j) {
                 bool inwin;
-                uint32_t t = candidate_key(S, rule, j, qx, qy, qr, ql0, ql1, qd0, qd1, inwin);
+                uint32_t t = candidate_key(S, rule, j, qx, qy, qr, ql0, ql1, qd0, qd1, E, inwin);
                 any |= inwin;
                 uint32_t lo;
                 lo = min(e0, t); t = max(e0, t); e0 = lo;
@@ -307,8 +358,9 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
             }
         }
         // train index | octave << 16 of the four entries
-        const uint32_t f0 = e0 != KEY_NONE ? tmeta[e0 & 0xFFFFu] : 0u, f1 = e1 != KEY_NONE ? tmeta[e1 & 0xFFFFu] : 0u;
-        const uint32_t f2 = e2 != KEY_NONE ? tmeta[e2 & 0xFFFFu] : 0u, f3 = e3 != KEY_NONE ? tmeta[e3 & 0xFFFFu] : 0u;
+        const uint32_t f0 = e0 != KEY_NONE ? tmeta[e0 & pos_mask] : 0u, f1 = e1 != KEY_NONE ? tmeta[e1 & pos_mask] : 0u;
+        const uint32_t f2 = e2 != KEY_NONE ? tmeta[e2 & pos_mask] : 0u, f3 = e3 != KEY_NONE ? tmeta[e3 & pos_mask] : 0u;
+        const uint32_t on_line = tri ? ((e0 >> 15) & 1u) | ((e1 >> 14) & 2u) | ((e2 >> 13) & 4u) | ((e3 >> 12) & 8u) : 0u;
         const bool full = e3 != KEY_NONE;              // a fifth candidate may exist
         int my_best = -1, my_second = -1;
         __syncthreads();
@@ -332,22 +384,26 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
                         if (e3 != KEY_NONE && state[f3 & 0xFFFFu] == 0) alive |= 8u;
                     }
                     // current best / second = first two alive entries
+                    // (TRIANGULATION: "second" = the first alive entry ON the epipolar line — possibly the best itself)
                     const int ib = alive ? (__ffs((int)alive) - 1) : 4;
-                    const uint32_t rest = alive & ~(1u << (ib & 3));
-                    const int is = (alive && rest) ? (__ffs((int)rest) - 1) : 4;
+                    const uint32_t rest = tri ? (alive & on_line) : (alive & ~(1u << (ib & 3)));
+                    const int is = rest ? (__ffs((int)rest) - 1) : 4;
                     const uint32_t kb = ib == 0 ? e0 : ib == 1 ? e1 : ib == 2 ? e2 : ib == 3 ? e3 : KEY_NONE;
                     const uint32_t mb = ib == 0 ? f0 : ib == 1 ? f1 : ib == 2 ? f2 : f3;
-                    const uint32_t ks = is == 1 ? e1 : is == 2 ? e2 : is == 3 ? e3 : KEY_NONE;
-                    const uint32_t ms = is == 1 ? f1 : is == 2 ? f2 : f3;
+                    const uint32_t ks = is == 0 ? e0 : is == 1 ? e1 : is == 2 ? e2 : is == 3 ? e3 : KEY_NONE;
+                    const uint32_t ms = is == 0 ? f0 : is == 1 ? f1 : is == 2 ? f2 : f3;
                     const int vBest = kb != KEY_NONE ? (int)(kb >> 16) : INT_MAX, vBest2 = ks != KEY_NONE ? (int)(ks >> 16) : INT_MAX;
                     const int vLev = kb != KEY_NONE ? (int)(mb >> 16) : -1, vLev2 = ks != KEY_NONE ? (int)(ms >> 16) : -1;
                     const bool active = any && lane >= cursor;
-                    const bool dry = full && __popc(alive) < 2;                // list exhausted: the exact answer needs a rescan
+                    // list exhausted: the exact answer needs a rescan.  TRIANGULATION: no alive on-line entry left, and a fifth
+                    // candidate could still lie within DistTh (it has distance >= e3's)
+                    const bool dry = tri ? (full && is == 4 && (ib == 4 || (int)(e3 >> 16) <= 2 * vBest)) : (full && __popc(alive) < 2);
                     const bool vAccept = !dry && accept_rule(prm, vBest, vBest2, vLev, vLev2);
                     // accepting lanes post their claim; the earliest lane of this round wins the slot
                     const uint32_t stamp = (uint32_t)((group * (GROUP / 64) + w) * 128 + round + 1);
                     const uint32_t bIdx = mb & 0xFFFFu, sIdx = ms & 0xFFFFu;
-                    if (claims && active && vAccept) atomicMax(&claim_by[bIdx], (stamp << 6) | (uint32_t)(63 - lane));
+                    const uint32_t cIdx = tri ? sIdx : bIdx, kc = tri ? ks : kb;        // what an accepting query takes
+                    if (claims && active && vAccept) atomicMax(&claim_by[cIdx], (stamp << 6) | (uint32_t)(63 - lane));
                     bool affected = false;
                     if (claims && active && kb != KEY_NONE) { const uint32_t c = claim_by[bIdx]; affected |= (c >> 6) == stamp && (int)(63u - (c & 63u)) < lane; }
                     if (claims && active && ks != KEY_NONE) { const uint32_t c = claim_by[sIdx]; affected |= (c >> 6) == stamp && (int)(63u - (c & 63u)) < lane; }
@@ -356,22 +412,22 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
                     // every lane before F is final: record, and commit its own claim
                     if (active && lane < F) {
                         my_best = vBest;
-                        my_second = vBest2;
+                        my_second = tri ? (vAccept ? vBest2 : INT_MAX) : vBest2;
                         if (vAccept) {
                             const int q = q0 + w * 64 + lane;
                             int bin = 255;
-                            if (rot_on) bin = rot_bin(qa, tang[kb & 0xFFFFu]);
+                            if (rot_on) bin = rot_bin(qa, tang[kc & pos_mask]);
                             if (rule == ORBS_RULE_INIT) {
                                 const int prev = t2q[bIdx];
                                 if (prev >= 0) q2t[prev] = -1;                 // vnMatches12[vnMatches21[bestIdx2]] = -1
                                 state[bIdx] = (uint16_t)vBest;                 // vMatchedDistance[bestIdx2] = bestDist
                                 binv[q] = (uint8_t)bin;                        // rotHist[bin].push_back(i1)
                             } else if (claims) {
-                                state[bIdx] = 1;
-                                binv[bIdx] = (uint8_t)bin;                     // rotHist[bin].push_back(bestIdx2)
+                                state[cIdx] = 1;
+                                binv[tri ? (uint32_t)q : cIdx] = (uint8_t)bin; // rotHist[bin].push_back(bestIdx2)  (TRIANGULATION: idx1)
                             }
-                            q2t[q] = (int16_t)bIdx;
-                            if (claims) t2q[bIdx] = (int16_t)q;
+                            q2t[q] = (int16_t)cIdx;
+                            if (claims) t2q[cIdx] = (int16_t)q;
                         }
                     }
                     cursor = F;
@@ -381,16 +437,17 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
                         uint32_t k1, k2;
                         scan_wave(S, rule, list_mode, lane, __builtin_amdgcn_readlane(wx0, F), __builtin_amdgcn_readlane(wx1, F), __builtin_amdgcn_readlane(wy0, F),
                                   __builtin_amdgcn_readlane(wy1, F), lane_f(qx, F), lane_f(qy, F), lane_f(qr, F), __builtin_amdgcn_readlane(ql0, F),
-                                  __builtin_amdgcn_readlane(ql1, F), lane_u4(qd0, F), lane_u4(qd1, F), k1, k2);
-                        const uint32_t m1 = k1 != KEY_NONE ? tmeta[k1 & 0xFFFFu] : 0u, m2 = k2 != KEY_NONE ? tmeta[k2 & 0xFFFFu] : 0u;
+                                  __builtin_amdgcn_readlane(ql1, F), lane_u4(qd0, F), lane_u4(qd1, F),
+                                  EpiLine{lane_f(E.a, F), lane_f(E.b, F), lane_f(E.c, F), lane_f(E.den, F), prm.th}, k1, k2);
+                        const uint32_t m1 = k1 != KEY_NONE ? tmeta[k1 & pos_mask] : 0u, m2 = k2 != KEY_NONE ? tmeta[k2 & pos_mask] : 0u;
                         const int bestDist = k1 != KEY_NONE ? (int)(k1 >> 16) : INT_MAX, bestDist2 = k2 != KEY_NONE ? (int)(k2 >> 16) : INT_MAX;
-                        const int bestIdx = (int)(m1 & 0xFFFFu);
+                        const int bestIdx = (int)((tri ? m2 : m1) & 0xFFFFu);
                         const bool accept = accept_rule(prm, bestDist, bestDist2, k1 != KEY_NONE ? (int)(m1 >> 16) : -1, k2 != KEY_NONE ? (int)(m2 >> 16) : -1);
-                        if (lane == F) { my_best = bestDist; my_second = bestDist2; }
+                        if (lane == F) { my_best = bestDist; my_second = tri ? (accept ? bestDist2 : INT_MAX) : bestDist2; }
                         if (accept) {
                             const int q = q0 + w * 64 + F;
                             int bin = 255;
-                            if (rot_on) bin = rot_bin(lane_f(qa, F), tang[k1 & 0xFFFFu]);
+                            if (rot_on) bin = rot_bin(lane_f(qa, F), tang[(tri ? k2 : k1) & pos_mask]);
                             if (lane == 0) {
                                 if (rule == ORBS_RULE_INIT) {
                                     const int prev = t2q[bestIdx];
@@ -399,7 +456,7 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
                                     binv[q] = (uint8_t)bin;
                                 } else {
                                     state[bestIdx] = 1;
-                                    binv[bestIdx] = (uint8_t)bin;
+                                    binv[tri ? q : bestIdx] = (uint8_t)bin;
                                 }
                                 q2t[q] = (int16_t)bestIdx;
                                 t2q[bestIdx] = (int16_t)q;
@@ -426,7 +483,7 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
         for (int i = tid; i < nbin; i += GROUP) {
             const int bn = binv[i];
             if (bn == 255 || bn == i1 || bn == i2 || bn == i3) continue;
-            if (rule == ORBS_RULE_INIT) {
+            if (bin_by_query) {
                 const int t = q2t[i];
                 if (t >= 0) { t2q[t] = -1; q2t[i] = -1; }
             } else {
@@ -469,6 +526,27 @@ __global__ __launch_bounds__(256) void k_bow_ranges(const uint32_t* __restrict__
     }
 }
 
+// The "check agreement" tail of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1487-1503): keep i1 -> idx2 only when idx2 -> i1.
+__global__ __launch_bounds__(256) void k_agreement(const int32_t* __restrict__ m12, const int32_t* __restrict__ n1, int cap1,
+                                                  const int32_t* __restrict__ m21, const int32_t* __restrict__ n2, int cap2,
+                                                  int32_t* __restrict__ out12, int32_t* __restrict__ nfound) {
+    __shared__ int total;
+    const int p = blockIdx.x, N1 = min(n1[p], cap1), N2 = min(n2[p], cap2);
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int i1 = threadIdx.x; i1 < N1; i1 += 256) {
+        const int idx2 = m12[(size_t)p * cap1 + i1];
+        const bool ok = idx2 >= 0 && idx2 < N2 && m21[(size_t)p * cap2 + idx2] == i1;
+        out12[(size_t)p * cap1 + i1] = ok ? idx2 : -1;
+        cnt += ok;
+    }
+    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&total, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) nfound[p] = total;
+}
+
 }  // namespace orbs
 
 // the kernel may use up to the whole 160 KiB of LDS: raise the dynamic-LDS limit once per process (per device context)
@@ -486,6 +564,13 @@ extern "C" {
 size_t orbs_lds_bytes(int cap, int qcap) {
     if (cap < 1 || qcap < 1) return 0;
     return orbs::make_layout(cap, qcap).total;
+}
+
+float orbs_epipolar_bound(float sigma2) {
+    const double T = 3.84 * (double)sigma2;          // `dsqr<3.84*pKF2->GetSigma2(kp2.octave)`: float < double, compared in double
+    float t = (float)T;
+    if ((double)t < T) t = nextafterf(t, INFINITY);   // the smallest float >= T: for a float d, d < t  <=>  (double)d < T
+    return t;
 }
 
 void orbs_three_maxima(const int32_t* sizes, int L, int32_t* ind) {
@@ -512,7 +597,7 @@ int orbs_window_search_batch_device(const orbf_bounds* b, const orbs_params* prm
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
     if (const char* e = getenv("ORBS_DBG")) prm2.check_orientation |= atoi(e) << 8;
     orbs::Args a{d_kps_un, d_desc, d_cell_off, d_cell_feat, d_nt, d_claimed, d_qxyr, d_qlev, d_qdesc, d_qangle, d_qvalid, d_nq,
-                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, nullptr, nullptr, nullptr};
+                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
     hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, *b, prm2, a);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
@@ -534,9 +619,43 @@ int orbs_list_search_batch_device(const orbs_params* prm, const orbx_keypoint* d
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
     if (const char* e = getenv("ORBS_DBG")) prm2.check_orientation |= atoi(e) << 8;
     orbs::Args a{d_kps, d_desc, nullptr, d_list, d_nt, d_claimed, nullptr, nullptr, d_qdesc, d_qangle, d_qvalid, d_nq,
-                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, d_nlist, d_qrange, d_qindex};
+                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, d_nlist, d_qrange, d_qindex, nullptr, nullptr, {}};
     orbf_bounds nob{};
     hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, nob, prm2, a);
+    return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbs_triangulation_search_batch_device(const orbs_params* prm, const float* d_F12, const float* level_sigma2, int nlevels,
+                                           const orbx_keypoint* d_kps2, const uint8_t* d_desc2, const int32_t* d_list, const int32_t* d_nlist,
+                                           const int32_t* d_nt, int cap, const uint8_t* d_claimed, const int32_t* d_qrange, const int32_t* d_qindex,
+                                           const orbx_keypoint* d_kps1, const uint8_t* d_qdesc, const uint8_t* d_qvalid, const int32_t* d_nq, int qcap,
+                                           int nproblems, int32_t* d_q2t, int32_t* d_t2q, int32_t* d_best, int32_t* d_second, int32_t* d_nmatches,
+                                           void* stream) {
+    if (!prm || nproblems < 0 || cap < 1 || cap > ORBF_MAX_FEATURES || qcap < 1 || qcap > ORBF_MAX_FEATURES) return ORBX_ERR_ARG;
+    if (prm->rule != ORBS_RULE_TRIANGULATION || !level_sigma2 || nlevels < 1 || nlevels > ORBS_MAX_LEVELS || prm->th < 0 || prm->th > 256) return ORBX_ERR_ARG;
+    if (nproblems == 0) return ORBX_OK;
+    if (!d_F12 || !d_kps2 || !d_desc2 || !d_list || !d_nlist || !d_nt || !d_qrange || !d_kps1 || !d_qdesc || !d_nq || !d_q2t || !d_t2q || !d_nmatches)
+        return ORBX_ERR_ARG;
+    const size_t lds = orbs::make_layout(cap, qcap).total;
+    if (lds > 160 * 1024) return ORBX_ERR_CAPACITY;
+    if (orbs_set_lds(lds) != ORBX_OK) return ORBX_ERR_DEVICE;
+    orbs_params prm2 = *prm;
+    prm2.check_orientation = prm->check_orientation ? 1 : 0;
+    if (const char* e = getenv("ORBS_DBG")) prm2.check_orientation |= atoi(e) << 8;
+    orbs::Args a{d_kps2, d_desc2, nullptr, d_list, d_nt, d_claimed, nullptr, nullptr, d_qdesc, nullptr, d_qvalid, d_nq,
+                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, d_nlist, d_qrange, d_qindex, d_kps1, d_F12, {}};
+    for (int i = 0; i < ORBS_MAX_LEVELS; ++i) a.epi_thr[i] = orbs_epipolar_bound(level_sigma2[i < nlevels ? i : nlevels - 1]);
+    orbf_bounds nob{};
+    hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, nob, prm2, a);
+    return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbs_agreement_batch_device(const int32_t* d_match12, const int32_t* d_n1, int cap1, const int32_t* d_match21, const int32_t* d_n2, int cap2,
+                                int nproblems, int32_t* d_out12, int32_t* d_nfound, void* stream) {
+    if (nproblems < 0 || cap1 < 1 || cap2 < 1) return ORBX_ERR_ARG;
+    if (nproblems == 0) return ORBX_OK;
+    if (!d_match12 || !d_n1 || !d_match21 || !d_n2 || !d_out12 || !d_nfound) return ORBX_ERR_ARG;
+    hipLaunchKernelGGL(orbs::k_agreement, dim3(nproblems), dim3(256), 0, (hipStream_t)stream, d_match12, d_n1, cap1, d_match21, d_n2, cap2, d_out12, d_nfound);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
 

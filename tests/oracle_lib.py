@@ -59,6 +59,10 @@ def lib():
         L.orc_search_by_bow.argtypes = [c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
         L.orc_distinctive.argtypes = [c_void_p, c_int, c_void_p]
+        L.orc_search_by_bow_kf.argtypes = [c_int, c_float, c_int] + [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int] * 2 + [c_void_p, c_void_p]
+        L.orc_check_dist_epipolar_line.argtypes = [c_float, c_float, c_float, c_float, c_void_p, c_float]
+        L.orc_search_for_triangulation.argtypes = [c_int, c_int, c_void_p, c_void_p] + [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int] * 2 + [c_void_p] * 4
+        L.orc_sim3_agreement.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p]
         L.orc_three_maxima.argtypes = [c_void_p, c_int, c_void_p]
         L.orc_window_search.argtypes = [c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
@@ -425,3 +429,51 @@ def search_by_bow(th, ratio, check_orientation, kf_fv, kf_desc, kf_angle, kf_val
                                 ka.ctypes.data, kv.ctypes.data, nK, fn.ctypes.data, fo.ctypes.data, ff.ctypes.data, len(fn), fd.ctypes.data, fa.ctypes.data, nF,
                                 q2t.ctypes.data, t2q.ctypes.data, best.ctypes.data, second.ctypes.data)
     return n, q2t[:nK], t2q[:nF], best[:nK], second[:nK]
+
+
+def _fv(fv):
+    return (np.ascontiguousarray(fv[0], dtype=np.uint32), np.ascontiguousarray(fv[1], dtype=np.int32), np.ascontiguousarray(fv[2], dtype=np.uint32))
+
+
+def search_by_bow_kf(th_low, ratio, check_orientation, fv1, desc1, angle1, valid1, fv2, desc2, angle2, valid2):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...) -> (nmatches, q2t[n1], t2q[n2])"""
+    n1_, o1, f1 = _fv(fv1); n2_, o2, f2 = _fv(fv2)
+    d1 = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 32)
+    a1 = np.ascontiguousarray(angle1, dtype=np.float32); a2 = np.ascontiguousarray(angle2, dtype=np.float32)
+    v1 = np.ascontiguousarray(valid1, dtype=np.uint8); v2 = np.ascontiguousarray(valid2, dtype=np.uint8)
+    N1, N2 = len(d1), len(d2)
+    q2t = np.zeros(max(N1, 1), np.int32); t2q = np.zeros(max(N2, 1), np.int32)
+    n = lib().orc_search_by_bow_kf(th_low, ctypes.c_float(ratio), 1 if check_orientation else 0, n1_.ctypes.data, o1.ctypes.data, f1.ctypes.data, len(n1_),
+                                   d1.ctypes.data, a1.ctypes.data, v1.ctypes.data, N1, n2_.ctypes.data, o2.ctypes.data, f2.ctypes.data, len(n2_),
+                                   d2.ctypes.data, a2.ctypes.data, v2.ctypes.data, N2, q2t.ctypes.data, t2q.ctypes.data)
+    return n, q2t[:N1], t2q[:N2]
+
+
+def check_dist_epipolar_line(x1, y1, x2, y2, F12, sigma2):
+    F = np.ascontiguousarray(F12, dtype=np.float32).reshape(9)
+    f = ctypes.c_float
+    return bool(lib().orc_check_dist_epipolar_line(f(x1), f(y1), f(x2), f(y2), F.ctypes.data, f(sigma2)))
+
+
+def search_for_triangulation(th_low, check_orientation, F12, level_sigma2, fv1, kps1, desc1, has_mp1, fv2, kps2, desc2, has_mp2):
+    """ORBmatcher::SearchForTriangulation -> (nmatches, q2t[n1] (= vMatches12), t2q[n2], best[n1], second[n1])"""
+    n1_, o1, f1 = _fv(fv1); n2_, o2, f2 = _fv(fv2)
+    F = np.ascontiguousarray(F12, dtype=np.float32).reshape(9)
+    s2 = np.ascontiguousarray(level_sigma2, dtype=np.float32)
+    k1 = np.ascontiguousarray(kps1); k2 = np.ascontiguousarray(kps2)
+    d1 = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 32)
+    m1 = np.ascontiguousarray(has_mp1, dtype=np.uint8); m2 = np.ascontiguousarray(has_mp2, dtype=np.uint8)
+    N1, N2 = len(d1), len(d2)
+    q2t = np.zeros(max(N1, 1), np.int32); t2q = np.zeros(max(N2, 1), np.int32); best = np.zeros(max(N1, 1), np.int32); second = np.zeros(max(N1, 1), np.int32)
+    n = lib().orc_search_for_triangulation(th_low, 1 if check_orientation else 0, F.ctypes.data, s2.ctypes.data, n1_.ctypes.data, o1.ctypes.data, f1.ctypes.data,
+                                           len(n1_), k1.ctypes.data, d1.ctypes.data, m1.ctypes.data, N1, n2_.ctypes.data, o2.ctypes.data, f2.ctypes.data,
+                                           len(n2_), k2.ctypes.data, d2.ctypes.data, m2.ctypes.data, N2, q2t.ctypes.data, t2q.ctypes.data, best.ctypes.data,
+                                           second.ctypes.data)
+    return n, q2t[:N1], t2q[:N2], best[:N1], second[:N1]
+
+
+def sim3_agreement(m12, m21):
+    a = np.ascontiguousarray(m12, dtype=np.int32); b = np.ascontiguousarray(m21, dtype=np.int32)
+    out = np.zeros(max(len(a), 1), np.int32)
+    n = lib().orc_sim3_agreement(a.ctypes.data, len(a), b.ctypes.data, len(b), out.ctypes.data)
+    return n, out[:len(a)]
