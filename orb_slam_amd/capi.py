@@ -411,7 +411,10 @@ class ORBVocabulary:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except TypeError:           # interpreter shutdown: module globals are already gone
+            pass
 
     def info(self):
         vals = [ctypes.c_int() for _ in range(6)]
