@@ -18,20 +18,20 @@
  *   ORBS_RULE_BOW        <- int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                 :155-281
  *                           (candidates = the features of the same vocabulary node instead of a grid window:
  *                           orbs_bow_ranges_batch_device + orbs_list_search_batch_device; accept best <= th && best < ratio*second)
- *                           int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&)              :718-850
+ *                           int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&)              :715-850
  *                           (the same with d_claimed = "pMP2 is NULL or bad" and th = TH_LOW - 1: that function tests `bestDist1<TH_LOW`)
  *   ORBS_RULE_TRIANGULATION <- int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, ...)  :852-1014
  *                           with ORBmatcher::CheckDistEpipolarLine :136-153 (orbs_triangulation_search_batch_device: candidates of the
  *                           same vocabulary node with distance <= th, sorted by (distance, index); the first one within
  *                           2 x the best distance that lies on the query's epipolar line is taken)
  *   ORBS_RULE_FREE       <- the searches WITHOUT the "already matched" masking, every query independent: the scan of
- *                           int ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, float th)                       :1000-1135
- *                           int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, ..., int th)             :283-400
+ *                           int ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, float th)                       :1016-1134
+ *                           int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, ..., int th)             :286-407
  *                           (window + level range, best distance only, accept best <= th; several queries may end on the same
  *                           feature, so d_t2q is not produced (all -1) and there is no rotation check)
  *   orbs_agreement_batch_device <- the two scans of int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, vector<MapPoint*>&, s12, R12, t12, th)
- *                           :1258-1506 are two ORBS_RULE_FREE searches (window + levels [predicted-1, predicted], best <= TH_HIGH);
- *                           this is its "check agreement" tail :1487-1503
+ *                           :1267-1505 are two ORBS_RULE_FREE searches (window + levels [predicted-1, predicted], best <= TH_HIGH);
+ *                           this is its "check agreement" tail :1486-1505
  *   rotation filter      <- the rotHist blocks of those functions + ORBmatcher::ComputeThreeMaxima            :1748-1789
  *   candidate windows    <- Frame::GetFeaturesInArea                                                          src/Frame.cc:200-265
  *

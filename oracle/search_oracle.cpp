@@ -9,12 +9,12 @@
 //           ORBmatcher::SearchByProjection(Frame&, Frame&, int, vector<MapPoint*>&)       :519-594 (no rotation check)
 //   rule 2  ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, float)      :1508-1619
 //   rule 3  ORBmatcher::SearchForInitialization(Frame&, Frame&, vector<Point2f>&, vector<int>&, int)   :596-716
-//   rule 5  the scans of ORBmatcher::Fuse :1000-1135 and SearchByProjection(KeyFrame*, Scw, ...) :283-400 (no claims)
+//   rule 5  the scans of ORBmatcher::Fuse :1016-1134 and SearchByProjection(KeyFrame*, Scw, ...) :286-407 (no claims)
 //   ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                        :155-281   (orc_search_by_bow)
-//   ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&)                      :718-850   (orc_search_by_bow_kf)
+//   ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&)                      :715-850   (orc_search_by_bow_kf)
 //   ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, ...)             :852-1014  (orc_search_for_triangulation)
 //   ORBmatcher::CheckDistEpipolarLine                                                     :136-153   (orc_check_dist_epipolar_line)
-//   ORBmatcher::SearchBySim3 "check agreement"                                            :1487-1503 (orc_sim3_agreement)
+//   ORBmatcher::SearchBySim3 "check agreement"                                            :1486-1505 (orc_sim3_agreement)
 //   ORBmatcher::ComputeThreeMaxima                                                        :1748-1789
 // What stays with the caller (pointer-graph work): which queries are valid (pMP != NULL, !isBad(), mbTrackInView, level
 // bounds), their window centres / radii (projection, RadiusByViewingCos, scale factors) and what a match means
@@ -150,7 +150,7 @@ int orc_search_by_bow(int th, float ratio, int check_orientation,
     return nmatches;
 }
 
-// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:718-850).
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:715-850).
 // valid1[i] / valid2[i] = (pMP != NULL && !pMP->isBad()).  q2t[n1]: the pKF2 feature whose map point vpMatches12[idx1] holds.
 int orc_search_by_bow_kf(int th_low, float ratio, int check_orientation,
                          const uint32_t* node1, const int32_t* off1, const uint32_t* feat1, int nnodes1,
@@ -286,7 +286,7 @@ int orc_search_for_triangulation(int th_low, int check_orientation, const float*
     return nmatches;
 }
 
-// ORBmatcher::SearchBySim3's agreement check (src/ORBmatcher.cc:1487-1503)
+// ORBmatcher::SearchBySim3's agreement check (src/ORBmatcher.cc:1486-1505)
 int orc_sim3_agreement(const int32_t* vnMatch1, int N1, const int32_t* vnMatch2, int N2, int32_t* out12) {
     int nFound = 0;
     for (int i1 = 0; i1 < N1; i1++) {

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void k_bow_ranges(const uint32_t* __restrict__
     }
 }
 
-// The "check agreement" tail of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1487-1503): keep i1 -> idx2 only when idx2 -> i1.
+// The "check agreement" tail of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1486-1505): keep i1 -> idx2 only when idx2 -> i1.
 __global__ __launch_bounds__(256) void k_agreement(const int32_t* __restrict__ m12, const int32_t* __restrict__ n1, int cap1,
                                                   const int32_t* __restrict__ m21, const int32_t* __restrict__ n2, int cap2,
                                                   int32_t* __restrict__ out12, int32_t* __restrict__ nfound) {

@@ -13,6 +13,7 @@ timeout 400 python bench.py --width 1920 --height 1080 --nfeatures 2000 --batch 
 timeout 300 python bench.py --family 0 --no-cpu-baseline > $D/bench_noise.json 2>/dev/null
 timeout 200 python tools/bench_match.py > $D/match100k.txt 2>/dev/null
 (timeout 100 python tools/bench_single_frame.py; timeout 100 python tools/bench_single_frame.py 1920 1080 2000) > $D/single_frame.txt 2>/dev/null
+timeout 200 python tools/bench_kf_search.py 2>/dev/null | tail -1 > $D/kf_search.json
 timeout 300 python tools/bench_frontend.py --window 15 2>/dev/null | tail -1 > $D/frontend_w15.json
 timeout 300 python tools/bench_frontend.py 2>/dev/null | tail -1 > $D/frontend_w100.json
 ls $D | wc -l
