@@ -5,102 +5,36 @@ in-order search."""
 import numpy as np
 import pytest
 
+import kf_device as kd
 import kf_pairs
 import oracle_lib as ol
-from orb_slam_amd import capi, synth
+from orb_slam_amd import capi
 
 pytestmark = pytest.mark.gpu
 
 
-def _device_feature_vectors(torch, V, D, n, P, cap, levelsup, st):
-    i32, f64 = torch.int32, torch.float64
-    dD, dn = torch.from_numpy(D).cuda(), torch.from_numpy(n).cuda()
-    o = dict(bid=torch.zeros((P, cap), dtype=i32, device="cuda"), bval=torch.zeros((P, cap), dtype=f64, device="cuda"),
-             node=torch.zeros((P, cap), dtype=i32, device="cuda"), off=torch.zeros((P, cap + 1), dtype=i32, device="cuda"),
-             feat=torch.zeros((P, cap), dtype=i32, device="cuda"), cnt=torch.zeros((2, P), dtype=i32, device="cuda"), D=dD, n=dn)
-    V.transform_batch_device(dD.data_ptr(), dn.data_ptr(), P, cap, levelsup, o["bid"].data_ptr(), o["bval"].data_ptr(), o["cnt"][0].data_ptr(),
-                             o["node"].data_ptr(), o["off"].data_ptr(), o["feat"].data_ptr(), o["cnt"][1].data_ptr(), st)
-    return o
-
-
-def _host_fv(o, i):
-    node, off, feat, cnt = (o[x].cpu().numpy() for x in ("node", "off", "feat", "cnt"))
-    nn = cnt[1, i]
-    return node[i, :nn].view(np.uint32), off[i, :nn + 1], feat[i, :off[i, nn]].view(np.uint32)
-
-
-def _setup(pairs, cap, seed_voc=6, k=10, L=4, levelsup=2):
-    torch = pytest.importorskip("torch")
-    P = len(pairs)
-    voc = synth.vocabulary(k, L, seed=seed_voc)
-    V = capi.ORBVocabulary.from_nodes(k, L, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
-    n1 = np.array([len(p["d1"]) for p in pairs], np.int32); n2 = np.array([len(p["d2"]) for p in pairs], np.int32)
-    D1 = np.zeros((P, cap, 32), np.uint8); D2 = np.zeros((P, cap, 32), np.uint8)
-    K1 = np.zeros((P, cap), dtype=capi.KP_DTYPE); K2 = np.zeros((P, cap), dtype=capi.KP_DTYPE)
-    M1 = np.zeros((P, cap), np.uint8); M2 = np.zeros((P, cap), np.uint8)
-    Fm = np.zeros((P, 9), np.float32)
-    for i, p in enumerate(pairs):
-        D1[i, :n1[i]] = p["d1"]; D2[i, :n2[i]] = p["d2"]; K1[i, :n1[i]] = p["k1"]; K2[i, :n2[i]] = p["k2"]
-        M1[i, :n1[i]] = p["mp1"]; M2[i, :n2[i]] = p["mp2"]; Fm[i] = p["F"].reshape(9)
-    st = torch.cuda.current_stream().cuda_stream
-    A = _device_feature_vectors(torch, V, D1, n1, P, cap, levelsup, st)
-    B = _device_feature_vectors(torch, V, D2, n2, P, cap, levelsup, st)
-    qrange = torch.zeros((P, cap, 2), dtype=torch.int32, device="cuda")
-    nq = torch.zeros(P, dtype=torch.int32, device="cuda")
-    capi.bow_ranges_batch_device(A["node"].data_ptr(), A["off"].data_ptr(), A["cnt"][1].data_ptr(), B["node"].data_ptr(), B["off"].data_ptr(),
-                                 B["cnt"][1].data_ptr(), cap, P, qrange.data_ptr(), nq.data_ptr(), st)
-    torch.cuda.synchronize()
-    b_off, b_cnt = B["off"].cpu().numpy(), B["cnt"].cpu().numpy()
-    nlist = torch.from_numpy(np.array([b_off[i, b_cnt[1, i]] for i in range(P)], np.int32)).cuda()
-    dK1 = torch.from_numpy(K1.view(np.uint8).reshape(P, cap, 28)).cuda(); dK2 = torch.from_numpy(K2.view(np.uint8).reshape(P, cap, 28)).cuda()
-    return dict(torch=torch, P=P, st=st, V=V, A=A, B=B, qrange=qrange, nq=nq, nlist=nlist, dK1=dK1, dK2=dK2, n1=n1, n2=n2, K1=K1, K2=K2,
-                M1=M1, M2=M2, dF=torch.from_numpy(Fm).cuda())
-
-
-def _outputs(torch, P, cap):
-    i32 = torch.int32
-    return [torch.full((P, cap), -9, dtype=i32, device="cuda") for _ in range(4)] + [torch.zeros(P, dtype=i32, device="cuda")]
-
-
-def _by_feature(pos_feat, n, arr, fill=-1):
-    out = np.full(n, fill, np.int32)
-    out[pos_feat] = arr[:len(pos_feat)]
-    return out
-
-
 @pytest.mark.parametrize("check", [True, False], ids=["rot", "norot"])
 def test_search_for_triangulation_pipeline(check):
+    pytest.importorskip("torch")
     cap = 1000
     pairs = [kf_pairs.pair(100, 1000, 1000), kf_pairs.pair(101, 1000, 700, line_noise=1.0), kf_pairs.pair(102, 500, 1000, max_flips=40),
              kf_pairs.pair(103, 1000, 1000, p_mp1=0.0, p_mp2=0.0, line_noise=3.0), kf_pairs.pair(104, 1, 300), kf_pairs.pair(105, 40, 0),
              kf_pairs.pair(106, 1000, 1000, max_flips=6, line_noise=0.5)]
-    S = _setup(pairs, cap)
-    torch, P, st = S["torch"], S["P"], S["st"]
-    q2t, t2q, best, second, nm = _outputs(torch, P, cap)
-    dMP2 = torch.from_numpy(S["M2"]).cuda()
-    dQV = torch.from_numpy((1 - S["M1"]).astype(np.uint8)).cuda()                   # a query is valid when it has NO map point yet
-    capi.triangulation_search_batch_device(capi.TH_LOW, check, S["dF"].data_ptr(), kf_pairs.LEVEL_SIGMA2, S["dK2"].data_ptr(), S["B"]["D"].data_ptr(),
-                                           S["B"]["feat"].data_ptr(), S["nlist"].data_ptr(), S["B"]["n"].data_ptr(), cap, dMP2.data_ptr(),
-                                           S["qrange"].data_ptr(), S["A"]["feat"].data_ptr(), S["dK1"].data_ptr(), S["A"]["D"].data_ptr(), dQV.data_ptr(),
-                                           S["nq"].data_ptr(), cap, P, q2t.data_ptr(), t2q.data_ptr(), best.data_ptr(), second.data_ptr(), nm.data_ptr(), st)
-    torch.cuda.synchronize()
-    q2t, t2q, best, second, nm, nqh = (x.cpu().numpy() for x in (q2t, t2q, best, second, nm, S["nq"]))
+    S = kd.setup(pairs, cap)
+    q2t, t2q, best, second, nm, nqh = kd.run_triangulation(S, cap, capi.TH_LOW, check, kf_pairs.LEVEL_SIGMA2)
     total = not_best = 0
     for i, p in enumerate(pairs):
-        fv1, fv2 = _host_fv(S["A"], i), _host_fv(S["B"], i)
+        fv1, fv2 = kd.host_fv(S["A"], i), kd.host_fv(S["B"], i)
         w = ol.search_for_triangulation(capi.TH_LOW, check, p["F"], kf_pairs.LEVEL_SIGMA2, fv1, p["k1"], p["d1"], p["mp1"], fv2, p["k2"], p["d2"], p["mp2"])
         assert nm[i] == w[0], (i, nm[i], w[0])
         nqi = nqh[i]
         assert nqi == len(fv1[2])
         pos_feat = fv1[2].astype(np.int64)
         n1, n2 = S["n1"][i], S["n2"][i]
-        np.testing.assert_array_equal(_by_feature(pos_feat, n1, q2t[i, :nqi]), w[1], err_msg="vMatches12 pair %d" % i)
-        got_t2q = t2q[i, :n2].copy()
-        m = got_t2q >= 0
-        got_t2q[m] = pos_feat[got_t2q[m]]
-        np.testing.assert_array_equal(got_t2q, w[2], err_msg="inverse pair %d" % i)
-        np.testing.assert_array_equal(_by_feature(pos_feat, n1, best[i, :nqi]), w[3], err_msg="BestDist pair %d" % i)
-        np.testing.assert_array_equal(_by_feature(pos_feat, n1, second[i, :nqi]), w[4], err_msg="match distance pair %d" % i)
+        np.testing.assert_array_equal(kd.by_feature(pos_feat, n1, q2t[i, :nqi]), w[1], err_msg="vMatches12 pair %d" % i)
+        np.testing.assert_array_equal(kd.inverse_by_feature(pos_feat, t2q[i, :n2]), w[2], err_msg="inverse pair %d" % i)
+        np.testing.assert_array_equal(kd.by_feature(pos_feat, n1, best[i, :nqi]), w[3], err_msg="BestDist pair %d" % i)
+        np.testing.assert_array_equal(kd.by_feature(pos_feat, n1, second[i, :nqi]), w[4], err_msg="match distance pair %d" % i)
         total += w[0]
         not_best += int(((w[1] >= 0) & (w[4] > w[3])).sum())
     assert total > 400 and not_best > 5
@@ -110,33 +44,21 @@ def test_search_for_triangulation_pipeline(check):
 def test_search_by_bow_keyframes(check):
     """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...) = the list search with rule BOW, th = TH_LOW - 1 (that function tests
     `bestDist1 < TH_LOW`) and the pKF2 features WITHOUT a good map point marked as claimed"""
+    pytest.importorskip("torch")
     cap = 1000
     pairs = [kf_pairs.pair(200, 1000, 1000, max_flips=40), kf_pairs.pair(201, 800, 1000, max_flips=60), kf_pairs.pair(202, 1000, 300, max_flips=30),
              kf_pairs.pair(203, 0, 100), kf_pairs.pair(204, 1000, 1000, max_flips=50, p_mp1=0.05, p_mp2=0.05)]
-    S = _setup(pairs, cap)
-    torch, P, st = S["torch"], S["P"], S["st"]
-    q2t, t2q, best, second, nm = _outputs(torch, P, cap)
-    V1, V2 = (1 - S["M1"]).astype(np.uint8), (1 - S["M2"]).astype(np.uint8)      # "holds a good map point"
-    dV1, dC2 = torch.from_numpy(V1).cuda(), torch.from_numpy((1 - V2).astype(np.uint8)).cuda()
-    dA1 = torch.from_numpy(np.ascontiguousarray(S["K1"]["angle"])).cuda()
-    capi.list_search_batch_device(capi.RULE_BOW, capi.TH_LOW - 1, 0.6, check, S["dK2"].data_ptr(), S["B"]["D"].data_ptr(), S["B"]["feat"].data_ptr(),
-                                  S["nlist"].data_ptr(), S["B"]["n"].data_ptr(), cap, dC2.data_ptr(), S["qrange"].data_ptr(), S["A"]["feat"].data_ptr(),
-                                  S["A"]["D"].data_ptr(), dA1.data_ptr(), dV1.data_ptr(), S["nq"].data_ptr(), cap, P, q2t.data_ptr(), t2q.data_ptr(),
-                                  best.data_ptr(), second.data_ptr(), nm.data_ptr(), st)
-    torch.cuda.synchronize()
-    q2t, t2q, nm, nqh = (x.cpu().numpy() for x in (q2t, t2q, nm, S["nq"]))
+    S = kd.setup(pairs, cap)
+    q2t, t2q, nm, nqh, V1, V2 = kd.run_bow_kf(S, cap, capi.TH_LOW, 0.6, check)
     total = 0
     for i, p in enumerate(pairs):
-        fv1, fv2 = _host_fv(S["A"], i), _host_fv(S["B"], i)
+        fv1, fv2 = kd.host_fv(S["A"], i), kd.host_fv(S["B"], i)
         n1, n2 = S["n1"][i], S["n2"][i]
         w = ol.search_by_bow_kf(capi.TH_LOW, 0.6, check, fv1, p["d1"], p["k1"]["angle"], V1[i, :n1], fv2, p["d2"], p["k2"]["angle"], V2[i, :n2])
         assert nm[i] == w[0], (i, nm[i], w[0])
         pos_feat = fv1[2].astype(np.int64)
-        np.testing.assert_array_equal(_by_feature(pos_feat, n1, q2t[i, :nqh[i]]), w[1], err_msg="vpMatches12 pair %d" % i)
-        got_t2q = t2q[i, :n2].copy()
-        m = got_t2q >= 0
-        got_t2q[m] = pos_feat[got_t2q[m]]
-        np.testing.assert_array_equal(got_t2q, w[2], err_msg="inverse pair %d" % i)
+        np.testing.assert_array_equal(kd.by_feature(pos_feat, n1, q2t[i, :nqh[i]]), w[1], err_msg="vpMatches12 pair %d" % i)
+        np.testing.assert_array_equal(kd.inverse_by_feature(pos_feat, t2q[i, :n2]), w[2], err_msg="inverse pair %d" % i)
         total += w[0]
     assert total > 300
 

@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
 """Randomised differential test of the rows either side of the path: bag-of-words transform, undistortion + grid, window queries,
-greedy searches (every rule), distinctive descriptor — HIP vs the CPU oracle on random shapes / parameters.
+greedy searches (every rule, incl. the key-frame pair searches over vocabulary nodes), distinctive descriptor — HIP vs the CPU oracle on random shapes / parameters.
 usage: fuzz_frontend.py [cases] [seed]   — prints one JSON line."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
+import kf_device as kd
+import kf_pairs
 import oracle_lib as ol
 from orb_slam_amd import capi, synth
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-bad, done = [], {"bow": 0, "frame": 0, "area": 0, "search": 0, "distinctive": 0}
+bad, done = [], {"bow": 0, "kf_search": 0, "frame": 0, "area": 0, "search": 0, "distinctive": 0}
 t0 = time.time()
 st = torch.cuda.current_stream().cuda_stream
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
@@ -42,6 +44,34 @@ for c in range(cases):
         bad.append(("bow", c, k, L, scoring, weighting, n, lu))
     done["bow"] += 1
     V.close()
+    # ---- key-frame pair searches over the vocabulary nodes: SearchForTriangulation and SearchByBoW(KF, KF), two pairs per case
+    if c % 2 == 0:
+        capk = int(rng.choice([64, 500, 1000, 2000]))
+        prs = [kf_pairs.pair(int(rng.integers(1, 10**6)), int(rng.integers(0, capk + 1)), int(rng.integers(0, capk + 1)), max_flips=int(rng.choice([4, 24, 60])),
+                             line_noise=float(rng.choice([0.5, 2.0, 4.0])), p_mp1=float(rng.choice([0.0, 0.3, 0.9])), p_mp2=float(rng.choice([0.0, 0.3])))
+               for _ in range(2)]
+        lsup = int(rng.integers(0, L + 1))
+        S = kd.setup(prs, capk, voc=voc, k=k, L=L, levelsup=lsup)
+        chk = bool(rng.random() < 0.5); thl = int(rng.choice([50, 30, 80])); ratio = float(rng.choice([0.6, 0.75, 0.9]))
+        sig2 = (kf_pairs.LEVEL_SIGMA2 * np.float32(rng.choice([1.0, 0.3, 4.0]))).astype(np.float32)
+        g = kd.run_triangulation(S, capk, thl, chk, sig2)
+        h = kd.run_bow_kf(S, capk, thl, ratio, chk)
+        for i, p in enumerate(prs):
+            fv1, fv2 = kd.host_fv(S["A"], i), kd.host_fv(S["B"], i)
+            n1, n2 = S["n1"][i], S["n2"][i]
+            pos = fv1[2].astype(np.int64)
+            wt = ol.search_for_triangulation(thl, chk, p["F"], sig2, fv1, p["k1"], p["d1"], p["mp1"], fv2, p["k2"], p["d2"], p["mp2"])
+            gt = (int(g[4][i]), kd.by_feature(pos, n1, g[0][i, :g[5][i]]), kd.inverse_by_feature(pos, g[1][i, :n2]), kd.by_feature(pos, n1, g[2][i, :g[5][i]]),
+                  kd.by_feature(pos, n1, g[3][i, :g[5][i]]))
+            if gt[0] != wt[0] or any(not np.array_equal(x, y) for x, y in zip(gt[1:], wt[1:])):
+                bad.append(("triangulation", c, i, k, L, lsup, n1, n2, thl, chk))
+            wb = ol.search_by_bow_kf(thl, ratio, chk, fv1, p["d1"], p["k1"]["angle"], h[4][i, :n1], fv2, p["d2"], p["k2"]["angle"], h[5][i, :n2])
+            gb = (int(h[2][i]), kd.by_feature(pos, n1, h[0][i, :h[3][i]]), kd.inverse_by_feature(pos, h[1][i, :n2]))
+            if gb[0] != wb[0] or any(not np.array_equal(x, y) for x, y in zip(gb[1:], wb[1:])):
+                bad.append(("bow_kf", c, i, k, L, lsup, n1, n2, thl, ratio, chk))
+            done["kf_matches"] = done.get("kf_matches", 0) + int(wt[0]) + int(wb[0])
+        S["V"].close()
+        done["kf_search"] += 2
     # ---- frame steps + searches
     w, h = int(rng.integers(200, 1300)), int(rng.integers(150, 1000))
     dist = [(0.2624, -0.9531, -0.0054, 0.0026), (-0.2834, 0.0739, 0.0002, 0.00002), (0.0, 0.0, 0.0, 0.0), (-0.1, 0.02, 0.001, -0.002, 0.003)][int(rng.integers(0, 4))]
