@@ -7,6 +7,12 @@ A step = one pass of the hot path over one batch of synthetic frames already res
 Workload = BASELINE.json `metric` ("frames/s ORB extract+match @640x480, 1000 kp"): configs[1] (single MI355X,
 640x480 stream, 8 levels, nFeatures 1000) plus the frame-to-frame match of the metric.
 
+A step's `batch` consecutive frames go through `--lanes` (default 4) lanes of batch/lanes consecutive frames, each lane with its
+own extractor handle and HIP stream; a lane matches its own frames, and lanes meet only where the frame-to-frame match crosses
+a lane border (event-ordered hand-off of one frame's descriptors).  So the latency-bound kernels of one lane run next to the
+VALU-bound kernels of another, and consecutive steps overlap.
+The per-kernel roofline numbers come from a short serial pass after the timed region (every kernel alone on the chip).
+
   python bench.py --gpus N --steps K --warmup W
 For N>1 launch under torch.distributed.run (one rank per GPU); every rank extracts its own stream
 (weak scaling, no data-path collective), RCCL only reduces the timing / counters.
@@ -79,15 +85,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
-    ap.add_argument("--ring", type=int, default=1024, help="distinct frames resident per GPU (>= 1024 VGA frames exceeds the 256 MiB Infinity Cache)")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU")
+    ap.add_argument("--ring", type=int, default=2048, help="distinct frames resident per GPU (>= 1024 VGA frames exceeds the 256 MiB Infinity Cache)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--family", type=int, default=1, help="0 noise, 1 blocks (default), 3 lowtex")
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE configs[1] verbatim)")
-    ap.add_argument("--match-stream", choices=["side", "same"], default="side",
-                    help="side: the match of step i runs on a second stream while step i+1 is extracted (default); same: one stream")
+    ap.add_argument("--lanes", type=int, default=4,
+                    help="a step's frames go through this many concurrent lanes (own extractor handle + HIP stream each); 1 = one stream")
+    ap.add_argument("--region-timing", action="store_true",
+                    help="also time every kernel inside the timed region (HIP events between the kernels of every lane: costs a few percent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo")
@@ -109,78 +117,139 @@ def main():
     frames = synth.frames(w, h, a.family, dist_util.stream_first_index(rank, ring), ring)          # one independent image stream per rank
     d_img = torch.from_numpy(frames).to(dev)
     del frames
-    ex = capi.ORBextractor(nfeatures=a.nfeatures, device=local_rank, max_batch=B)
-    cap = ex.max_keypoints
-    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
-    # two generations of outputs: the match of step i (side stream) runs while step i+1 is being extracted (main stream)
-    d_desc = torch.zeros((2, B + 1, cap, 32), dtype=torch.uint8, device=dev)   # slot 0 = last frame of the previous step
-    d_n = torch.zeros((2, B + 1), dtype=torch.int32, device=dev)
-    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_match = torch.zeros((3, B, cap), dtype=torch.int32, device=dev)
-    main = torch.cuda.current_stream(dev)
-    stream = main.cuda_stream
-    side = torch.cuda.Stream(dev) if a.match_stream == "side" else main
+    G = max(1, min(a.lanes, B))
+    while B % G:
+        G -= 1
+    b = B // G                     # frames per lane and step
     do_match = not a.no_match
+
+    class Lane:
+        """One contiguous b-frame slice of every step: its own extractor handle, HIP stream and output buffers.  Slot 0 of
+        desc / n holds the frame before the slice (the last frame of the lane to the left, or of the previous step)."""
+        def __init__(self):
+            self.ex = capi.ORBextractor(nfeatures=a.nfeatures, device=local_rank, max_batch=b)
+            self.stream = torch.cuda.Stream(dev)
+            cap = self.ex.max_keypoints
+            self.kps = torch.zeros((b, cap, 7), dtype=torch.float32, device=dev)
+            self.desc = torch.zeros((b + 1, cap, 32), dtype=torch.uint8, device=dev)
+            self.n = torch.zeros(b + 1, dtype=torch.int32, device=dev)
+            self.status = torch.zeros(b, dtype=torch.int32, device=dev)
+            self.match = torch.zeros((3, b, cap), dtype=torch.int32, device=dev)
+            # hand-off of the slice's last frame to the lane on the right: two slots (step parity)
+            self.h_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
+            self.h_n = torch.zeros((2, 1), dtype=torch.int32, device=dev)
+            self.h_written = [None, None]
+            self.h_consumed = [None, None]
+
+    lanes = [Lane() for _ in range(G)]
+    cap = lanes[0].ex.max_keypoints
     match_events = []
-    ev_extract = [None, None]      # extraction of the generation finished
-    ev_match = [None, None]        # its match finished (the generation may be overwritten)
 
     def step(i, timed):
-        # generation g holds this step's outputs in slots 1..B and the previous step's last frame in slot 0.
-        # main stream: extract(i) -> [wait match(i-1)] -> hand slot B over to the other generation's slot 0.
-        # side stream: match(i) as soon as extract(i) is done, i.e. concurrently with extract(i+1).
+        """Lane g extracts frames [g*b, (g+1)*b) of the step on its own stream, publishes its last frame, takes the frame before
+        its slice from the lane on its left (lane 0: from the last lane's previous step) and matches every frame against its
+        predecessor.  Lanes only meet at those hand-offs (events), so kernels of different lanes and steps co-run."""
         f0 = (i * B) % ring
-        g = i & 1
-        ex.extract_batch_device(d_img.data_ptr() + f0 * w * h, B, w, h, w, w * h, d_kps.data_ptr(),
-                                d_desc[g, 1].data_ptr(), d_n[g, 1:].data_ptr(), cap, d_status.data_ptr(), stream)
-        if do_match:
-            ev_extract[g] = torch.cuda.Event()
-            ev_extract[g].record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ev_extract[g])
+        par = i & 1
+        for g, ln in enumerate(lanes):
+            s = ln.stream
+            with torch.cuda.stream(s):
+                ln.ex.extract_batch_device(d_img.data_ptr() + (f0 + g * b) * w * h, b, w, h, w, w * h, ln.kps.data_ptr(),
+                                           ln.desc[1].data_ptr(), ln.n[1:].data_ptr(), cap, ln.status.data_ptr(), s.cuda_stream)
+                if not do_match:
+                    continue
+                if ln.h_consumed[par] is not None:
+                    s.wait_event(ln.h_consumed[par])              # the slot's reader of step i-2 is done
+                ln.h_desc[par].copy_(ln.desc[b], non_blocking=True)
+                ln.h_n[par].copy_(ln.n[b:b + 1], non_blocking=True)
+                ln.h_written[par] = torch.cuda.Event()
+                ln.h_written[par].record(s)
+                src, sp = (lanes[g - 1], par) if g > 0 else (lanes[G - 1], par ^ 1)
+                if g > 0 or i > 0:
+                    s.wait_event(src.h_written[sp])
+                    ln.desc[0].copy_(src.h_desc[sp], non_blocking=True)
+                    ln.n[0:1].copy_(src.h_n[sp], non_blocking=True)
+                    src.h_consumed[sp] = torch.cuda.Event()
+                    src.h_consumed[sp].record(s)
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(side)
-                capi.match_top2_batch_device(d_desc[g, 1].data_ptr(), d_n[g, 1:].data_ptr(), d_desc[g, 0].data_ptr(), d_n[g].data_ptr(),
-                                             B, cap, d_match[0].data_ptr(), d_match[1].data_ptr(), d_match[2].data_ptr(), side.cuda_stream)
+                    e0.record(s)
+                capi.match_top2_batch_device(ln.desc[1].data_ptr(), ln.n[1:].data_ptr(), ln.desc[0].data_ptr(), ln.n.data_ptr(),
+                                             b, cap, ln.match[0].data_ptr(), ln.match[1].data_ptr(), ln.match[2].data_ptr(), s.cuda_stream)
                 if timed:
-                    e1.record(side)
+                    e1.record(s)
                     match_events.append((e0, e1))
-                ev_match[g] = torch.cuda.Event()
-                ev_match[g].record(side)
-            if ev_match[g ^ 1] is not None:
-                main.wait_event(ev_match[g ^ 1])          # the other generation is free again (its match has finished)
-            d_desc[g ^ 1, 0].copy_(d_desc[g, B], non_blocking=True)
-            d_n[g ^ 1, 0:1].copy_(d_n[g, B:B + 1], non_blocking=True)
 
     for i in range(a.warmup):
         step(i, False)
     torch.cuda.synchronize(dev)
-    ex.stage_timing(2)
+    for ln in lanes:
+        ln.ex.stage_timing(2 if a.region_timing else 0)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(a.steps):
-        step(a.warmup + i, True)
+        step(a.warmup + i, a.region_timing)
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
 
-    stage = ex.stage_times()
-    ex.stage_timing(0)
+    stage = {}
+    for ln in lanes:
+        for k, (ms, n) in ln.ex.stage_times().items():
+            t = stage.get(k, (0.0, 0))
+            stage[k] = (t[0] + ms, t[1] + n)
+        ln.ex.stage_timing(0)
     match_ms = sum(e0.elapsed_time(e1) for e0, e1 in match_events) / max(len(match_events), 1)
-    last = (a.warmup + a.steps - 1) & 1
-    kp_mean = float(d_n[last, 1:].float().mean().item())
-    bad_status = int((d_status != 0).sum().item())
+    kp_mean = float(torch.cat([ln.n[1:] for ln in lanes]).float().mean().item())
+    bad_status = int(sum((ln.status != 0).sum().item() for ln in lanes))
     accepted = -1
     if do_match:
-        best = d_match[1, B - 1, :cap].cpu().numpy()
-        sec = d_match[2, B - 1, :cap].cpu().numpy()
-        nq = int(d_n[last, B].item())
+        last = lanes[G - 1]
+        best = last.match[1, b - 1, :cap].cpu().numpy()
+        sec = last.match[2, b - 1, :cap].cpu().numpy()
+        nq = int(last.n[b].item())
         accepted = capi.count_accepted(best[:nq], sec[:nq], 50, 0.6)
+
+    def serial_pass(nsteps):
+        """The same step with every kernel alone on the chip: one extractor over all B frames, one launch per kernel, the match
+        on the same stream.  Per-kernel roofline numbers come from here; in the timed region above the lanes co-run, so a
+        kernel's duration there includes sharing the CUs with the kernels of the other lanes."""
+        ex1 = capi.ORBextractor(nfeatures=a.nfeatures, device=local_rank, max_batch=B)
+        main = torch.cuda.current_stream(dev)
+        kps1 = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+        desc1 = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
+        n1 = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        match1 = torch.zeros((3, B, cap), dtype=torch.int32, device=dev)
+        evs = []
+        for i in range(2 + nsteps):
+            if i == 2:
+                torch.cuda.synchronize(dev)
+                ex1.stage_timing(2)
+            f0 = (i * B) % ring
+            ex1.extract_batch_device(d_img.data_ptr() + f0 * w * h, B, w, h, w, w * h, kps1.data_ptr(), desc1[1].data_ptr(), n1[1:].data_ptr(), cap, 0,
+                                     main.cuda_stream)
+            if do_match:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                capi.match_top2_batch_device(desc1[1].data_ptr(), n1[1:].data_ptr(), desc1[0].data_ptr(), n1.data_ptr(), B, cap,
+                                             match1[0].data_ptr(), match1[1].data_ptr(), match1[2].data_ptr(), main.cuda_stream)
+                e1.record(main)
+                if i >= 2:
+                    evs.append((e0, e1))
+                desc1[0].copy_(desc1[B], non_blocking=True)
+                n1[0:1].copy_(n1[B:B + 1], non_blocking=True)
+        torch.cuda.synchronize(dev)
+        st1 = ex1.stage_times()
+        ex1.stage_timing(0)
+        ms1 = {k: (ms / n if n else 0.0) for k, (ms, n) in st1.items()}
+        if do_match:
+            ms1["match"] = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(len(evs), 1)
+        ex1.close()
+        return ms1
 
     # RCCL: the only collectives of the run (MAX of the timing, all-gather of the counters)
     tmax, counters, _ = dist_util.reduce_run(dist, elapsed, [a.steps * B, kp_mean * a.steps * B, bad_status],
@@ -189,15 +258,21 @@ def main():
 
     if rank == 0:
         a_extract, a_match, per_stage = algorithmic_bytes(w, h, a.nfeatures)
-        stage_ms = {k: (ms / n if n else 0.0) for k, (ms, n) in stage.items()}
+        region_ms = {k: (ms / n if n else 0.0) for k, (ms, n) in stage.items()}      # per LAUNCH: one lane's slice of b frames
         if do_match:
-            stage_ms["match"] = match_ms
+            region_ms["match"] = match_ms
+        concurrent = G > 1 or not a.region_timing        # without in-region timing the serial pass is the only per-kernel timing
+        stage_ms = serial_pass(min(a.steps, 10)) if concurrent else dict(region_ms)
         dom = max(stage_ms, key=lambda k: stage_ms[k])
-        dom_bytes = (per_stage.get(dom, a_match if dom == "match" else 0)) * B
+        dom_frame_bytes = per_stage.get(dom, a_match if dom == "match" else 0)
+        dom_bytes = dom_frame_bytes * B
         dom_gbs = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        region_frames = b
+        region_gbs = dom_frame_bytes * region_frames / (region_ms[dom] * 1e-3) / 1e9 if region_ms.get(dom, 0) > 0 else 0.0
         kernel_ms = sum(stage_ms.values())
         pipe_bytes = (a_extract + (a_match if do_match else 0)) * B
-        pipe_gbs = pipe_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        step_ms = tmax / a.steps * 1e3
+        pipe_gbs = pipe_bytes / (step_ms * 1e-3) / 1e9
         traffic, valu_busy = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")      # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
         if os.path.exists(tfile):
@@ -224,17 +299,28 @@ def main():
             "config": {"workload": "%dx%d grayscale stream, 8 levels, nFeatures %d, %s frames, extract%s" % (
                            w, h, a.nfeatures, {0: "S-noise", 1: "S-blocks", 3: "S-lowtex"}.get(a.family, str(a.family)),
                            " + Hamming top-2 match vs previous frame" if do_match else " only"),
-                       "frames_per_step_per_gpu": B, "resident_frames_per_gpu": ring, "parallelism": "one image stream per GPU",
+                       "frames_per_step_per_gpu": B, "resident_frames_per_gpu": ring,
+                       "parallelism": "one image stream per GPU; a step's %d frames go through %d lanes of %d consecutive frames "
+                                      "(own extractor handle + HIP stream each), frame-to-frame matches across lane borders via event-ordered hand-off" % (B, G, b),
+                       "lanes": G,
                        "mean_keypoints_per_frame": round(float(counters[1]) / total_frames, 2),
                        "frames_with_error_status": int(counters[2]), "accepted_matches_last_frame": accepted},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(dom_gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "valu_busy": valu_busy,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(stage_ms[dom], 4)},
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(stage_ms[dom], 4), "frames_per_launch": B,
+                         "timing": ("serial pass after the timed region: %d steps, one launch per kernel over all %d frames, nothing else on the chip "
+                                    "(HIP events on the launch stream)" % (min(a.steps, 10), B)) if concurrent else "timed region (one stream)",
+                         "timed_region": {"lanes": G, "frames_per_launch": region_frames, "avg_launch_ms": round(region_ms[dom], 4) if a.region_timing else None,
+                                          "achieved": round(region_gbs, 2) if a.region_timing else None,
+                                          "note": "the lanes co-run, a kernel shares the CUs with the kernels of the other lanes; --region-timing measures the "
+                                                  "per-launch durations there (event pairs between all kernels cost 2-6 % of the throughput)"}},
             "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(pipe_gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": pipe_bytes,
-                                  "kernel_ms_per_step": round(kernel_ms, 4)},
+                                  "ms_per_step": round(step_ms, 4), "kernel_ms_per_step_serial": round(kernel_ms, 4)},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
         }
+        if a.region_timing:
+            out["stage_ms_per_launch_timed_region"] = {k: round(v, 4) for k, v in region_ms.items()}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h, a.nfeatures, a.cpu_seconds)
         print(json.dumps(out))
