@@ -117,74 +117,18 @@ def main():
     frames = synth.frames(w, h, a.family, dist_util.stream_first_index(rank, ring), ring)          # one independent image stream per rank
     d_img = torch.from_numpy(frames).to(dev)
     del frames
-    G = max(1, min(a.lanes, B))
-    while B % G:
-        G -= 1
-    b = B // G                     # frames per lane and step
     do_match = not a.no_match
-
-    class Lane:
-        """One contiguous b-frame slice of every step: its own extractor handle, HIP stream and output buffers.  Slot 0 of
-        desc / n holds the frame before the slice (the last frame of the lane to the left, or of the previous step)."""
-        def __init__(self):
-            self.ex = capi.ORBextractor(nfeatures=a.nfeatures, device=local_rank, max_batch=b)
-            self.stream = torch.cuda.Stream(dev)
-            cap = self.ex.max_keypoints
-            self.kps = torch.zeros((b, cap, 7), dtype=torch.float32, device=dev)
-            self.desc = torch.zeros((b + 1, cap, 32), dtype=torch.uint8, device=dev)
-            self.n = torch.zeros(b + 1, dtype=torch.int32, device=dev)
-            self.status = torch.zeros(b, dtype=torch.int32, device=dev)
-            self.match = torch.zeros((3, b, cap), dtype=torch.int32, device=dev)
-            # hand-off of the slice's last frame to the lane on the right: two slots (step parity)
-            self.h_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
-            self.h_n = torch.zeros((2, 1), dtype=torch.int32, device=dev)
-            self.h_written = [None, None]
-            self.h_consumed = [None, None]
-
-    lanes = [Lane() for _ in range(G)]
-    cap = lanes[0].ex.max_keypoints
-    match_events = []
+    from orb_slam_amd.pipeline import LanePipeline
+    pipe = LanePipeline(w, h, B, lanes=a.lanes, nfeatures=a.nfeatures, device=local_rank, do_match=do_match)   # orb_slam_amd/pipeline.py
+    G, b, cap = pipe.G, pipe.b, pipe.cap
 
     def step(i, timed):
-        """Lane g extracts frames [g*b, (g+1)*b) of the step on its own stream, publishes its last frame, takes the frame before
-        its slice from the lane on its left (lane 0: from the last lane's previous step) and matches every frame against its
-        predecessor.  Lanes only meet at those hand-offs (events), so kernels of different lanes and steps co-run."""
-        f0 = (i * B) % ring
-        par = i & 1
-        for g, ln in enumerate(lanes):
-            s = ln.stream
-            with torch.cuda.stream(s):
-                ln.ex.extract_batch_device(d_img.data_ptr() + (f0 + g * b) * w * h, b, w, h, w, w * h, ln.kps.data_ptr(),
-                                           ln.desc[1].data_ptr(), ln.n[1:].data_ptr(), cap, ln.status.data_ptr(), s.cuda_stream)
-                if not do_match:
-                    continue
-                if ln.h_consumed[par] is not None:
-                    s.wait_event(ln.h_consumed[par])              # the slot's reader of step i-2 is done
-                ln.h_desc[par].copy_(ln.desc[b], non_blocking=True)
-                ln.h_n[par].copy_(ln.n[b:b + 1], non_blocking=True)
-                ln.h_written[par] = torch.cuda.Event()
-                ln.h_written[par].record(s)
-                src, sp = (lanes[g - 1], par) if g > 0 else (lanes[G - 1], par ^ 1)
-                if g > 0 or i > 0:
-                    s.wait_event(src.h_written[sp])
-                    ln.desc[0].copy_(src.h_desc[sp], non_blocking=True)
-                    ln.n[0:1].copy_(src.h_n[sp], non_blocking=True)
-                    src.h_consumed[sp] = torch.cuda.Event()
-                    src.h_consumed[sp].record(s)
-                if timed:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(s)
-                capi.match_top2_batch_device(ln.desc[1].data_ptr(), ln.n[1:].data_ptr(), ln.desc[0].data_ptr(), ln.n.data_ptr(),
-                                             b, cap, ln.match[0].data_ptr(), ln.match[1].data_ptr(), ln.match[2].data_ptr(), s.cuda_stream)
-                if timed:
-                    e1.record(s)
-                    match_events.append((e0, e1))
+        pipe.step(d_img.data_ptr() + ((i * B) % ring) * w * h, timed=timed)
 
     for i in range(a.warmup):
         step(i, False)
     torch.cuda.synchronize(dev)
-    for ln in lanes:
-        ln.ex.stage_timing(2 if a.region_timing else 0)
+    pipe.stage_timing(2 if a.region_timing else 0)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -197,18 +141,13 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
 
-    stage = {}
-    for ln in lanes:
-        for k, (ms, n) in ln.ex.stage_times().items():
-            t = stage.get(k, (0.0, 0))
-            stage[k] = (t[0] + ms, t[1] + n)
-        ln.ex.stage_timing(0)
-    match_ms = sum(e0.elapsed_time(e1) for e0, e1 in match_events) / max(len(match_events), 1)
-    kp_mean = float(torch.cat([ln.n[1:] for ln in lanes]).float().mean().item())
-    bad_status = int(sum((ln.status != 0).sum().item() for ln in lanes))
+    stage = pipe.stage_times()
+    pipe.stage_timing(0)
+    kp_mean = float(pipe.counts().float().mean().item())
+    bad_status = int((pipe.status() != 0).sum().item())
     accepted = -1
     if do_match:
-        last = lanes[G - 1]
+        last = pipe.lanes[G - 1]
         best = last.match[1, b - 1, :cap].cpu().numpy()
         sec = last.match[2, b - 1, :cap].cpu().numpy()
         nq = int(last.n[b].item())
@@ -259,8 +198,6 @@ def main():
     if rank == 0:
         a_extract, a_match, per_stage = algorithmic_bytes(w, h, a.nfeatures)
         region_ms = {k: (ms / n if n else 0.0) for k, (ms, n) in stage.items()}      # per LAUNCH: one lane's slice of b frames
-        if do_match:
-            region_ms["match"] = match_ms
         concurrent = G > 1 or not a.region_timing        # without in-region timing the serial pass is the only per-kernel timing
         stage_ms = serial_pass(min(a.steps, 10)) if concurrent else dict(region_ms)
         dom = max(stage_ms, key=lambda k: stage_ms[k])

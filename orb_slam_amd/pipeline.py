@@ -1,0 +1,120 @@
+"""Host side of the throughput configuration: a step's B consecutive frames go through G lanes of B/G
+consecutive frames, each lane with its own extractor handle and HIP stream, every frame matched against its predecessor.
+
+Lanes never join.  The only cross-lane dependency is the one frame per lane whose predecessor lies in the lane to its left
+(lane 0: in the last lane's slice of the previous step): that frame's descriptors travel through a two-slot hand-off buffer
+ordered by HIP events.  torch is used for device memory, streams and events only."""
+import torch
+
+from . import capi
+
+
+class _Lane:
+    """One contiguous b-frame slice of every step.  Slot 0 of desc / n holds the frame before the slice."""
+
+    def __init__(self, nfeatures, device, b, extractor_kw):
+        dev = torch.device("cuda", device)
+        self.ex = capi.ORBextractor(nfeatures=nfeatures, device=device, max_batch=b, **extractor_kw)
+        self.stream = torch.cuda.Stream(dev)
+        cap = self.ex.max_keypoints
+        self.kps = torch.zeros((b, cap, 7), dtype=torch.float32, device=dev)
+        self.desc = torch.zeros((b + 1, cap, 32), dtype=torch.uint8, device=dev)
+        self.n = torch.zeros(b + 1, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(b, dtype=torch.int32, device=dev)
+        self.match = torch.zeros((3, b, cap), dtype=torch.int32, device=dev)       # train index, best, second per query slot
+        # hand-off of the slice's last frame to the lane on the right: two slots (step parity)
+        self.h_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
+        self.h_n = torch.zeros((2, 1), dtype=torch.int32, device=dev)
+        self.h_written = [None, None]
+        self.h_consumed = [None, None]
+
+
+class LanePipeline:
+    def __init__(self, width, height, batch, lanes=4, nfeatures=1000, device=0, do_match=True, **extractor_kw):
+        G = max(1, min(lanes, batch))
+        while batch % G:
+            G -= 1
+        self.w, self.h, self.B, self.G, self.b = width, height, batch, G, batch // G
+        self.do_match = do_match
+        self.lanes = [_Lane(nfeatures, device, self.b, extractor_kw) for _ in range(G)]
+        self.cap = self.lanes[0].ex.max_keypoints
+        self.steps_done = 0
+        self.match_events = []
+
+    def step(self, d_frames_ptr, frame_stride=None, row_stride=None, timed=False):
+        """d_frames_ptr: device address of the step's first frame (B frames, frame_stride bytes apart).  Asynchronous: lane g
+        extracts frames [g*b, (g+1)*b) on its own stream, publishes its last frame, takes the frame before its slice from the
+        lane on its left and matches every frame against its predecessor."""
+        w, h, b, G, cap = self.w, self.h, self.b, self.G, self.cap
+        row_stride = row_stride or w
+        frame_stride = frame_stride or row_stride * h
+        i = self.steps_done
+        par = i & 1
+        for g, ln in enumerate(self.lanes):
+            s = ln.stream
+            with torch.cuda.stream(s):
+                ln.ex.extract_batch_device(d_frames_ptr + g * b * frame_stride, b, w, h, row_stride, frame_stride, ln.kps.data_ptr(),
+                                           ln.desc[1].data_ptr(), ln.n[1:].data_ptr(), cap, ln.status.data_ptr(), s.cuda_stream)
+                if not self.do_match:
+                    continue
+                if ln.h_consumed[par] is not None:
+                    s.wait_event(ln.h_consumed[par])              # the slot's reader of step i-2 is done
+                ln.h_desc[par].copy_(ln.desc[b], non_blocking=True)
+                ln.h_n[par].copy_(ln.n[b:b + 1], non_blocking=True)
+                ln.h_written[par] = torch.cuda.Event()
+                ln.h_written[par].record(s)
+                src, sp = (self.lanes[g - 1], par) if g > 0 else (self.lanes[G - 1], par ^ 1)
+                if g > 0 or i > 0:
+                    s.wait_event(src.h_written[sp])
+                    ln.desc[0].copy_(src.h_desc[sp], non_blocking=True)
+                    ln.n[0:1].copy_(src.h_n[sp], non_blocking=True)
+                    src.h_consumed[sp] = torch.cuda.Event()
+                    src.h_consumed[sp].record(s)
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(s)
+                capi.match_top2_batch_device(ln.desc[1].data_ptr(), ln.n[1:].data_ptr(), ln.desc[0].data_ptr(), ln.n.data_ptr(),
+                                             b, cap, ln.match[0].data_ptr(), ln.match[1].data_ptr(), ln.match[2].data_ptr(), s.cuda_stream)
+                if timed:
+                    e1.record(s)
+                    self.match_events.append((e0, e1))
+        self.steps_done += 1
+
+    # ---- results of the last step (call after torch.cuda.synchronize())
+    def counts(self):
+        return torch.cat([ln.n[1:] for ln in self.lanes])
+
+    def keypoints(self):
+        return torch.cat([ln.kps for ln in self.lanes])
+
+    def descriptors(self):
+        return torch.cat([ln.desc[1:] for ln in self.lanes])
+
+    def matches(self):
+        """(3, B, cap): train index in the previous frame, best and second-best distance per query slot"""
+        return torch.cat([ln.match for ln in self.lanes], dim=1)
+
+    def status(self):
+        return torch.cat([ln.status for ln in self.lanes])
+
+    # ---- per-kernel timing (HIP events between the kernels of every lane; costs a few percent of throughput)
+    def stage_timing(self, mode):
+        for ln in self.lanes:
+            ln.ex.stage_timing(mode)
+        if mode == 2:
+            self.match_events = []
+
+    def stage_times(self):
+        """{stage: (total ms, launches)} summed over the lanes; one launch = one lane's slice of b frames"""
+        stage = {}
+        for ln in self.lanes:
+            for k, (ms, n) in ln.ex.stage_times().items():
+                t = stage.get(k, (0.0, 0))
+                stage[k] = (t[0] + ms, t[1] + n)
+        if self.do_match and self.match_events:
+            stage["match"] = (sum(e0.elapsed_time(e1) for e0, e1 in self.match_events), len(self.match_events))
+        return stage
+
+    def close(self):
+        for ln in self.lanes:
+            ln.ex.close()

@@ -1,0 +1,65 @@
+"""GPU parity of the throughput configuration (orb_slam_amd/pipeline.py): a step cut into concurrent lanes with the border
+frame's descriptors handed over between streams gives, for EVERY frame of consecutive steps, exactly the keypoints,
+descriptors and top-2 matches against the previous frame that one handle on one stream — and the oracle — give."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from orb_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(frames, B, lanes, nf, steps):
+    torch = pytest.importorskip("torch")
+    from orb_slam_amd.pipeline import LanePipeline
+    _, h, w = frames.shape
+    d_img = torch.from_numpy(frames).cuda()
+    pipe = LanePipeline(w, h, B, lanes=lanes, nfeatures=nf)
+    assert pipe.G == lanes and pipe.b * lanes == B
+    out = []
+    for i in range(steps):
+        pipe.step(d_img.data_ptr() + i * B * w * h)
+        if i % 2 == 1 or i == steps - 1:
+            torch.cuda.synchronize()           # (results are only read after a synchronise; steps 0->1 run back to back)
+        if i % 2 == 0 and i != steps - 1:
+            continue
+        out.append((i, pipe.counts().cpu().numpy(), pipe.keypoints().cpu().numpy().view(np.uint8).reshape(B, pipe.cap, 28),
+                    pipe.descriptors().cpu().numpy(), pipe.matches().cpu().numpy()))
+    assert (pipe.status().cpu().numpy() == 0).all()
+    pipe.close()
+    return out
+
+
+@pytest.mark.parametrize("lanes", [4, 3, 8])
+def test_lanes_pipeline_equals_one_stream_and_oracle(lanes):
+    B, w, h, nf, steps = 24, 320, 240, 300, 4
+    frames = np.concatenate([synth.frames(w, h, synth.BLOCKS, 40, 60), synth.frames(w, h, synth.NOISE, 90, 20), synth.frames(w, h, synth.LOWTEX, 7, 16)])
+    assert len(frames) == B * steps
+    one = _run(frames, B, 1, nf, steps)
+    many = _run(frames, B, lanes, nf, steps)
+    assert [o[0] for o in one] == [o[0] for o in many] and len(one) >= 2
+    o = ol.OracleExtractor(nfeatures=nf)
+    checked = 0
+    for (i, n1, k1, d1, m1), (_, n2, k2, d2, m2) in zip(one, many):
+        np.testing.assert_array_equal(n1, n2)
+        for f in range(B):
+            n = n1[f]
+            assert k1[f, :n].tobytes() == k2[f, :n].tobytes(), (i, f)
+            assert d1[f, :n].tobytes() == d2[f, :n].tobytes(), (i, f)
+            np.testing.assert_array_equal(m1[:, f, :n], m2[:, f, :n], err_msg="step %d frame %d" % (i, f))
+        # the frames at the lane borders (and the step border) against the oracle: extraction and match vs the previous frame
+        b = B // lanes
+        for f in sorted({0, b - 1, b, 2 * b, B - 1}):
+            g = i * B + f
+            ok, od = o(frames[g])
+            assert n2[f] == len(ok)
+            np.testing.assert_array_equal(d2[f, :len(ok)], od)
+            _, pd = o(frames[g - 1])
+            if len(od) and len(pd):
+                idx, best, sec = ol.match_top2(od, pd)
+                np.testing.assert_array_equal(m2[0, f, :len(od)], idx)
+                np.testing.assert_array_equal(m2[1, f, :len(od)], best)
+                np.testing.assert_array_equal(m2[2, f, :len(od)], sec)
+                checked += 1
+    assert checked >= 8
