@@ -157,7 +157,15 @@ def main():
         """The same step with every kernel alone on the chip: one extractor over all B frames, one launch per kernel, the match
         on the same stream.  Per-kernel roofline numbers come from here; in the timed region above the lanes co-run, so a
         kernel's duration there includes sharing the CUs with the kernels of the other lanes."""
-        ex1 = capi.ORBextractor(nfeatures=a.nfeatures, device=local_rank, max_batch=B)
+        keep = os.environ.get("ORBX_OVERLAP")
+        os.environ["ORBX_OVERLAP"] = "0"          # read by orbx_create: no blur side stream either, every kernel alone on the chip
+        try:
+            ex1 = capi.ORBextractor(nfeatures=a.nfeatures, device=local_rank, max_batch=B)
+        finally:
+            if keep is None:
+                del os.environ["ORBX_OVERLAP"]
+            else:
+                os.environ["ORBX_OVERLAP"] = keep
         main = torch.cuda.current_stream(dev)
         kps1 = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
         desc1 = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
@@ -210,14 +218,18 @@ def main():
         pipe_bytes = (a_extract + (a_match if do_match else 0)) * B
         step_ms = tmax / a.steps * 1e3
         pipe_gbs = pipe_bytes / (step_ms * 1e-3) / 1e9
-        traffic, valu_busy = None, None
+        traffic, valu_busy, valu_insts = None, None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")      # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("workload") == "vga_640x480_nf1000" and tj.get("batch") == B:
-                    traffic = tj.get("per_launch_bytes", {}).get(dom)
+                if tj.get("workload") == "vga_640x480_nf1000" and (w, h, a.nfeatures, a.family) == (640, 480, 1000, 1):
+                    if tj.get("batch") == B:
+                        traffic = tj.get("per_launch_bytes", {}).get(dom)
                     valu_busy = tj.get("sq_activity", {}).get(dom, {}).get("valu_busy")
+                    pf = tj.get("valu_wave_insts_per_frame", {})
+                    if pf and (not do_match or "match" in pf):
+                        valu_insts = {k: v for k, v in pf.items() if do_match or k != "match"}
             except Exception:
                 traffic = None
         out = {
@@ -256,6 +268,28 @@ def main():
                                   "ms_per_step": round(step_ms, 4), "kernel_ms_per_step_serial": round(kernel_ms, 4)},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
         }
+        if valu_insts:
+            # the resource that actually binds this integer path: VALU issue.  A wave64 op occupies one of the 1024 SIMDs for 4 cycles.
+            # Measured on gfx950 (tools/microbench/valu_rate): 2 cycles for mov/add/sub/and/or/xor/ashr, 4 for the rest; the kernels'
+            # mix is priced from their static opcode histograms (tools/valu_mix.py -> profiles/valu_mix.json), unmeasured opcodes at 2 (lo) / 4 (hi).
+            simd_cycles = 256 * 4 * 2.4e9
+            n_inst = sum(valu_insts.values())
+            ach = out["value"] / world * n_inst
+            rv = {"bound": "valu_issue", "achieved": round(ach / 1e9, 2), "unit": "G wave-insts/s", "wave_insts_per_frame": round(n_inst),
+                  "peak_if_every_inst_took_4_cycles": round(simd_cycles / 4 / 1e9, 2), "frac_if_every_inst_took_4_cycles": round(ach / (simd_cycles / 4), 4),
+                  "source": "SQ_INSTS_VALU of every kernel of the step per frame (rocprofv3 --pmc pass, profiles/traffic.json) x measured frames/s per GPU"}
+            try:
+                mix = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))["kernels"]
+                lo = sum(v * mix[k]["cycles_per_inst_lo"] for k, v in valu_insts.items())
+                hi = sum(v * mix[k]["cycles_per_inst_hi"] for k, v in valu_insts.items())
+                rv.update({"peak": round(simd_cycles / (lo / n_inst) / 1e9, 2), "frac": round(out["value"] / world * lo / simd_cycles, 4),
+                           "frac_range": [round(out["value"] / world * lo / simd_cycles, 4), round(out["value"] / world * hi / simd_cycles, 4)],
+                           "cycles_per_inst_range": [round(lo / n_inst, 3), round(hi / n_inst, 3)],
+                           "pricing": "2 cycles per wave64 inst for mov/add/sub/and/or/xor/ashr/fma_f32, 4 for every other measured opcode "
+                                      "(profiles/r01_valu_issue_rates.txt), static opcode mix per kernel (profiles/valu_mix.json); peak and frac use the low end"})
+            except Exception:
+                pass
+            out["roofline_valu"] = rv
         if a.region_timing:
             out["stage_ms_per_launch_timed_region"] = {k: round(v, 4) for k, v in region_ms.items()}
         if world == 1 and not a.no_cpu_baseline:

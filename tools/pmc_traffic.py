@@ -41,7 +41,16 @@ if len(sys.argv) > 5:
             valu[stage] = {"valu_busy": round(sum(busy[k]) / len(busy[k]) * 4 / (cyc * 1024), 3),       # quad-cycles -> SIMD cycles, 1024 SIMDs
                            "lds_busy": round(sum(lds[k]) / len(lds[k]) / (cyc * 256), 3) if k in lds else None,
                            "valu_wave_insts_per_launch": int(sum(insts[k]) / len(insts[k])) if k in insts else None}
-json.dump({"workload": "vga_640x480_nf1000", "batch": batch, "sq_activity": valu, "per_launch_bytes": per_launch, "detail": detail,
+# wave-level VALU instructions per FRAME (all dispatches of a kernel in the SQ pass / the frames that pass processed): the
+# instruction-issue roofline of bench.py (`roofline_valu`): 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 op = 6.144e11 wave-insts/s
+per_frame = {}
+if len(sys.argv) > 5:
+    sq_batch = int(sys.argv[6]) if len(sys.argv) > 6 else 256
+    frames = len(insts.get("k_fast_cells", [])) * sq_batch
+    if frames:
+        per_frame = {STAGE[k]: round(sum(v) / frames, 1) for k, v in insts.items() if k in STAGE}
+json.dump({"workload": "vga_640x480_nf1000", "batch": batch, "sq_activity": valu, "valu_wave_insts_per_frame": per_frame,
+           "per_launch_bytes": per_launch, "detail": detail,
            "read_correction": "none applied (4 B/lane and 1 B/lane accesses; the guide's x2 applies to 16 B/lane reads)",
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py"}, open(out, "w"), indent=1)
 print(json.dumps(per_launch))
