@@ -141,6 +141,18 @@ int orbx_device_free(int device, void* d_ptr);
 int orbx_device_upload(int device, void* d_dst, const void* src, size_t bytes);
 int orbx_device_download(int device, void* dst, const void* d_src, size_t bytes);      /* waits for all queued work of the device */
 
+/* Stream / event helpers in the same spirit (opaque HIP handles): what a host needs to run several extractor handles
+ * concurrently and order them against each other — the lanes of orb_slam_amd/cpp/LanePipeline.h — without HIP headers. */
+int orbx_stream_create(int device, void** stream);                  /* a non-blocking stream */
+int orbx_stream_create_priority(int device, int priority, void** stream);   /* hipStreamCreateWithPriority(non-blocking, priority) */
+int orbx_stream_destroy(int device, void* stream);
+int orbx_stream_synchronize(int device, void* stream);              /* stream == NULL: everything queued on the device */
+int orbx_event_create(int device, void** event);                    /* ordering only (no timing) */
+int orbx_event_destroy(int device, void* event);
+int orbx_event_record(void* event, void* stream);
+int orbx_stream_wait_event(void* stream, void* event);
+int orbx_device_copy_async(void* d_dst, const void* d_src, size_t bytes, void* stream);    /* device to device */
+
 /* MapPoint::ComputeDistinctiveDescriptors for M map points at once (src/MapPoint.cc:216-244): point p owns the descriptors
  * [seg_off[p], seg_off[p+1]) of `desc`; best_idx[p] = the index INSIDE its segment of the descriptor whose sorted row of
  * distances (self included) has the smallest element at position (int)(0.5*(N-1)) — first such row on ties —, best_median[p]

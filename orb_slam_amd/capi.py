@@ -27,7 +27,9 @@ EXPORTS = [
     "orbx_max_keypoints", "orbx_last_error", "orbx_extract", "orbx_extract_batch_device",
     "orbm_hamming256", "orbm_match_top2", "orbm_match_top2_device", "orbm_match_top2_batch_device",
     "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbm_distinctive", "orbm_distinctive_device",
-    "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_device_download", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
+    "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_device_download",
+    "orbx_stream_create", "orbx_stream_create_priority", "orbx_stream_destroy", "orbx_stream_synchronize", "orbx_event_create", "orbx_event_destroy", "orbx_event_record",
+    "orbx_stream_wait_event", "orbx_device_copy_async", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
     "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element", "orbx_debug_geometry",
 ]
 # include/orbf.h (Frame-side steps: undistortion, search grid, window query)
@@ -578,6 +580,19 @@ def agreement_batch_device(d_match12, d_n1, cap1, d_match21, d_n2, cap2, nproble
     rc = lib().orbs_agreement_batch_device(d_match12, d_n1, cap1, d_match21, d_n2, cap2, nproblems, d_out12, d_nfound, stream or None)
     if rc != ORBX_OK:
         raise OrbxError(rc, "orbs_agreement_batch_device")
+
+
+def stream_create(device=0):
+    """a raw non-blocking HIP stream (address) from the C ABI: creation order is under the caller's control"""
+    p = ctypes.c_void_p()
+    rc = lib().orbx_stream_create(device, ctypes.byref(p))
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbx_stream_create")
+    return p.value
+
+
+def stream_destroy(device, stream):
+    lib().orbx_stream_destroy(device, ctypes.c_void_p(stream))
 
 
 def bow_ranges_batch_device(d_fvq_node, d_fvq_off, d_nfv_q, d_fvt_node, d_fvt_off, d_nfv_t, cap, nproblems, d_qrange, d_nq, stream=0):

@@ -458,4 +458,62 @@ int orbx_device_download(int device, void* dst, const void* d_src, size_t bytes)
     return hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
 
+int orbx_stream_create(int device, void** stream) {
+    if (!stream) return ORBX_ERR_ARG;
+    hipStream_t s = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return ORBX_ERR_DEVICE;
+    *stream = s;
+    return ORBX_OK;
+}
+
+int orbx_stream_create_priority(int device, int priority, void** stream) {
+    if (!stream) return ORBX_ERR_ARG;
+    hipStream_t s = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority) != hipSuccess) return ORBX_ERR_DEVICE;
+    *stream = s;
+    return ORBX_OK;
+}
+
+int orbx_stream_destroy(int device, void* stream) {
+    if (!stream) return ORBX_OK;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbx_stream_synchronize(int device, void* stream) {
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    const hipError_t e = stream ? hipStreamSynchronize((hipStream_t)stream) : hipDeviceSynchronize();
+    return e == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbx_event_create(int device, void** event) {
+    if (!event) return ORBX_ERR_ARG;
+    hipEvent_t e = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return ORBX_ERR_DEVICE;
+    *event = e;
+    return ORBX_OK;
+}
+
+int orbx_event_destroy(int device, void* event) {
+    if (!event) return ORBX_OK;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    return hipEventDestroy((hipEvent_t)event) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbx_event_record(void* event, void* stream) {
+    if (!event) return ORBX_ERR_ARG;
+    return hipEventRecord((hipEvent_t)event, (hipStream_t)stream) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbx_stream_wait_event(void* stream, void* event) {
+    if (!event) return ORBX_ERR_ARG;
+    return hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbx_device_copy_async(void* d_dst, const void* d_src, size_t bytes, void* stream) {
+    if (bytes == 0) return ORBX_OK;
+    if (!d_dst || !d_src) return ORBX_ERR_ARG;
+    return hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
 }  // extern "C"

@@ -12,10 +12,10 @@ from . import capi
 class _Lane:
     """One contiguous b-frame slice of every step.  Slot 0 of desc / n holds the frame before the slice."""
 
-    def __init__(self, nfeatures, device, b, extractor_kw):
+    def __init__(self, ex, device, b, stream):
         dev = torch.device("cuda", device)
-        self.ex = capi.ORBextractor(nfeatures=nfeatures, device=device, max_batch=b, **extractor_kw)
-        self.stream = torch.cuda.Stream(dev)
+        self.ex = ex
+        self.stream = stream
         cap = self.ex.max_keypoints
         self.kps = torch.zeros((b, cap, 7), dtype=torch.float32, device=dev)
         self.desc = torch.zeros((b + 1, cap, 32), dtype=torch.uint8, device=dev)
@@ -36,7 +36,18 @@ class LanePipeline:
             G -= 1
         self.w, self.h, self.B, self.G, self.b = width, height, batch, G, batch // G
         self.do_match = do_match
-        self.lanes = [_Lane(nfeatures, device, self.b, extractor_kw) for _ in range(G)]
+        # Stream placement.  The HIP runtime binds a stream to one of its hardware queues (GPU_MAX_HW_QUEUES, 4 by default) when the
+        # stream is created: new queues until 4 exist, then the least-loaded one.  Streams on one hardware queue are launched in
+        # order.  Measured best (rocprofv3 Queue_Id column): every lane stream on a hardware queue of its own, the
+        # blur side streams (created inside the extractor handles) sharing those queues.  Creating the G handles first and the G
+        # lane streams after them, back to back, gives that placement; the other way round two lanes share a queue and the gain
+        # of the lanes is lost.  Raw HIP streams from the C ABI (torch creates its pool streams lazily, i.e. in an order of its own).
+        dev = torch.device("cuda", device)
+        handles = [capi.ORBextractor(nfeatures=nfeatures, device=device, max_batch=self.b, **extractor_kw) for _ in range(G)]
+        self._raw_streams = [capi.stream_create(device) for _ in range(G)]
+        streams = [torch.cuda.ExternalStream(p, device=dev) for p in self._raw_streams]
+        self.lanes = [_Lane(handles[g], device, self.b, streams[g]) for g in range(G)]
+        self.device = device
         self.cap = self.lanes[0].ex.max_keypoints
         self.steps_done = 0
         self.match_events = []
@@ -116,5 +127,9 @@ class LanePipeline:
         return stage
 
     def close(self):
+        torch.cuda.synchronize(self.device)
         for ln in self.lanes:
             ln.ex.close()
+        for p in self._raw_streams:
+            capi.stream_destroy(self.device, p)
+        self._raw_streams = []

@@ -63,3 +63,36 @@ def test_lanes_pipeline_equals_one_stream_and_oracle(lanes):
                 np.testing.assert_array_equal(m2[2, f, :len(od)], sec)
                 checked += 1
     assert checked >= 8
+
+
+def test_cpp_lane_pipeline(tmp_path):
+    """orb_slam_amd/cpp/LanePipeline.h (plain C++ over the C ABI, no HIP headers): the example runs the same frames through 4 lanes
+    and through one, checks them byte-identical itself, and its dump of the last step equals the Python pipeline's"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "orb_slam_amd", "cpp", "example_lanes")
+    assert os.path.exists(exe), "run make"
+    B, w, h, nf, steps = 24, 320, 240, 300, 4
+    frames = np.concatenate([synth.frames(w, h, synth.BLOCKS, 40, 60), synth.frames(w, h, synth.NOISE, 90, 20), synth.frames(w, h, synth.LOWTEX, 7, 16)])
+    raw, out = tmp_path / "frames.raw", tmp_path / "out.bin"
+    raw.write_bytes(frames.tobytes())
+    res = subprocess.run([exe, str(w), str(h), str(B), str(steps), "4", str(raw), str(out)], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, EXAMPLE_NFEATURES=str(nf)))
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "IDENTICAL" in res.stdout and "lanes 4 x 6 frames" in res.stdout
+    blob = out.read_bytes()
+    hdr = np.frombuffer(blob, np.int32, 4)
+    assert hdr[0] == B and hdr[2] == 28
+    cap = int(hdr[1])
+    o = 16
+    n = np.frombuffer(blob, np.int32, B, o); o += 4 * B
+    kps = np.frombuffer(blob, np.uint8, B * cap * 28, o).reshape(B, cap, 28); o += B * cap * 28
+    desc = np.frombuffer(blob, np.uint8, B * cap * 32, o).reshape(B, cap, 32); o += B * cap * 32
+    match = np.frombuffer(blob, np.int32, 3 * B * cap, o).reshape(3, B, cap)
+    i, n2, k2, d2, m2 = _run(frames, B, 4, nf, steps)[-1]
+    assert i == steps - 1 and cap == k2.shape[1]
+    np.testing.assert_array_equal(n, n2)
+    for f in range(B):
+        assert kps[f, :n[f]].tobytes() == k2[f, :n[f]].tobytes(), f
+        assert desc[f, :n[f]].tobytes() == d2[f, :n[f]].tobytes(), f
+        np.testing.assert_array_equal(match[:, f, :n[f]], m2[:, f, :n[f]], err_msg="frame %d" % f)
