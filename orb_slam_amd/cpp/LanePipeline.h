@@ -13,7 +13,6 @@
 
 #include <cstddef>
 #include <cstdint>
-#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
