@@ -129,15 +129,13 @@ def main():
         step(i, False)
     torch.cuda.synchronize(dev)
     pipe.stage_timing(2 if a.region_timing else 0)
-    if dist is not None:
-        dist.barrier()
+    dist_util.barrier(dist, a.backend, local_rank)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i, a.region_timing)
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+    dist_util.barrier(dist, a.backend, local_rank)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
 

@@ -17,11 +17,20 @@ def init(backend, world, rank, local_rank=0):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    kw = {}
-    if backend == "nccl":
-        kw["device_id"] = torch.device("cuda", local_rank)
-    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    # No device_id here: with it torch builds the RCCL communicator (and RCCL its streams) eagerly, BEFORE the pipeline creates
+    # its lane streams, and the runtime's stream -> hardware-queue placement the lanes rely on would shift.
+    # The communicator is built lazily at the first collective instead: the barrier in front of the timed region.
+    dist.init_process_group(backend, rank=rank, world_size=world)
     return dist
+
+
+def barrier(dist, backend, local_rank=0):
+    if dist is None:
+        return
+    if backend == "nccl":
+        dist.barrier(device_ids=[local_rank])
+    else:
+        dist.barrier()
 
 
 def stream_first_index(rank, ring):
