@@ -68,6 +68,7 @@ public:
                 check(orbx_event_create(device_, &L.h_consumed[s]), "orbx_event_create");
             }
         }
+        check(orbx_stream_synchronize(device_, nullptr), "orbx_stream_synchronize");   // the zero-fills of the allocations are done
     }
 
     ~LanePipeline() {

@@ -51,6 +51,7 @@ class LanePipeline:
         self.cap = self.lanes[0].ex.max_keypoints
         self.steps_done = 0
         self.match_events = []
+        torch.cuda.synchronize(dev)      # the zero-fills above ran on the default stream; the lane streams do not wait for it
 
     def step(self, d_frames_ptr, frame_stride=None, row_stride=None, timed=False):
         """d_frames_ptr: device address of the step's first frame (B frames, frame_stride bytes apart).  Asynchronous: lane g
