@@ -20,89 +20,111 @@ ap.add_argument("--nfeatures", type=int, default=1000)
 ap.add_argument("--batch", type=int, default=512); ap.add_argument("--ring", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--window", type=float, default=100.0)
 ap.add_argument("--voc-k", type=int, default=10); ap.add_argument("--voc-l", type=int, default=6)
+ap.add_argument("--lanes", type=int, default=4, help="the step's frames go through this many free-running lanes (own handles + stream each, DESIGN.md §4.5)")
 a = ap.parse_args()
 B, w, h = a.batch, a.w, a.h
+G = max(1, min(a.lanes, B))
+while B % G:
+    G -= 1
+b = B // G
 frames = synth.frames(w, h, synth.BLOCKS, 0, a.ring)
 d_img = torch.from_numpy(frames).cuda()
-ex = capi.ORBextractor(nfeatures=a.nfeatures, max_batch=B)
-cap = ex.max_keypoints
 voc = synth.vocabulary(a.voc_k, a.voc_l, seed=1)
-V = capi.ORBVocabulary.from_nodes(a.voc_k, a.voc_l, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
 cam = capi.Camera.make(517.3, 516.5, 318.6, 255.3, (0.2624, -0.9531, -0.0054, 0.0026), w, h)
 bounds = capi.image_bounds(cam)
 dev = "cuda"
 i32, u8, f32, f64 = torch.int32, torch.uint8, torch.float32, torch.float64
-# two generations of frame state (t and t-1)
-S = [dict(kps=torch.zeros((B, cap, 7), dtype=f32, device=dev), desc=torch.zeros((B, cap, 32), dtype=u8, device=dev),
-          n=torch.zeros(B, dtype=i32, device=dev), un=torch.zeros((B, cap, 7), dtype=f32, device=dev),
-          off=torch.zeros((B, capi.GRID_CELLS + 1), dtype=i32, device=dev), feat=torch.zeros((B, cap), dtype=i32, device=dev)) for _ in range(2)]
-bow_id = torch.zeros((B, cap), dtype=i32, device=dev); bow_val = torch.zeros((B, cap), dtype=f64, device=dev)
-fv_node = torch.zeros((B, cap), dtype=i32, device=dev); fv_off = torch.zeros((B, cap + 1), dtype=i32, device=dev)
-fv_feat = torch.zeros((B, cap), dtype=i32, device=dev); cnt = torch.zeros((2, B), dtype=i32, device=dev)
-qxyr = torch.zeros((B, cap, 3), dtype=f32, device=dev); qlev = torch.zeros((B, cap, 2), dtype=i32, device=dev)
-qang = torch.zeros((B, cap), dtype=f32, device=dev)
-q2t = torch.zeros((B, cap), dtype=i32, device=dev); t2q = torch.zeros((B, cap), dtype=i32, device=dev)
-best = torch.zeros((B, cap), dtype=i32, device=dev); second = torch.zeros((B, cap), dtype=i32, device=dev)
-nm = torch.zeros(B, dtype=i32, device=dev)
-m_idx = torch.zeros((B, cap), dtype=i32, device=dev); m_best = torch.zeros((B, cap), dtype=i32, device=dev); m_sec = torch.zeros((B, cap), dtype=i32, device=dev)
-st = torch.cuda.current_stream().cuda_stream
 names = ["extract", "undistort_grid", "bow", "query_setup", "window_search", "dense_match"]
 acc = {k: 0.0 for k in names}
+# handles first, then the lane streams back to back (stream -> hardware queue placement)
+exs = [capi.ORBextractor(nfeatures=a.nfeatures, max_batch=b) for _ in range(G)]
+vocs = [capi.ORBVocabulary.from_nodes(a.voc_k, a.voc_l, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"]) for _ in range(G)]   # a handle owns scratch
+raw = [capi.stream_create(0) for _ in range(G)]
+cap = exs[0].max_keypoints
 
 
-def step(i, timed):
-    cur, prev = S[i & 1], S[(i + 1) & 1]
-    f0 = (i * B) % (a.ring - B + 1)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
-    ev[0].record()
-    ex.extract_batch_device(d_img.data_ptr() + f0 * w * h, B, w, h, w, w * h, cur["kps"].data_ptr(), cur["desc"].data_ptr(), cur["n"].data_ptr(), cap, 0, st)
-    ev[1].record()
-    capi.undistort_grid_batch_device(cam, bounds, cur["kps"].data_ptr(), cur["n"].data_ptr(), B, cap, cur["un"].data_ptr(), cur["off"].data_ptr(),
-                                     cur["feat"].data_ptr(), st)
-    ev[2].record()
-    V.transform_batch_device(cur["desc"].data_ptr(), cur["n"].data_ptr(), B, cap, 4, bow_id.data_ptr(), bow_val.data_ptr(), cnt[0].data_ptr(),
-                             fv_node.data_ptr(), fv_off.data_ptr(), fv_feat.data_ptr(), cnt[1].data_ptr(), st)
-    ev[3].record()
-    # WindowSearch(last, current, window, ..): queries = the previous frame's undistorted keypoints at their own level
-    qxyr[:, :, 0:2] = prev["un"][:, :, 0:2]
-    qxyr[:, :, 2] = a.window
-    oct_prev = prev["un"][:, :, 5].view(i32)
-    qlev[:, :, 0] = oct_prev
-    qlev[:, :, 1] = oct_prev
-    qang.copy_(prev["un"][:, :, 3])
-    ev[4].record()
-    capi.window_search_batch_device(bounds, capi.RULE_WINDOW, capi.TH_HIGH, 0.8, True, cur["un"].data_ptr(), cur["desc"].data_ptr(), cur["off"].data_ptr(),
-                                    cur["feat"].data_ptr(), cur["n"].data_ptr(), cap, 0, qxyr.data_ptr(), qlev.data_ptr(), prev["desc"].data_ptr(),
-                                    qang.data_ptr(), 0, prev["n"].data_ptr(), cap, B, q2t.data_ptr(), t2q.data_ptr(), best.data_ptr(), second.data_ptr(),
-                                    nm.data_ptr(), st)
-    ev[5].record()
-    capi.match_top2_batch_device(cur["desc"].data_ptr(), cur["n"].data_ptr(), prev["desc"].data_ptr(), prev["n"].data_ptr(), B, cap, m_idx.data_ptr(),
-                                 m_best.data_ptr(), m_sec.data_ptr(), st)
-    ev[6].record()
-    if timed:
-        torch.cuda.synchronize()
-        for j, k in enumerate(names):
-            acc[k] += ev[j].elapsed_time(ev[j + 1])
+class Lane:
+    """b consecutive frames of every step: frame t is searched / matched against the same slot of the previous step"""
+    def __init__(self, g):
+        self.g, self.ex, self.V = g, exs[g], vocs[g]
+        self.stream = torch.cuda.ExternalStream(raw[g], device=torch.device("cuda", 0))
+        z = lambda *shape, dt=i32: torch.zeros(shape, dtype=dt, device=dev)
+        self.S = [dict(kps=z(b, cap, 7, dt=f32), desc=z(b, cap, 32, dt=u8), n=z(b), un=z(b, cap, 7, dt=f32), off=z(b, capi.GRID_CELLS + 1), feat=z(b, cap))
+                  for _ in range(2)]
+        self.bow_id, self.bow_val = z(b, cap), z(b, cap, dt=f64)
+        self.fv_node, self.fv_off, self.fv_feat, self.cnt = z(b, cap), z(b, cap + 1), z(b, cap), z(2, b)
+        self.qxyr, self.qlev, self.qang = z(b, cap, 3, dt=f32), z(b, cap, 2), z(b, cap, dt=f32)
+        self.q2t, self.t2q, self.best, self.second, self.nm = z(b, cap), z(b, cap), z(b, cap), z(b, cap), z(b)
+        self.m_idx, self.m_best, self.m_sec = z(b, cap), z(b, cap), z(b, cap)
+
+    def step(self, i, timed):
+        cur, prev = self.S[i & 1], self.S[(i + 1) & 1]
+        f0 = (i * B) % (a.ring - B + 1) + self.g * b
+        s = self.stream
+        st = s.cuda_stream
+        with torch.cuda.stream(s):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] if timed else None
+            mark = (lambda j: ev[j].record(s)) if timed else (lambda j: None)
+            mark(0)
+            self.ex.extract_batch_device(d_img.data_ptr() + f0 * w * h, b, w, h, w, w * h, cur["kps"].data_ptr(), cur["desc"].data_ptr(), cur["n"].data_ptr(), cap, 0, st)
+            mark(1)
+            capi.undistort_grid_batch_device(cam, bounds, cur["kps"].data_ptr(), cur["n"].data_ptr(), b, cap, cur["un"].data_ptr(), cur["off"].data_ptr(),
+                                             cur["feat"].data_ptr(), st)
+            mark(2)
+            self.V.transform_batch_device(cur["desc"].data_ptr(), cur["n"].data_ptr(), b, cap, 4, self.bow_id.data_ptr(), self.bow_val.data_ptr(), self.cnt[0].data_ptr(),
+                                          self.fv_node.data_ptr(), self.fv_off.data_ptr(), self.fv_feat.data_ptr(), self.cnt[1].data_ptr(), st)
+            mark(3)
+            # WindowSearch(last, current, window, ..): queries = the previous frame's undistorted keypoints at their own level
+            self.qxyr[:, :, 0:2] = prev["un"][:, :, 0:2]
+            self.qxyr[:, :, 2] = a.window
+            oct_prev = prev["un"][:, :, 5].view(i32)
+            self.qlev[:, :, 0] = oct_prev
+            self.qlev[:, :, 1] = oct_prev
+            self.qang.copy_(prev["un"][:, :, 3])
+            mark(4)
+            capi.window_search_batch_device(bounds, capi.RULE_WINDOW, capi.TH_HIGH, 0.8, True, cur["un"].data_ptr(), cur["desc"].data_ptr(), cur["off"].data_ptr(),
+                                            cur["feat"].data_ptr(), cur["n"].data_ptr(), cap, 0, self.qxyr.data_ptr(), self.qlev.data_ptr(), prev["desc"].data_ptr(),
+                                            self.qang.data_ptr(), 0, prev["n"].data_ptr(), cap, b, self.q2t.data_ptr(), self.t2q.data_ptr(), self.best.data_ptr(),
+                                            self.second.data_ptr(), self.nm.data_ptr(), st)
+            mark(5)
+            capi.match_top2_batch_device(cur["desc"].data_ptr(), cur["n"].data_ptr(), prev["desc"].data_ptr(), prev["n"].data_ptr(), b, cap, self.m_idx.data_ptr(),
+                                         self.m_best.data_ptr(), self.m_sec.data_ptr(), st)
+            mark(6)
+        if timed:
+            torch.cuda.synchronize()      # stage times: this lane alone on the chip
+            for j, k in enumerate(names):
+                acc[k] += ev[j].elapsed_time(ev[j + 1])
+
+
+lanes = [Lane(g) for g in range(G)]
+torch.cuda.synchronize()
+
+
+def step(i, timed=False):
+    for ln in lanes:
+        ln.step(i, timed)
 
 
 for i in range(3):
-    step(i, False)
+    step(i)
 torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
+import time  # noqa: E402
+t0 = time.perf_counter()
 for i in range(3, 3 + a.steps):
-    step(i, False)
-e1.record()
+    step(i)
 torch.cuda.synchronize()
-total_ms = e0.elapsed_time(e1) / a.steps
+total_ms = (time.perf_counter() - t0) * 1e3 / a.steps
 for i in range(3 + a.steps, 3 + 2 * a.steps):
     step(i, True)
+cat = lambda f: torch.cat([f(ln) for ln in lanes])
 out = {"metric": "frontend_frames_per_s", "value": round(B / (total_ms * 1e-3), 1), "unit": "frames/s", "ms_per_step": round(total_ms, 4),
-       "config": {"workload": "%dx%d, %d kp, batch %d: extract + undistort/grid + BoW(k=%d,L=%d) + WindowSearch(r=%g, rot) + dense top-2" %
-                  (w, h, a.nfeatures, B, a.voc_k, a.voc_l, a.window)},
+       "config": {"workload": "%dx%d, %d kp, %d frames per step in %d lanes: extract + undistort/grid + BoW(k=%d,L=%d) + WindowSearch(r=%g, rot) + dense top-2" %
+                  (w, h, a.nfeatures, B, G, a.voc_k, a.voc_l, a.window), "lanes": G},
        "stage_ms_per_step": {k: round(v / a.steps, 4) for k, v in acc.items()},
-       "mean_keypoints": round(float(S[0]["n"].float().mean().item()), 1), "mean_window_matches": round(float(nm.float().mean().item()), 1),
-       "mean_bow_words": round(float(cnt[0].float().mean().item()), 1)}
+       "stage_timing": "every lane's stages alone on the chip (a serial pass after the timed loop), summed over the lanes",
+       "mean_keypoints": round(float(cat(lambda ln: ln.S[0]["n"]).float().mean().item()), 1),
+       "mean_window_matches": round(float(cat(lambda ln: ln.nm).float().mean().item()), 1),
+       "mean_bow_words": round(float(cat(lambda ln: ln.cnt[0]).float().mean().item()), 1)}
 # the same chain on one host core through the CPU oracle (test infrastructure), a bounded sample of frames
 if os.environ.get("FRONTEND_CPU", "1") != "0":
     import time
