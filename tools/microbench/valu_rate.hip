@@ -10,7 +10,7 @@
     asm volatile(OP(%0) OP(%1) OP(%2) OP(%3) OP(%4) OP(%5) OP(%6) OP(%7)                                        \
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)             \
                  : "v"(b), "v"(c), "s"(m)                                                                         \
-                 : "vcc");
+                 : "vcc", "s20", "s21");
 
 #define KERNEL(NAME, OP)                                                                                          \
     __global__ __launch_bounds__(256) void NAME(unsigned* out, int iters) {                                      \
@@ -59,6 +59,26 @@
 KERNEL(k_mov, OP_MOV) KERNEL(k_cnd, OP_CND) KERNEL(k_dot2, OP_DOT2) KERNEL(k_lshlor, OP_LSHLOR) KERNEL(k_ashr, OP_ASHR) KERNEL(k_add3, OP_ADD3)
 KERNEL(k_mini, OP_MINI) KERNEL(k_sub, OP_SUB) KERNEL(k_bfe, OP_BFE) KERNEL(k_and, OP_AND) KERNEL(k_or, OP_OR) KERNEL(k_lshladd, OP_LSHLADD)
 KERNEL(k_cmp, OP_CMP) KERNEL(k_mul24, OP_MUL24) KERNEL(k_or3, OP_OR3)
+#define OP_LSHR(x) "v_lshrrev_b32 " #x ", 1, " #x "\n"
+#define OP_MULF(x) "v_mul_f32 " #x ", " #x ", %8\n"
+#define OP_ADDF(x) "v_add_f32 " #x ", " #x ", %8\n"
+#define OP_CVTFI(x) "v_cvt_f32_i32 " #x ", " #x "\n"
+#define OP_CVTIF(x) "v_cvt_i32_f32 " #x ", " #x "\n"
+#define OP_RNDNE(x) "v_rndne_f32 " #x ", " #x "\n"
+#define OP_UBYTE(x) "v_cvt_f32_ubyte0 " #x ", " #x "\n"
+#define OP_DPP(x) "v_mov_b32_dpp " #x ", " #x " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define OP_ANDSDWA(x) "v_and_b32_sdwa " #x ", " #x ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n"
+#define OP_MINSDWA(x) "v_min_u32_sdwa " #x ", " #x ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n"
+#define OP_ADDSDWA(x) "v_add_u32_sdwa " #x ", " #x ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
+#define OP_MED3(x) "v_med3_u32 " #x ", " #x ", %8, %9\n"
+#define OP_BFEI(x) "v_bfe_i32 " #x ", " #x ", 3, 8\n"
+#define OP_RFL(x) "v_readfirstlane_b32 s20, " #x "\n"
+#define OP_CMPS(x) "v_cmp_lt_i32_e64 s[20:21], " #x ", %8\n"
+#define OP_MULHI(x) "v_mul_hi_u32 " #x ", " #x ", %8\n"
+#define OP_NOT(x) "v_not_b32 " #x ", " #x "\n"
+KERNEL(k_lshr, OP_LSHR) KERNEL(k_mulf, OP_MULF) KERNEL(k_addf, OP_ADDF) KERNEL(k_cvtfi, OP_CVTFI) KERNEL(k_cvtif, OP_CVTIF) KERNEL(k_rndne, OP_RNDNE)
+KERNEL(k_ubyte, OP_UBYTE) KERNEL(k_dpp, OP_DPP) KERNEL(k_andsdwa, OP_ANDSDWA) KERNEL(k_minsdwa, OP_MINSDWA) KERNEL(k_addsdwa, OP_ADDSDWA) KERNEL(k_med3, OP_MED3)
+KERNEL(k_bfei, OP_BFEI) KERNEL(k_rfl, OP_RFL) KERNEL(k_cmps, OP_CMPS) KERNEL(k_mulhi, OP_MULHI) KERNEL(k_not, OP_NOT)
 KERNEL(k_xor, OP_XOR) KERNEL(k_add, OP_ADD) KERNEL(k_and_or, OP_AND_OR) KERNEL(k_min, OP_MIN) KERNEL(k_shl, OP_SHL)
 KERNEL(k_bcnt, OP_BCNT) KERNEL(k_perm, OP_PERM) KERNEL(k_dot4, OP_DOT4) KERNEL(k_align, OP_ALIGN) KERNEL(k_mullo, OP_MULLO)
 KERNEL(k_mad24, OP_MAD24) KERNEL(k_sad, OP_SAD) KERNEL(k_fma, OP_FMA) KERNEL(k_cmpcnd, OP_CMPCND) KERNEL(k_max3, OP_MAX3) KERNEL(k_xad, OP_XAD)
@@ -78,7 +98,11 @@ int main() {
         {"v_cmp+v_cndmask", k_cmpcnd, 2}, {"v_max3_u32", k_max3, 1}, {"v_xad_u32", k_xad, 1},
         {"v_mov_b32", k_mov, 1}, {"v_cndmask_b32", k_cnd, 1}, {"v_dot2_u32_u16", k_dot2, 1}, {"v_lshl_or_b32", k_lshlor, 1}, {"v_ashrrev_i32", k_ashr, 1},
         {"v_add3_u32", k_add3, 1}, {"v_min_i32", k_mini, 1}, {"v_sub_u32", k_sub, 1}, {"v_bfe_u32", k_bfe, 1}, {"v_and_b32", k_and, 1}, {"v_or_b32", k_or, 1},
-        {"v_lshl_add_u32", k_lshladd, 1}, {"v_cmp_lt_i32", k_cmp, 1}, {"v_mul_i32_i24", k_mul24, 1}, {"v_or3_b32", k_or3, 1}};
+        {"v_lshl_add_u32", k_lshladd, 1}, {"v_cmp_lt_i32", k_cmp, 1}, {"v_mul_i32_i24", k_mul24, 1}, {"v_or3_b32", k_or3, 1},
+        {"v_lshrrev_b32", k_lshr, 1}, {"v_mul_f32", k_mulf, 1}, {"v_add_f32", k_addf, 1}, {"v_cvt_f32_i32", k_cvtfi, 1}, {"v_cvt_i32_f32", k_cvtif, 1},
+        {"v_rndne_f32", k_rndne, 1}, {"v_cvt_f32_ubyte0", k_ubyte, 1}, {"v_mov_b32_dpp row_shr", k_dpp, 1}, {"v_and_b32_sdwa WORD_1", k_andsdwa, 1},
+        {"v_min_u32_sdwa WORD_1", k_minsdwa, 1}, {"v_add_u32_sdwa BYTE_1", k_addsdwa, 1}, {"v_med3_u32", k_med3, 1}, {"v_bfe_i32", k_bfei, 1},
+        {"v_readfirstlane_b32", k_rfl, 1}, {"v_cmp_lt_i32 -> sgpr pair", k_cmps, 1}, {"v_mul_hi_u32", k_mulhi, 1}, {"v_not_b32", k_not, 1}};
     const int iters = 1000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);

@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """VALU issue cost of the hot kernels' instruction mix (no GPU needed): compiles the kernels to gfx950 assembly, takes the static
 histogram of VALU opcodes per kernel and prices every opcode with the issue cost measured by tools/microbench/valu_rate on an
-MI355X (profiles/r01_valu_issue_rates.txt): 2 cycles per wave64 instruction for the plain VOP2 integer ops (mov, add, sub, and,
-or, xor, ashr) and v_fma_f32, 4 cycles for everything else measured (min/max, compares, cndmask, left shifts, bfe, perm,
-alignbyte, bcnt, dot2/dot4, sad, 24/32-bit multiplies and every three-operand fused op).  Unmeasured opcodes are priced at both
+MI355X (profiles/r01_valu_issue_rates.txt): 2 cycles per wave64 instruction for the plain VOP1/VOP2 ops (mov, not, add, sub, and,
+or, xor, right shifts, f32 add/mul/fma), 4 cycles for everything else measured (min/max/med3, compares, cndmask, left shift, bfe,
+perm, alignbyte, bcnt, dot2/dot4, sad, integer multiplies, conversions, readfirstlane, every three-operand fused op and every
+SDWA / DPP form).  Unmeasured opcodes are priced at both
 ends (2 and 4) and give the [lo, hi] interval.  Writes profiles/valu_mix.json, read by bench.py for `roofline_valu`.
 The histogram is static (all code of the kernel counts once), so the result is an estimate of the dynamic mix."""
 import collections, json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAST = {"v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_ashrrev_i32", "v_fma_f32"}
+FAST = {"v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_ashrrev_i32", "v_lshrrev_b32",
+        "v_fma_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32"}
 SLOW = {"v_and_or_b32", "v_min_u32", "v_max_u32", "v_min_i32", "v_max_i32", "v_lshlrev_b32", "v_bcnt_u32_b32", "v_perm_b32", "v_dot4_u32_u8",
         "v_dot2_u32_u16", "v_alignbyte_b32", "v_mul_lo_u32", "v_mad_u32_u24", "v_mad_i32_i24", "v_sad_u8", "v_cndmask_b32", "v_max3_u32", "v_min3_u32",
-        "v_xad_u32", "v_lshl_or_b32", "v_add3_u32", "v_bfe_u32", "v_lshl_add_u32", "v_mul_i32_i24", "v_mul_u32_u24", "v_or3_b32"}
+        "v_xad_u32", "v_lshl_or_b32", "v_add3_u32", "v_bfe_u32", "v_bfe_i32", "v_lshl_add_u32", "v_mul_i32_i24", "v_mul_u32_u24", "v_or3_b32", "v_med3_u32",
+        "v_med3_i32", "v_mul_hi_u32", "v_cvt_f32_i32", "v_cvt_i32_f32", "v_cvt_f32_u32", "v_cvt_u32_f32", "v_rndne_f32", "v_cvt_f32_ubyte0",
+        "v_cvt_f32_ubyte1", "v_cvt_f32_ubyte2", "v_cvt_f32_ubyte3", "v_readfirstlane_b32"}
 STAGE = {"k_resize<true>": "pyramid", "k_fast_cells<true, 256, 2, 256>": "fast_cells", "k_quota": "quota", "k_cell_select": "cell_select",
          "k_level_select": "level_select", "k_blur<true>": "blur", "k_describe": "describe", "k_match_batch<1>": "match"}
 hist = {}
@@ -32,7 +36,9 @@ with tempfile.TemporaryDirectory() as td:
                 cur = None
             m = re.match(r"^\s+(v_[a-z0-9_]+)", line)
             if m and cur:
-                op = re.sub(r"_(e32|e64|sdwa|dpp)$", "", m.group(1))
+                op = re.sub(r"_(e32|e64)$", "", m.group(1))
+                if op.endswith("_sdwa") or op.endswith("_dpp"):
+                    op = "sdwa/dpp form"            # measured: 4 cycles whatever the base opcode (v_mov_b32_dpp, v_and_b32_sdwa, v_add_u32_sdwa ...)
                 if op.startswith("v_cmp"):
                     op = "v_cmp"
                 hist.setdefault(cur, collections.Counter())[op] += 1
@@ -40,7 +46,7 @@ out = {"issue_cycles": {"fast_class": 2, "slow_class": 4, "measured_by": "tools/
 for st, h in hist.items():
     n = sum(h.values())
     fast = sum(c for o, c in h.items() if o in FAST)
-    slow = sum(c for o, c in h.items() if o in SLOW or o == "v_cmp")
+    slow = sum(c for o, c in h.items() if o in SLOW or o in ("v_cmp", "sdwa/dpp form"))
     unk = n - fast - slow
     out["kernels"][st] = {"static_valu_insts": n, "fast_frac": round(fast / n, 3), "slow_frac": round(slow / n, 3), "unmeasured_frac": round(unk / n, 3),
                           "cycles_per_inst_lo": round((2 * fast + 4 * slow + 2 * unk) / n, 3), "cycles_per_inst_hi": round((2 * fast + 4 * slow + 4 * unk) / n, 3),
