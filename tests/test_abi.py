@@ -152,6 +152,18 @@ def test_no_cpu_fallback_without_device():
     with pytest.raises(capi.OrbxError) as e:
         capi.match_top2(np.zeros((4, 32), np.uint8), np.zeros((4, 32), np.uint8))
     assert e.value.code == capi.ORBX_ERR_DEVICE
+    # the stream / event / device-memory helpers of the C ABI fail the same way (nothing is emulated on the host)
+    with pytest.raises(capi.OrbxError) as e:
+        capi.stream_create(0)
+    assert e.value.code == capi.ORBX_ERR_DEVICE
+    L = capi.lib()
+    p = ctypes.c_void_p()
+    assert L.orbx_event_create(0, ctypes.byref(p)) == capi.ORBX_ERR_DEVICE
+    assert L.orbx_stream_create_priority(0, 0, ctypes.byref(p)) == capi.ORBX_ERR_DEVICE
+    assert L.orbx_device_alloc(0, ctypes.c_size_t(64), ctypes.byref(p)) == capi.ORBX_ERR_DEVICE
+    with pytest.raises(capi.OrbxError) as e:         # the searches, too: argument checks pass, the launch cannot
+        capi.triangulation_search_batch_device(50, False, 8, np.ones(8, np.float32), 8, 8, 8, 8, 8, 4, 0, 8, 0, 8, 8, 0, 8, 4, 1, 8, 8, 0, 0, 8)
+    assert e.value.code == capi.ORBX_ERR_DEVICE
 
 
 def test_product_never_references_the_oracle():
