@@ -1,0 +1,128 @@
+// =====================================================================================
+// ORACLE SUPPORT — TEST INFRASTRUCTURE ONLY (never part of the product path).
+//
+// Stand-ins for the three classes /root/reference/include/ORBmatcher.h pulls in — MapPoint, KeyFrame, Frame — holding just
+// the members src/ORBmatcher.cc touches, as plain data.  This header is force-included (-include) in front of the reference's
+// ORBmatcher.cc and defines the reference headers' include guards, so the reference's OWN ORBmatcher.h (class declaration)
+// and ORBmatcher.cc (every search function, ComputeThreeMaxima, CheckDistEpipolarLine, DescriptorDistance) compile unmodified
+// against them, while MapPoint.h / KeyFrame.h / Frame.h (g2o, Boost, the whole SLAM graph) are skipped.
+// Frame::GetFeaturesInArea / KeyFrame::GetFeaturesInArea forward to the oracle's restatement of src/Frame.cc:200-265
+// (oracle/frame_oracle.cpp) — the candidate windows are therefore the restated ones; what is pinned is everything
+// ORBmatcher.cc does with them.
+// =====================================================================================
+#ifndef ORB_ORACLE_MATCHERSTUB_STUBS_H
+#define ORB_ORACLE_MATCHERSTUB_STUBS_H
+#define MAPPOINT_H
+#define KEYFRAME_H
+#define FRAME_H
+#define FRAME_GRID_ROWS 48
+#define FRAME_GRID_COLS 64
+
+#include <climits>
+#include <set>
+#include <utility>
+#include <vector>
+
+#include <opencv2/core/core.hpp>
+
+#include "Thirdparty/DBoW2/DBoW2/BowVector.h"
+#include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+
+extern "C" int orc_frame_features_in_area(const void* bounds, const void* kps_un, const int32_t* cell_off, const int32_t* cell_feat,
+                                          float x, float y, float r, int minLevel, int maxLevel, int32_t* out);
+
+namespace ORB_SLAM {
+using std::pair;
+using std::vector;
+
+class KeyFrame;
+class Frame;
+
+class MapPoint {
+public:
+    bool bad = false;
+    cv::Mat descriptor, worldPos, normal;
+    float minDistance = 0, maxDistance = 0;
+    // Tracking's per-frame projection (include/MapPoint.h: public members)
+    float mTrackProjX = 0, mTrackProjY = 0;
+    bool mbTrackInView = false;
+    int mnTrackScaleLevel = 0;
+    float mTrackViewCos = 0;
+    std::vector<std::pair<KeyFrame*, int> > observations;
+
+    bool isBad() { return bad; }
+    cv::Mat GetDescriptor() { return descriptor.clone(); }
+    cv::Mat GetWorldPos() { return worldPos.clone(); }
+    cv::Mat GetNormal() { return normal.clone(); }
+    float GetMinDistanceInvariance() { return minDistance; }
+    float GetMaxDistanceInvariance() { return maxDistance; }
+    bool IsInKeyFrame(KeyFrame* pKF) { return GetIndexInKeyFrame(pKF) >= 0; }
+    int GetIndexInKeyFrame(KeyFrame* pKF) { for (auto& o : observations) if (o.first == pKF) return o.second; return -1; }
+    void AddObservation(KeyFrame* pKF, size_t idx) { observations.push_back(std::make_pair(pKF, (int)idx)); }
+    void Replace(MapPoint*) { bad = true; }
+};
+
+// grid + window query shared by the two frame classes (the flattened form oracle/frame_oracle.cpp works on)
+struct GridView {
+    struct Bounds { int32_t min_x, max_x, min_y, max_y; float inv_w, inv_h; } bounds;
+    std::vector<int32_t> cell_off, cell_feat;
+    std::vector<size_t> query(const std::vector<cv::KeyPoint>& kps_un, float x, float y, float r, int minLevel, int maxLevel) const {
+        std::vector<int32_t> out(kps_un.size() + 1);
+        const int n = orc_frame_features_in_area(&bounds, kps_un.data(), cell_off.data(), cell_feat.data(), x, y, r, minLevel, maxLevel, out.data());
+        return std::vector<size_t>(out.begin(), out.begin() + n);
+    }
+};
+
+class Frame {
+public:
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+    cv::Mat mDescriptors;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    std::vector<float> mvScaleFactors;
+    int mnScaleLevels = 8;
+    cv::Mat mTcw;
+    DBoW2::FeatureVector mFeatVec;
+    static float fx, fy, cx, cy;
+    static int mnMinX, mnMaxX, mnMinY, mnMaxY;
+    GridView grid;
+    std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel = -1, const int maxLevel = -1) const {
+        return grid.query(mvKeysUn, x, y, r, minLevel, maxLevel);
+    }
+};
+
+class KeyFrame {
+public:
+    std::vector<cv::KeyPoint> keysUn;
+    cv::Mat descriptors;
+    std::vector<MapPoint*> mapPoints;
+    DBoW2::FeatureVector featVec;
+    std::vector<float> scaleFactors, levelSigma2;
+    cv::Mat Rcw, tcw, Ow;
+    float fx = 0, fy = 0, cx = 0, cy = 0;
+    int minX = 0, maxX = 0, minY = 0, maxY = 0;
+    GridView grid;
+
+    DBoW2::FeatureVector GetFeatureVector() { return featVec; }
+    std::vector<MapPoint*> GetMapPointMatches() { return mapPoints; }
+    std::set<MapPoint*> GetMapPoints() { std::set<MapPoint*> s; for (MapPoint* p : mapPoints) if (p && !p->isBad()) s.insert(p); return s; }
+    MapPoint* GetMapPoint(const size_t& idx) { return mapPoints[idx]; }
+    void AddMapPoint(MapPoint* pMP, const size_t& idx) { mapPoints[idx] = pMP; }
+    cv::Mat GetDescriptors() { return descriptors.clone(); }
+    cv::Mat GetDescriptor(const size_t& idx) { return descriptors.row((int)idx).clone(); }
+    std::vector<cv::KeyPoint> GetKeyPointsUn() const { return keysUn; }
+    cv::KeyPoint GetKeyPointUn(const size_t& idx) const { return keysUn[idx]; }
+    int GetKeyPointScaleLevel(const size_t& idx) const { return keysUn[idx].octave; }
+    int GetScaleLevels() { return (int)scaleFactors.size(); }
+    std::vector<float> GetScaleFactors() { return scaleFactors; }
+    float GetScaleFactor(int nLevel = 1) const { return scaleFactors[nLevel]; }
+    float GetSigma2(int nLevel = 1) const { return levelSigma2[nLevel]; }
+    cv::Mat GetRotation() { return Rcw.clone(); }
+    cv::Mat GetTranslation() { return tcw.clone(); }
+    cv::Mat GetCameraCenter() { return Ow.clone(); }
+    bool IsInImage(const float& x, const float& y) const { return x >= minX && x < maxX && y >= minY && y < maxY; }
+    std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r) const { return grid.query(keysUn, x, y, r, -1, -1); }
+};
+
+}  // namespace ORB_SLAM
+#endif

@@ -19,7 +19,13 @@
 // What stays with the caller (pointer-graph work): which queries are valid (pMP != NULL, !isBad(), mbTrackInView, level
 // bounds), their window centres / radii (projection, RadiusByViewingCos, scale factors) and what a match means
 // (vpMapPointMatches2[i2] = pMP1 ...).  Candidate windows come from frame_oracle.cpp (Frame::GetFeaturesInArea).
-// PARITY UNPINNED (ORBmatcher.cc cannot be compiled here: Frame / KeyFrame / MapPoint / g2o / Boost).
+// PARITY PINNED to the reference's own src/ORBmatcher.cc for: rules 0, 1 (WindowSearch), 2, 3, 5 (through SearchBySim3, with its
+// agreement check), both SearchByBoW, SearchForTriangulation + CheckDistEpipolarLine, ComputeThreeMaxima, DescriptorDistance —
+// ORBmatcher.cc and the reference's ORBmatcher.h compile unmodified against plain-data stand-ins of Frame / KeyFrame / MapPoint
+// (oracle/matcherstub, oracle/ref_orbmatcher_wrap.cpp -> _ref/libref_orbmatcher.so) and tests/test_ref_pin_matcher.py runs the same
+// seeded problems through both.  Not pinned that way (restated + plain-Python KATs only): the scans inside Fuse (both),
+// SearchByProjection(KeyFrame*, Scw, ...), SearchByProjection(Frame&, KeyFrame*, ...) and SearchByProjection(F1, F2, windowSize, ...)
+// — the same loops as rules 5 / 2 / 1 behind pose-dependent projections —, and orc_distinctive (src/MapPoint.cc).
 // =====================================================================================
 #include <algorithm>
 #include <climits>
