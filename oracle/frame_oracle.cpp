@@ -9,11 +9,13 @@
 //   /root/reference/src/Frame.cc:108-123   the mGrid fill;  :267-277 Frame::PosInGrid
 //   /root/reference/src/Frame.cc:200-265   Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel)
 //
-// PARITY: the ORB_SLAM parts above are short enough to restate line by line but cannot be compiled here (Frame.h pulls
-// MapPoint / KeyFrame / Boost / g2o), so they are UNPINNED restatements.  cv::undistortPoints is an OpenCV primitive
-// (absent): restated from OpenCV 2.4 modules/imgproc/src/undistort.cpp (cvUndistortPoints: all
-// arithmetic in double, 5 fixed-point iterations when distortion coefficients are given, RR = P·I = K, float stores).
-// PARITY UNPINNED for that primitive.
+// PARITY PINNED for the ORB_SLAM parts above: the reference's own src/Frame.cc + include/Frame.h compile where they lie against
+// plain-data stand-ins of their heavy includes (oracle/matcherstub with -DORB_ORACLE_REAL_FRAME, oracle/ref_frame_wrap.cpp ->
+// _ref/libref_frame.so; the "extractor" hands the constructor preset key points) and tests/test_ref_pin_frame.py compares bounds,
+// inverse cell sizes, the grid, window queries (every level-argument form) and the scale tables on 4 cameras.
+// cv::undistortPoints is an OpenCV primitive (absent): restated from OpenCV 2.4 modules/imgproc/src/undistort.cpp
+// (cvUndistortPoints: all arithmetic in double, 5 fixed-point iterations when distortion coefficients are given, RR = P·I = K,
+// float stores).  PARITY UNPINNED for that primitive (behind the stand-in header Frame.cc calls this restatement).
 // =====================================================================================
 #include <cmath>
 #include <cstdint>

@@ -14,9 +14,16 @@
 #define ORB_ORACLE_MATCHERSTUB_STUBS_H
 #define MAPPOINT_H
 #define KEYFRAME_H
+#ifdef ORB_ORACLE_REAL_FRAME
+// the Frame pin (oracle/ref_frame_wrap.cpp): the reference's own Frame.h / Frame.cc are compiled; its other heavy includes are cut here
+#define CONVERTER_H
+#define ORBVOCABULARY_H
+#define ORBEXTRACTOR_H
+#else
 #define FRAME_H
 #define FRAME_GRID_ROWS 48
 #define FRAME_GRID_COLS 64
+#endif
 
 #include <climits>
 #include <set>
@@ -28,10 +35,17 @@
 #include "Thirdparty/DBoW2/DBoW2/BowVector.h"
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
 
+// In the real build every translation unit that includes Frame.h / KeyFrame.h inherits `using namespace std;` at global scope from
+// Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:36 (via ORBVocabulary.h, cut here).  It decides overloads the reference relies on —
+// src/Frame.cc:255 `abs(kpUn.pt.x-x)` is std::abs(float) with it and ::abs(int) without — so the stand-in restores it.
+using namespace std;
+
 extern "C" int orc_frame_features_in_area(const void* bounds, const void* kps_un, const int32_t* cell_off, const int32_t* cell_feat,
                                           float x, float y, float r, int minLevel, int maxLevel, int32_t* out);
 
 namespace ORB_SLAM {
+using std::max;
+using std::min;
 using std::pair;
 using std::vector;
 
@@ -73,6 +87,26 @@ struct GridView {
     }
 };
 
+#ifdef ORB_ORACLE_REAL_FRAME
+// what src/Frame.cc calls on its collaborators: an "extractor" that hands out preset key points, a vocabulary and a converter that are never used
+class ORBextractor {
+public:
+    std::vector<cv::KeyPoint> preset;
+    int levels = 8;
+    float scaleFactor = 1.2f;
+    void operator()(cv::Mat&, cv::Mat, std::vector<cv::KeyPoint>& keys, cv::Mat& descriptors) { keys = preset; descriptors = cv::Mat((int)preset.size() + 1, 32, CV_8U); }
+    int GetLevels() { return levels; }
+    float GetScaleFactor() { return scaleFactor; }
+};
+class ORBVocabulary {
+public:
+    void transform(const std::vector<cv::Mat>&, DBoW2::BowVector&, DBoW2::FeatureVector&, int) {}
+};
+class Converter {
+public:
+    static std::vector<cv::Mat> toDescriptorVector(const cv::Mat&) { return std::vector<cv::Mat>(); }
+};
+#else
 class Frame {
 public:
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
@@ -90,6 +124,8 @@ public:
         return grid.query(mvKeysUn, x, y, r, minLevel, maxLevel);
     }
 };
+
+#endif
 
 class KeyFrame {
 public:
