@@ -70,6 +70,8 @@ public:
     Mat colRange(int a, int b) const { return view(0, rows, a, b); }
     Mat row(int y) const { return view(y, y + 1, 0, cols); }
     Mat col(int x) const { return view(0, rows, x, x + 1); }
+    void copyTo(Mat& dst) const { dst = clone(); }
+    static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
     Mat reshape(int /*channels*/) const { return *this; }      // N x 2 CV_32F <-> N x 1 CV_32FC2: the same bytes (no channel model here)
     Mat clone() const {
         Mat m(rows, cols, type_);

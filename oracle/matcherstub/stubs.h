@@ -12,7 +12,9 @@
 // =====================================================================================
 #ifndef ORB_ORACLE_MATCHERSTUB_STUBS_H
 #define ORB_ORACLE_MATCHERSTUB_STUBS_H
+#ifndef ORB_ORACLE_REAL_MAPPOINT
 #define MAPPOINT_H
+#endif
 #define KEYFRAME_H
 #ifdef ORB_ORACLE_REAL_FRAME
 // the Frame pin (oracle/ref_frame_wrap.cpp): the reference's own Frame.h / Frame.cc are compiled; its other heavy includes are cut here
@@ -52,6 +54,20 @@ using std::vector;
 class KeyFrame;
 class Frame;
 
+#ifdef ORB_ORACLE_REAL_MAPPOINT
+}  // namespace ORB_SLAM
+// the MapPoint pin (oracle/ref_mappoint_wrap.cpp): the reference's own MapPoint.h / MapPoint.cc are compiled; Map is never used
+#define MAP_H
+namespace ORB_SLAM {
+class MapPoint;
+class Map {
+public:
+    void EraseMapPoint(MapPoint*) {}
+};
+}
+#include "MapPoint.h"
+namespace ORB_SLAM {
+#else
 class MapPoint {
 public:
     bool bad = false;
@@ -75,6 +91,7 @@ public:
     void AddObservation(KeyFrame* pKF, size_t idx) { observations.push_back(std::make_pair(pKF, (int)idx)); }
     void Replace(MapPoint*) { bad = true; }
 };
+#endif
 
 // grid + window query shared by the two frame classes (the flattened form oracle/frame_oracle.cpp works on)
 struct GridView {
@@ -139,6 +156,11 @@ public:
     int minX = 0, maxX = 0, minY = 0, maxY = 0;
     GridView grid;
 
+    long unsigned int mnId = 0;
+    bool bad = false;
+    bool isBad() { return bad; }
+    void EraseMapPointMatch(const size_t& idx) { mapPoints[idx] = 0; }
+    void ReplaceMapPointMatch(const size_t& idx, MapPoint* pMP) { mapPoints[idx] = pMP; }
     DBoW2::FeatureVector GetFeatureVector() { return featVec; }
     std::vector<MapPoint*> GetMapPointMatches() { return mapPoints; }
     std::set<MapPoint*> GetMapPoints() { std::set<MapPoint*> s; for (MapPoint* p : mapPoints) if (p && !p->isBad()) s.insert(p); return s; }

@@ -25,7 +25,8 @@
 // (oracle/matcherstub, oracle/ref_orbmatcher_wrap.cpp -> _ref/libref_orbmatcher.so) and tests/test_ref_pin_matcher.py runs the same
 // seeded problems through both.  Not pinned that way (restated + plain-Python KATs only): the scans inside Fuse (both),
 // SearchByProjection(KeyFrame*, Scw, ...), SearchByProjection(Frame&, KeyFrame*, ...) and SearchByProjection(F1, F2, windowSize, ...)
-// — the same loops as rules 5 / 2 / 1 behind pose-dependent projections —, and orc_distinctive (src/MapPoint.cc).
+// — the same loops as rules 5 / 2 / 1 behind pose-dependent projections.  orc_distinctive is pinned to the reference's own
+// src/MapPoint.cc (MapPoint::ComputeDistinctiveDescriptors :185-250) through _ref/libref_mappoint.so.
 // =====================================================================================
 #include <algorithm>
 #include <climits>

@@ -334,3 +334,31 @@ def test_search_for_triangulation(seed, n1, n2, check, kw):
     np.testing.assert_array_equal(q2t[:n1], w[1])
     if n1 >= 500:
         assert n > 30
+
+
+def test_distinctive_descriptor():
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:185-250) through the reference's own MapPoint.cc: the descriptor it
+    keeps is the row orc_distinctive picks (first row with the smallest median on ties; bad key frames skipped)"""
+    path = os.path.join(ROOT, "oracle", "_ref", "libref_mappoint.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_mappoint.so is built only where /root/reference exists")
+    L = ctypes.CDLL(path)
+    L.ref_distinctive.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(4)
+    checked = 0
+    for n in [1, 2, 3, 4, 5, 8, 17, 40, 64]:
+        for rep in range(6):
+            d = synth.descriptors(n, 900 + 10 * n + rep)
+            if n > 3 and rep % 2:
+                d[rng.integers(0, n, n // 2)] = d[0]                   # duplicates: ties between rows
+            bad = (rng.random(n) < (0.3 if rep >= 4 else 0.0)).astype(np.uint8)
+            out = np.zeros(32, np.uint8)
+            ok = L.ref_distinctive(P(d), n, P(bad), P(out))
+            good = d[bad == 0]
+            if len(good) == 0:
+                assert ok == 0
+                continue
+            idx, med = ol.distinctive(good)
+            assert ok == 1 and np.array_equal(out, good[idx]), (n, rep, idx, med)
+            checked += 1
+    assert checked > 40
