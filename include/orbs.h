@@ -11,8 +11,12 @@
  *   ORBS_RULE_WINDOW     <- int ORBmatcher::WindowSearch(Frame&, Frame&, int, vector<MapPoint*>&, int, int)   :408-516
  *                           int ORBmatcher::SearchByProjection(Frame&, Frame&, int, vector<MapPoint*>&)       :519-594
  *                           (accept best <= second*ratio && best <= th)
- *   ORBS_RULE_BEST       <- int ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, float th)   :1508-1619
- *                           (accept best <= th)
+ *   ORBS_RULE_BEST       <- int ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, float th)   :1507-1619
+ *                           int ORBmatcher::SearchByProjection(Frame& Current, KeyFrame*, const set<MapPoint*>&, float th, int ORBdist)  :1622-1746
+ *                           (accept best <= th; th = TH_HIGH resp. ORBdist)
+ *                           int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>& vpMatched, int th)  :286-407
+ *                           (the same with th = TH_LOW, d_claimed = "vpMatched[idx] is set on entry" and no rotation check:
+ *                           a match claims its feature, later map points skip it)
  *   ORBS_RULE_INIT       <- int ORBmatcher::SearchForInitialization(Frame&, Frame&, vector<Point2f>&, vector<int>&, int)   :596-716
  *                           (a train feature may be re-matched by a later query with a strictly smaller distance)
  *   ORBS_RULE_BOW        <- int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                 :155-281
@@ -26,7 +30,8 @@
  *                           2 x the best distance that lies on the query's epipolar line is taken)
  *   ORBS_RULE_FREE       <- the searches WITHOUT the "already matched" masking, every query independent: the scan of
  *                           int ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, float th)                       :1016-1134
- *                           int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, ..., int th)             :286-407
+ *                           int ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, float th)    :1136-1265
+ *                           and the two scans of SearchBySim3                                                   :1267-1505
  *                           (window + level range, best distance only, accept best <= th; several queries may end on the same
  *                           feature, so d_t2q is not produced (all -1) and there is no rotation check)
  *   orbs_agreement_batch_device <- the two scans of int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, vector<MapPoint*>&, s12, R12, t12, th)

@@ -164,7 +164,8 @@ public:
     DBoW2::FeatureVector GetFeatureVector() { return featVec; }
     std::vector<MapPoint*> GetMapPointMatches() { return mapPoints; }
     std::set<MapPoint*> GetMapPoints() { std::set<MapPoint*> s; for (MapPoint* p : mapPoints) if (p && !p->isBad()) s.insert(p); return s; }
-    MapPoint* GetMapPoint(const size_t& idx) { return mapPoints[idx]; }
+    std::vector<int> getMapPointLog;          // every index Fuse asked for, in call order (= its bestIdx per fused point)
+    MapPoint* GetMapPoint(const size_t& idx) { getMapPointLog.push_back((int)idx); return mapPoints[idx]; }
     void AddMapPoint(MapPoint* pMP, const size_t& idx) { mapPoints[idx] = pMP; }
     cv::Mat GetDescriptors() { return descriptors.clone(); }
     cv::Mat GetDescriptor(const size_t& idx) { return descriptors.row((int)idx).clone(); }

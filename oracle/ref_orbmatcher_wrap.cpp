@@ -11,14 +11,18 @@
 //   SearchByProjection(Frame&, const vector<MapPoint*>&, float)   :49-125     (oracle rule 0)
 //   WindowSearch(Frame&, Frame&, int, vector<MapPoint*>&, int, int) :409-516  (oracle rule 1)
 //   SearchByProjection(Frame& Current, const Frame& Last, float)    :1507-1619 (oracle rule 2; identity pose, see below)
+//   SearchByProjection(Frame& F1, Frame& F2, int windowSize, ...)   :519-596  (oracle rule 1 behind a projection; identity pose)
+//   SearchByProjection(Frame&, KeyFrame*, set<MapPoint*>&, th, ORBdist) :1622-1746 (oracle rule 2 from a key frame; identity pose)
 //   SearchForInitialization(...)                                    :598-713  (oracle rule 3)
 //   SearchByBoW(KeyFrame*, Frame&, ...)                             :155-281
 //   SearchByBoW(KeyFrame*, KeyFrame*, ...)                          :715-850
 //   SearchForTriangulation(...) + CheckDistEpipolarLine             :852-1014, :136-153
 //   ComputeThreeMaxima :1748-1789, DescriptorDistance :1794-1810
 //   SearchBySim3 :1267-1505 (identity poses: its two scans = oracle rule 5, its agreement check)
-// Compiled but NOT pinned (they project map points through poses with cv::Mat algebra the stand-in only approximates):
-//   the SearchByProjection overloads on KeyFrames / Sim3 poses, SearchByProjection(F1, F2, windowSize, ...), Fuse (both).
+//   SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) :286-407 (oracle rule 2 without rotation check; identity Scw)
+//   Fuse(KeyFrame*, vector<MapPoint*>&, th) :1016-1134 and Fuse(KeyFrame*, Scw, ...) :1136-1265 (oracle rule 5; identity pose)
+// i.e. every function of ORBmatcher.cc.  (Non-identity poses only change where the windows lie: that arithmetic is the caller's side of the
+// boundary and is not restated.)
 // =====================================================================================
 #include <deque>
 
@@ -206,6 +210,75 @@ int ref_search_by_projection_last_frame(const void* bounds, float ratio, int che
     return n;
 }
 
+// rule 1 behind a projection: SearchByProjection(Frame& F1, Frame& F2, int windowSize, vector<MapPoint*>&) with F2.mTcw = identity.  state1 as in
+// ref_window_search, world1 = the map points' positions (X, Y, 1); claimed2 = F2 features that hold a map point on entry.  t2q[n2]: -2 = held on entry.
+int ref_search_by_projection_two_frames(const void* bounds, float ratio, const float* cam, const void* kps_un1, const uint8_t* desc1, const uint8_t* state1,
+                                        const float* world1, int n1, const void* kps_un2, const uint8_t* desc2, const int32_t* cell_off2,
+                                        const int32_t* cell_feat2, int n2, const uint8_t* claimed2, int windowSize, int32_t* t2q) {
+    Frame F1, F2;
+    Frame::fx = cam[0]; Frame::fy = cam[1]; Frame::cx = cam[2]; Frame::cy = cam[3];
+    F1.mvKeysUn = kp_vec(kps_un1, n1); F1.mDescriptors = desc_mat(desc1, n1);
+    F2.mvKeysUn = kp_vec(kps_un2, n2); F2.mDescriptors = desc_mat(desc2, n2);
+    fill_grid(F2.grid, bounds, cell_off2, cell_feat2, n2);
+    F2.mTcw = cv::Mat(4, 4, CV_32F);
+    for (int i = 0; i < 4; i++) F2.mTcw.at<float>(i, i) = 1.0f;
+    MapPoint old;
+    F2.mvpMapPoints.assign(n2, (MapPoint*)0);
+    for (int i = 0; i < n2; i++) if (claimed2 && claimed2[i]) F2.mvpMapPoints[i] = &old;
+    std::deque<MapPoint> pool;
+    F1.mvpMapPoints = map_points(pool, state1, n1);
+    for (int i = 0; i < n1; i++) if (F1.mvpMapPoints[i]) {
+        cv::Mat w(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) w.at<float>(k) = world1[3 * i + k];
+        F1.mvpMapPoints[i]->worldPos = w;
+    }
+    std::vector<MapPoint*> m2;
+    ORBmatcher matcher(ratio, true);
+    const int n = matcher.SearchByProjection(F1, F2, windowSize, m2);
+    for (int i = 0; i < n2; i++) t2q[i] = m2[i] == &old ? -2 : index_of(F1.mvpMapPoints, m2[i]);
+    return n;
+}
+
+// rule 2 from a key frame: SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, float th, int ORBdist) with
+// CurrentFrame.mTcw = identity.  kf_state: 0 none / 1 good / 2 bad / 3 good but in sAlreadyFound; world / mindist per key-frame feature.
+int ref_search_by_projection_keyframe(const void* bounds, int check, float th, int orbdist, const float* cam, const float* scale_factors, int nlevels,
+                                      const void* kps_un2, const uint8_t* desc2, const int32_t* cell_off2, const int32_t* cell_feat2, int n2,
+                                      const uint8_t* claimed2, const void* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_state, const float* world,
+                                      const float* mindist, int nKF, int32_t* t2q) {
+    Frame C;
+    Frame::fx = cam[0]; Frame::fy = cam[1]; Frame::cx = cam[2]; Frame::cy = cam[3];
+    GridView::Bounds bb;
+    memcpy(&bb, bounds, sizeof(bb));
+    Frame::mnMinX = bb.min_x; Frame::mnMaxX = bb.max_x; Frame::mnMinY = bb.min_y; Frame::mnMaxY = bb.max_y;
+    C.mvKeysUn = kp_vec(kps_un2, n2); C.mDescriptors = desc_mat(desc2, n2);
+    C.mvScaleFactors.assign(scale_factors, scale_factors + nlevels); C.mnScaleLevels = nlevels;
+    fill_grid(C.grid, bounds, cell_off2, cell_feat2, n2);
+    C.mTcw = cv::Mat(4, 4, CV_32F);
+    for (int i = 0; i < 4; i++) C.mTcw.at<float>(i, i) = 1.0f;
+    MapPoint old;
+    C.mvpMapPoints.assign(n2, (MapPoint*)0);
+    for (int i = 0; i < n2; i++) if (claimed2 && claimed2[i]) C.mvpMapPoints[i] = &old;
+    KeyFrame kf;
+    kf.keysUn = kp_vec(kf_kps, nKF);
+    std::deque<MapPoint> pool;
+    std::vector<uint8_t> st(kf_state, kf_state + nKF);
+    for (auto& v : st) if (v == 3) v = 1;
+    kf.mapPoints = map_points(pool, st.data(), nKF);
+    std::set<MapPoint*> found;
+    for (int i = 0; i < nKF; i++) if (kf.mapPoints[i]) {
+        MapPoint& m = *kf.mapPoints[i];
+        cv::Mat w(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) w.at<float>(k) = world[3 * i + k];
+        m.worldPos = w; m.minDistance = mindist[i]; m.maxDistance = 1e9f;
+        m.descriptor = desc_row(kf_desc + (size_t)i * 32);
+        if (kf_state[i] == 3) found.insert(&m);
+    }
+    ORBmatcher matcher(0.75f, check != 0);
+    const int n = matcher.SearchByProjection(C, &kf, found, th, orbdist);
+    for (int i = 0; i < n2; i++) t2q[i] = C.mvpMapPoints[i] == &old ? -2 : index_of(kf.mapPoints, C.mvpMapPoints[i]);
+    return n;
+}
+
 // SearchByBoW(KeyFrame*, Frame&, ...).  kf_state: 0 / 1 / 2 as above.  t2q[nF] = the key-frame feature whose map point vpMapPointMatches[iF] is.
 int ref_search_by_bow(float ratio, int check, const uint32_t* kf_node, const int32_t* kf_off, const uint32_t* kf_feat, int kf_nnodes, const uint8_t* kf_desc,
                       const float* kf_angle, const uint8_t* kf_state, int nKF, const uint32_t* f_node, const int32_t* f_off, const uint32_t* f_feat,
@@ -274,6 +347,91 @@ int ref_search_for_triangulation(float ratio, int check, const float* F12, const
         q2t[pairs[j].first] = (int)pairs[j].second;
         if (mk1[j].pt.x != k1.keysUn[pairs[j].first].pt.x || mk2[j].pt.y != k2.keysUn[pairs[j].second].pt.y) return -1001;
     }
+    return n;
+}
+
+namespace {
+// a key frame at the identity pose with camera `cam`, and map points at (X, Y, 1) looking straight at it
+void identity_keyframe(KeyFrame& k, const void* bounds, const float* cam, const float* scale_factors, int nlevels, const void* kps, const uint8_t* desc,
+                       const int32_t* off, const int32_t* feat, int n) {
+    GridView::Bounds bb;
+    memcpy(&bb, bounds, sizeof(bb));
+    k.keysUn = kp_vec(kps, n); k.descriptors = desc_mat(desc, n);
+    fill_grid(k.grid, bounds, off, feat, n);
+    k.scaleFactors.assign(scale_factors, scale_factors + nlevels);
+    k.fx = cam[0]; k.fy = cam[1]; k.cx = cam[2]; k.cy = cam[3];
+    k.minX = bb.min_x; k.maxX = bb.max_x; k.minY = bb.min_y; k.maxY = bb.max_y;
+    k.Rcw = cv::Mat(3, 3, CV_32F); k.tcw = cv::Mat(3, 1, CV_32F); k.Ow = cv::Mat(3, 1, CV_32F);
+    for (int i = 0; i < 3; i++) k.Rcw.at<float>(i, i) = 1.0f;
+}
+std::vector<MapPoint*> query_points(std::deque<MapPoint>& pool, const uint8_t* state, const float* world, const float* mindist, const uint8_t* desc, int nq) {
+    std::vector<MapPoint*> q(nq, (MapPoint*)0);
+    for (int i = 0; i < nq; i++) {
+        if (!state[i]) continue;
+        pool.emplace_back();
+        MapPoint& m = pool.back();
+        m.bad = state[i] == 2;
+        cv::Mat w(3, 1, CV_32F), nrm(3, 1, CV_32F);
+        double len = 0;
+        for (int c = 0; c < 3; c++) { w.at<float>(c) = world[3 * i + c]; len += (double)world[3 * i + c] * world[3 * i + c]; }
+        for (int c = 0; c < 3; c++) nrm.at<float>(c) = (float)(world[3 * i + c] / std::sqrt(len));
+        m.worldPos = w; m.normal = nrm; m.minDistance = mindist[i]; m.maxDistance = 1e9f;
+        m.descriptor = desc_row(desc + (size_t)i * 32);
+        q[i] = &m;
+    }
+    return q;
+}
+}  // namespace
+
+// SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched, int th) with Scw = identity.
+// qstate: 1 good, 2 bad, 3 good but already in vpMatched (it is put into the first claimed slot).  t2q[nKF]: -2 = matched on entry.
+int ref_search_by_projection_scw(const void* bounds, int th, const float* cam, const float* scale_factors, int nlevels, const void* kps, const uint8_t* desc,
+                                 const int32_t* off, const int32_t* feat, int nKF, const uint8_t* claimed, const uint8_t* qstate, const float* world,
+                                 const float* mindist, const uint8_t* qdesc, int nq, int32_t* t2q) {
+    KeyFrame kf;
+    identity_keyframe(kf, bounds, cam, scale_factors, nlevels, kps, desc, off, feat, nKF);
+    std::deque<MapPoint> pool;
+    std::vector<uint8_t> st(qstate, qstate + nq);
+    for (auto& v : st) if (v == 3) v = 1;
+    std::vector<MapPoint*> q = query_points(pool, st.data(), world, mindist, qdesc, nq);
+    MapPoint old;
+    std::vector<MapPoint*> matched(nKF, (MapPoint*)0);
+    for (int i = 0; i < nKF; i++) if (claimed[i]) matched[i] = &old;
+    int slot = 0;
+    for (int i = 0; i < nq; i++) if (qstate[i] == 3) { while (slot < nKF && !claimed[slot]) slot++; if (slot < nKF) matched[slot++] = q[i]; }
+    std::vector<MapPoint*> before = matched;
+    cv::Mat Scw(4, 4, CV_32F);
+    for (int i = 0; i < 4; i++) Scw.at<float>(i, i) = 1.0f;
+    ORBmatcher matcher(0.75f, true);
+    const int n = matcher.SearchByProjection(&kf, Scw, q, matched, th);
+    for (int i = 0; i < nKF; i++) t2q[i] = before[i] ? -2 : index_of(q, matched[i]);
+    return n;
+}
+
+// Fuse.  which = 0: Fuse(KeyFrame*, vector<MapPoint*>&, float th) with the key frame at the identity pose; which = 1: Fuse(KeyFrame*, cv::Mat Scw,
+// const vector<MapPoint*>&, float th) with Scw = identity.  kf_state: map points the key frame already holds (0 none / 1 good / 2 bad);
+// qstate: 0 NULL (variant 0 only) / 1 good / 2 bad.  log[]: the feature index of every fused point in query order (the reference asks the key frame
+// for exactly that index once per fused point); returns nFused.
+int ref_fuse(int which, const void* bounds, float th, const float* cam, const float* scale_factors, int nlevels, const void* kps, const uint8_t* desc,
+             const int32_t* off, const int32_t* feat, int nKF, const uint8_t* kf_state, const uint8_t* qstate, const float* world, const float* mindist,
+             const uint8_t* qdesc, int nq, int32_t* log, int* nlog) {
+    KeyFrame kf;
+    identity_keyframe(kf, bounds, cam, scale_factors, nlevels, kps, desc, off, feat, nKF);
+    std::deque<MapPoint> pool;
+    kf.mapPoints = map_points(pool, kf_state, nKF);
+    std::vector<MapPoint*> q = query_points(pool, qstate, world, mindist, qdesc, nq);
+    ORBmatcher matcher(0.75f, true);
+    int n;
+    if (which == 0) n = matcher.Fuse(&kf, q, th);
+    else {
+        cv::Mat Scw(4, 4, CV_32F);
+        for (int i = 0; i < 4; i++) Scw.at<float>(i, i) = 1.0f;
+        std::vector<MapPoint*> q2;
+        for (MapPoint* p : q) if (p) q2.push_back(p);               // this overload does not accept NULL entries
+        n = matcher.Fuse(&kf, Scw, q2, th);
+    }
+    *nlog = (int)kf.getMapPointLog.size();
+    for (size_t i = 0; i < kf.getMapPointLog.size(); i++) log[i] = kf.getMapPointLog[i];
     return n;
 }
 

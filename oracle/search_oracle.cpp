@@ -9,7 +9,9 @@
 //           ORBmatcher::SearchByProjection(Frame&, Frame&, int, vector<MapPoint*>&)       :519-594 (no rotation check)
 //   rule 2  ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, float)      :1508-1619
 //   rule 3  ORBmatcher::SearchForInitialization(Frame&, Frame&, vector<Point2f>&, vector<int>&, int)   :596-716
-//   rule 5  the scans of ORBmatcher::Fuse :1016-1134 and SearchByProjection(KeyFrame*, Scw, ...) :286-407 (no claims)
+//   rule 2  also SearchByProjection(Frame&, KeyFrame*, set<MapPoint*>&, th, ORBdist) :1622-1746 and, without rotation check,
+//           SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) :286-407 (vpMatched = the claim state)
+//   rule 5  the scans of ORBmatcher::Fuse :1016-1134, :1136-1265 and of SearchBySim3 :1267-1505 (no claims)
 //   ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                        :155-281   (orc_search_by_bow)
 //   ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&)                      :715-850   (orc_search_by_bow_kf)
 //   ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, ...)             :852-1014  (orc_search_for_triangulation)
@@ -23,9 +25,8 @@
 // agreement check), both SearchByBoW, SearchForTriangulation + CheckDistEpipolarLine, ComputeThreeMaxima, DescriptorDistance —
 // ORBmatcher.cc and the reference's ORBmatcher.h compile unmodified against plain-data stand-ins of Frame / KeyFrame / MapPoint
 // (oracle/matcherstub, oracle/ref_orbmatcher_wrap.cpp -> _ref/libref_orbmatcher.so) and tests/test_ref_pin_matcher.py runs the same
-// seeded problems through both.  Not pinned that way (restated + plain-Python KATs only): the scans inside Fuse (both),
-// SearchByProjection(KeyFrame*, Scw, ...), SearchByProjection(Frame&, KeyFrame*, ...) and SearchByProjection(F1, F2, windowSize, ...)
-// — the same loops as rules 5 / 2 / 1 behind pose-dependent projections.  orc_distinctive is pinned to the reference's own
+// seeded problems through both — every function of ORBmatcher.cc, the projection-based ones at identity poses (so that the
+// reference's own projection code runs and the test reproduces its float arithmetic).  orc_distinctive is pinned to the reference's own
 // src/MapPoint.cc (MapPoint::ComputeDistinctiveDescriptors :185-250) through _ref/libref_mappoint.so.
 // =====================================================================================
 #include <algorithm>

@@ -34,6 +34,10 @@ def ref():
         L.ref_window_search.argtypes = [vp, f, i, vp, vp, vp, i, vp, vp, vp, vp, i, i, i, i, vp]
         L.ref_search_for_initialization.argtypes = [vp, f, i, vp, vp, i, vp, vp, vp, vp, i, vp, i, vp]
         L.ref_search_by_projection_last_frame.argtypes = [vp, f, i, f, vp, vp, vp, vp, vp, i, vp, vp, i, vp, vp, vp, vp, vp, i, vp]
+        L.ref_search_by_projection_two_frames.argtypes = [vp, f, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, i, vp, i, vp]
+        L.ref_search_by_projection_keyframe.argtypes = [vp, i, f, i, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, vp]
+        L.ref_search_by_projection_scw.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i, vp]
+        L.ref_fuse.argtypes = [i, vp, f, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i, vp, vp]
         L.ref_search_by_sim3.argtypes = [vp, f, vp, vp, i] + [vp, vp, vp, vp, vp, vp, vp, i] * 2 + [vp]
         L.ref_search_by_bow.argtypes = [f, i] + [vp, vp, vp, i, vp, vp, vp, i] + [vp, vp, vp, i, vp, vp, i] + [vp]
         L.ref_search_by_bow_kf.argtypes = [f, i] + [vp, vp, vp, i, vp, vp, vp, i] * 2 + [vp]
@@ -279,6 +283,144 @@ def test_search_by_sim3(seed, n1, n2, th, crowd):
     assert (a12 >= 0).sum() > 150 and (a21 >= 0).sum() > 100
     np.testing.assert_array_equal(got, want)
     assert n == nf and n > 40
+
+
+@pytest.mark.parametrize("seed,n1,n2,win,crowd", [(81, 1000, 1000, 30, False), (82, 700, 1000, 10, True), (83, 1000, 500, 60, True)])
+def test_search_by_projection_between_two_frames(seed, n1, n2, win, crowd):
+    """SearchByProjection(F1, F2, windowSize, vpMapPointMatches2): WindowSearch's rule behind the reference's own projection (identity pose)"""
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    b = capi.image_bounds(CAM)
+    fx, fy, cx, cy = f32(517.3), f32(516.5), f32(318.6), f32(255.3)
+    cam = np.array([fx, fy, cx, cy], np.float32)
+    k2 = _frame(rng, n2, crowd)
+    d2 = synth.descriptors(n2, seed + 600)
+    off, feat = ol.frame_grid(b, k2)
+    featp = np.ascontiguousarray(np.append(feat, 0).astype(np.int32))
+    claimed = (rng.random(n2) < 0.15).astype(np.uint8)
+    src = rng.integers(0, n2, n1)
+    k1 = k2[src].copy()
+    d1 = _noisy_copies(rng, d2, src, 8)
+    tu, tv = k2["x"][src] + rng.normal(0, win / 4, n1), k2["y"][src] + rng.normal(0, win / 4, n1)
+    world = np.stack([(tu - cx) / fx, (tv - cy) / fy, np.ones(n1)], -1).astype(np.float32)
+    state1 = rng.choice([0, 1, 1, 1, 2], n1).astype(np.uint8)
+    t2q = np.zeros(max(n2, 1), np.int32)
+    n = ref().ref_search_by_projection_two_frames(ctypes.addressof(b), 0.8, P(cam), P(k1), P(d1), P(state1), P(world), n1, P(k2), P(d2), P(off), P(featp), n2,
+                                                  P(claimed), win, P(t2q))
+    u = (fx * world[:, 0] * f32(1.0) + cx).astype(np.float32); v = (fy * world[:, 1] * f32(1.0) + cy).astype(np.float32)
+    lvl = k1["octave"]
+    w = ol.window_search(b, capi.RULE_WINDOW, capi.TH_HIGH, 0.8, False, k2, d2, off, feat, claimed, np.stack([u, v, np.full(n1, win, np.float32)], -1),
+                         np.stack([lvl, lvl], -1), d1, None, (state1 == 1).astype(np.uint8))
+    got = t2q[:n2].copy(); got[got == -2] = -1
+    assert n == w[0] and n > 40
+    np.testing.assert_array_equal(got, w[2])
+
+
+@pytest.mark.parametrize("seed,nkf,n2,th,orbdist,check,crowd", [(91, 1000, 1000, 10.0, 100, True, False), (92, 800, 1000, 3.0, 64, True, True), (93, 1000, 600, 10.0, 100, False, True)])
+def test_search_by_projection_from_keyframe(seed, nkf, n2, th, orbdist, check, crowd):
+    """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (relocalisation): rule 2 with the level predicted from the distance"""
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    b = capi.image_bounds(CAM)
+    fx, fy, cx, cy = f32(517.3), f32(516.5), f32(318.6), f32(255.3)
+    cam = np.array([fx, fy, cx, cy], np.float32)
+    k2 = _frame(rng, n2, crowd)
+    d2 = synth.descriptors(n2, seed + 700)
+    off, feat = ol.frame_grid(b, k2)
+    featp = np.ascontiguousarray(np.append(feat, 0).astype(np.int32))
+    claimed = (rng.random(n2) < 0.15).astype(np.uint8)
+    src = rng.integers(0, n2, nkf)
+    kk = k2[src].copy()
+    kk["angle"] = ((k2["angle"][src] + rng.normal(10, 8, nkf)) % 360).astype(np.float32)
+    dk = _noisy_copies(rng, d2, src, 6)
+    lv = np.clip(k2["octave"][src] + rng.integers(-1, 2, nkf), 1, 9)
+    tu, tv = k2["x"][src] + rng.normal(0, th, nkf), k2["y"][src] + rng.normal(0, th, nkf)
+    tu[:15] = rng.choice([-40.0, 720.0], 15)
+    world = np.stack([(tu - cx) / fx, (tv - cy) / fy, np.ones(nkf)], -1).astype(np.float32)
+    dist = np.sqrt((world.astype(np.float64) ** 2).sum(1))
+    sc = np.concatenate([SCALE.astype(np.float64), [SCALE[7] * 1.2, SCALE[7] * 1.44, SCALE[7] * 1.7]])
+    mind = (dist / np.sqrt(sc[lv - 1] * sc[lv])).astype(np.float32)
+    state = rng.choice([0, 1, 1, 1, 1, 2, 3], nkf).astype(np.uint8)
+    t2q = np.zeros(max(n2, 1), np.int32)
+    n = ref().ref_search_by_projection_keyframe(ctypes.addressof(b), int(check), th, orbdist, P(cam), P(SCALE), 8, P(k2), P(d2), P(off), P(featp), n2, P(claimed),
+                                                P(kk), P(dk), P(state), P(world), P(mind), nkf, P(t2q))
+    u = (fx * world[:, 0] * f32(1.0) + cx).astype(np.float32); v = (fy * world[:, 1] * f32(1.0) + cy).astype(np.float32)
+    inb = ~((u < b.min_x) | (u > b.max_x)) & ~((v < b.min_y) | (v > b.max_y))
+    lvl = np.minimum(lv, 7)
+    qxyr = np.stack([u, v, (f32(th) * SCALE[lvl]).astype(np.float32)], -1)
+    w = ol.window_search(b, capi.RULE_BEST, orbdist, 0.0, check, k2, d2, off, feat, claimed, qxyr, np.stack([lvl - 1, lvl + 1], -1), dk, kk["angle"],
+                         ((state == 1) & inb).astype(np.uint8))
+    got = t2q[:n2].copy(); got[got == -2] = -1
+    assert n == w[0] and n > 60
+    np.testing.assert_array_equal(got, w[2])
+
+
+def _projected_queries(rng, k, src, nq, th, b, zero_state=False):
+    """map points at depth 1 in front of an identity-pose key frame, predicted level chosen through their minimum distance"""
+    f32 = np.float32
+    fx, fy, cx, cy = f32(517.3), f32(516.5), f32(318.6), f32(255.3)
+    lv = np.clip(k["octave"][src] + rng.integers(0, 2, nq), 1, 9)
+    tu, tv = k["x"][src] + rng.normal(0, th / 2, nq), k["y"][src] + rng.normal(0, th / 2, nq)
+    tu[:12] = rng.choice([-40.0, 720.0], 12)
+    world = np.stack([(tu - cx) / fx, (tv - cy) / fy, np.ones(nq)], -1).astype(np.float32)
+    dist = np.sqrt((world.astype(np.float64) ** 2).sum(1))
+    sc = np.concatenate([SCALE.astype(np.float64), [SCALE[7] * 1.2, SCALE[7] * 1.44, SCALE[7] * 1.7]])
+    mind = (dist / np.sqrt(sc[lv - 1] * sc[lv])).astype(np.float32)
+    u = (fx * (world[:, 0] * f32(1.0)) + cx).astype(np.float32); v = (fy * (world[:, 1] * f32(1.0)) + cy).astype(np.float32)
+    inimg = (u >= b.min_x) & (u < b.max_x) & (v >= b.min_y) & (v < b.max_y)
+    lvl = np.minimum(lv, 7)
+    qxyr = np.stack([u, v, (f32(th) * SCALE[lvl]).astype(np.float32)], -1)
+    return world, mind, inimg, qxyr, np.stack([lvl - 1, lvl], -1), np.array([fx, fy, cx, cy], np.float32)
+
+
+@pytest.mark.parametrize("seed,nkf,nq,th,crowd", [(101, 1000, 1000, 10, False), (102, 1000, 600, 4, True), (103, 500, 1000, 10, True)])
+def test_search_by_projection_with_sim3_pose(seed, nkf, nq, th, crowd):
+    """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (loop closing): features matched earlier are skipped, a match claims its
+    feature -> the in-order rule 2 without rotation check, TH_LOW"""
+    rng = np.random.default_rng(seed)
+    b = capi.image_bounds(CAM)
+    k = _frame(rng, nkf, crowd)
+    d = synth.descriptors(nkf, seed + 800)
+    off, feat = ol.frame_grid(b, k)
+    featp = np.ascontiguousarray(np.append(feat, 0).astype(np.int32))
+    claimed = (rng.random(nkf) < 0.15).astype(np.uint8)
+    src = rng.integers(0, nkf, nq)
+    qd = _noisy_copies(rng, d, src, 5)
+    world, mind, inimg, qxyr, qlev, cam = _projected_queries(rng, k, src, nq, float(th), b)
+    state = rng.choice([1, 1, 1, 1, 2, 3], nq).astype(np.uint8)
+    state[(state == 3) & (np.cumsum(state == 3) > claimed.sum())] = 1           # at most as many "already found" points as claimed slots
+    t2q = np.zeros(max(nkf, 1), np.int32)
+    n = ref().ref_search_by_projection_scw(ctypes.addressof(b), th, P(cam), P(SCALE), 8, P(k), P(d), P(off), P(featp), nkf, P(claimed), P(state), P(world), P(mind),
+                                           P(qd), nq, P(t2q))
+    w = ol.window_search(b, capi.RULE_BEST, capi.TH_LOW, 0.0, False, k, d, off, feat, claimed, qxyr, qlev, qd, None, ((state == 1) & inimg).astype(np.uint8))
+    got = t2q[:nkf].copy(); got[got == -2] = -1
+    assert n == w[0] and n > 60
+    np.testing.assert_array_equal(got, w[2])
+
+
+@pytest.mark.parametrize("which", [0, 1], ids=["Fuse(pKF, vpMapPoints, th)", "Fuse(pKF, Scw, vpPoints, th)"])
+@pytest.mark.parametrize("seed,nkf,nq,th,crowd", [(111, 1000, 1000, 2.5, False), (112, 1000, 700, 4.0, True), (113, 400, 1000, 2.5, True)])
+def test_fuse(which, seed, nkf, nq, th, crowd):
+    """both Fuse overloads: every map point scans its window on its own (nothing is claimed) -> rule 5 with TH_LOW; the sequence of
+    feature indices the reference fuses into, in query order, is the oracle's"""
+    rng = np.random.default_rng(seed)
+    b = capi.image_bounds(CAM)
+    k = _frame(rng, nkf, crowd)
+    d = synth.descriptors(nkf, seed + 900)
+    off, feat = ol.frame_grid(b, k)
+    featp = np.ascontiguousarray(np.append(feat, 0).astype(np.int32))
+    kf_state = rng.choice([0, 0, 1, 2], nkf).astype(np.uint8)
+    src = rng.integers(0, nkf, nq)
+    qd = _noisy_copies(rng, d, src, 5)
+    world, mind, inimg, qxyr, qlev, cam = _projected_queries(rng, k, src, nq, th, b)
+    state = rng.choice([0, 1, 1, 1, 1, 2] if which == 0 else [1, 1, 1, 1, 2], nq).astype(np.uint8)
+    log = np.zeros(nq + 1, np.int32); nlog = ctypes.c_int()
+    n = ref().ref_fuse(which, ctypes.addressof(b), th, P(cam), P(SCALE), 8, P(k), P(d), P(off), P(featp), nkf, P(kf_state), P(state), P(world), P(mind), P(qd), nq,
+                       P(log), ctypes.addressof(nlog))
+    w = ol.window_search(b, capi.RULE_FREE, capi.TH_LOW, 0.0, False, k, d, off, feat, None, qxyr, qlev, qd, None, ((state == 1) & inimg).astype(np.uint8))
+    want = w[1][w[1] >= 0]
+    assert n == len(want) == nlog.value and n > 60
+    np.testing.assert_array_equal(log[:n], want)
 
 
 def _fvs(pr, levelsup=2):
