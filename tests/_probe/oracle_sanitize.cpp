@@ -29,6 +29,19 @@ int orc_window_search(const void* bounds, int rule, int th, float ratio, int che
                       const int32_t* cell_off, const int32_t* cell_feat, int nt, const uint8_t* claimed_in, const float* qxyr, const int32_t* qlev,
                       const uint8_t* qdesc, const float* qangle, const uint8_t* qvalid, int nq, int32_t* q2t, int32_t* t2q, int32_t* best_out, int32_t* second_out);
 int orc_distinctive(const uint8_t* desc, int N, int32_t* best_median);
+int orc_search_by_bow(int th, float ratio, int check_orientation, const uint32_t* kf_node, const int32_t* kf_off, const uint32_t* kf_feat, int kf_nnodes,
+                      const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_valid, int nKF, const uint32_t* f_node, const int32_t* f_off,
+                      const uint32_t* f_feat, int f_nnodes, const uint8_t* f_desc, const float* f_angle, int nF, int32_t* q2t, int32_t* t2q, int32_t* best_out,
+                      int32_t* second_out);
+int orc_search_by_bow_kf(int th_low, float ratio, int check_orientation, const uint32_t* node1, const int32_t* off1, const uint32_t* feat1, int nnodes1,
+                         const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1, const uint32_t* node2, const int32_t* off2,
+                         const uint32_t* feat2, int nnodes2, const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2, int32_t* q2t, int32_t* t2q);
+int orc_search_for_triangulation(int th_low, int check_orientation, const float* F12, const float* level_sigma2, const uint32_t* node1, const int32_t* off1,
+                                 const uint32_t* feat1, int nnodes1, const void* kps1, const uint8_t* desc1, const uint8_t* has_mp1, int n1,
+                                 const uint32_t* node2, const int32_t* off2, const uint32_t* feat2, int nnodes2, const void* kps2, const uint8_t* desc2,
+                                 const uint8_t* has_mp2, int n2, int32_t* q2t, int32_t* t2q, int32_t* best_out, int32_t* second_out);
+int orc_sim3_agreement(const int32_t* vnMatch1, int N1, const int32_t* vnMatch2, int N2, int32_t* out12);
+int orc_check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float* F12, float sigma2);
 }
 
 int main() {
@@ -104,6 +117,37 @@ int main() {
         for (int rule = 0; rule < 4; rule++)
             checksum += orc_window_search(&b, rule, rule == 3 ? 50 : 100, 0.8f, 1, un.data(), last_desc.data(), off.data(), feat.data(), n, rule == 0 ? cl.data() : nullptr,
                                           qxyr.data(), ql.data(), last_desc.data(), qa.data(), qv.data(), n, q2t.data(), t2q.data(), be.data(), se.data());
+        checksum += orc_window_search(&b, 5, 50, 0.0f, 0, un.data(), last_desc.data(), off.data(), feat.data(), n, nullptr, qxyr.data(), ql.data(),
+                                      last_desc.data(), nullptr, qv.data(), n, q2t.data(), t2q.data(), be.data(), se.data());
+        // the vocabulary-node searches on a FeatureVector of the frame against itself (every third feature dropped on one side), the
+        // agreement check and the epipolar test
+        std::vector<unsigned> node, featv, node2, featv2;
+        std::vector<int32_t> offv(1, 0), offv2(1, 0);
+        for (int i = 0; i < n; i += 16) {
+            node.push_back(100 + i); node2.push_back(100 + i + (i % 64 == 0 ? 1 : 0));
+            for (int j = i; j < i + 16 && j < n; j++) { featv.push_back(j); if (j % 3) featv2.push_back(j); }
+            offv.push_back((int)featv.size()); offv2.push_back((int)featv2.size());
+        }
+        std::vector<uint8_t> mp1(n), mp2(n);
+        for (int i = 0; i < n; i++) { mp1[i] = i % 4 == 0; mp2[i] = i % 5 == 0; }
+        const float F12[9] = {0, 0, 0, 0, 0, -1, 0, 1, 0};
+        const float sig[8] = {1.f, 1.44f, 2.0736f, 2.98598f, 4.29982f, 6.19174f, 8.9161f, 12.8392f};
+        for (int chk = 0; chk < 2; chk++) {
+            checksum += orc_search_by_bow(50, 0.75f, chk, node.data(), offv.data(), featv.data(), (int)node.size(), last_desc.data(), qa.data(), qv.data(), n,
+                                          node2.data(), offv2.data(), featv2.data(), (int)node2.size(), last_desc.data(), qa.data(), n, q2t.data(), t2q.data(),
+                                          be.data(), se.data());
+            checksum += orc_search_by_bow_kf(50, 0.9f, chk, node.data(), offv.data(), featv.data(), (int)node.size(), last_desc.data(), qa.data(), qv.data(), n,
+                                             node2.data(), offv2.data(), featv2.data(), (int)node2.size(), last_desc.data(), qa.data(), cl.data(), n, q2t.data(),
+                                             t2q.data());
+            checksum += orc_search_for_triangulation(50, chk, F12, sig, node.data(), offv.data(), featv.data(), (int)node.size(), un.data(), last_desc.data(),
+                                                     mp1.data(), n, node2.data(), offv2.data(), featv2.data(), (int)node2.size(), un.data(), last_desc.data(),
+                                                     mp2.data(), n, q2t.data(), t2q.data(), be.data(), se.data());
+        }
+        checksum += orc_search_for_triangulation(50, 1, F12, sig, node.data(), offv.data(), featv.data(), 0, un.data(), last_desc.data(), mp1.data(), 0,
+                                                 node2.data(), offv2.data(), featv2.data(), 0, un.data(), last_desc.data(), mp2.data(), 0, q2t.data(), t2q.data(),
+                                                 be.data(), se.data());
+        checksum += orc_sim3_agreement(q2t.data(), n, t2q.data(), n, be.data()) + orc_sim3_agreement(q2t.data(), 0, t2q.data(), 0, be.data());
+        checksum += orc_check_dist_epipolar_line(1.f, 2.f, 3.f, 4.f, F12, 1.f) + orc_check_dist_epipolar_line(0.f, 0.f, 0.f, 0.f, std::vector<float>(9, 0.f).data(), 1.f);
         int32_t med;
         checksum += orc_distinctive(last_desc.data(), 40, &med) + orc_distinctive(last_desc.data(), 1, &med) + orc_distinctive(last_desc.data(), 0, &med);
     }
