@@ -8,7 +8,7 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -ffp-contract=off -Wal
 ORBX_SRCS  := $(wildcard orb_slam_amd/csrc/*.hip)
 ORBX_HDRS  := $(wildcard orb_slam_amd/csrc/*.h orb_slam_amd/csrc/*.inc include/*.h)
 
-all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so oracle_ref orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/cpp/example_lanes tools/microbench/valu_rate
+all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so oracle_ref orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/cpp/example_lanes tools/microbench/valu_rate tools/microbench/valu_rate2
 
 orb_slam_amd/liborbx.so: $(ORBX_SRCS) $(ORBX_HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared $(ORBX_SRCS) -o $@
@@ -39,9 +39,11 @@ orb_slam_amd/cpp/example_lanes: orb_slam_amd/cpp/example_lanes.cpp orb_slam_amd/
 # measurement aid: issue rate of the VALU opcodes the kernels are made of (profiles/r01_valu_issue_rates.txt)
 tools/microbench/valu_rate: tools/microbench/valu_rate.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value $< -o $@
+tools/microbench/valu_rate2: tools/microbench/valu_rate2.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value $< -o $@
 
 clean:
-	rm -f tools/microbench/valu_rate orb_slam_amd/cpp/example_lanes orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
+	rm -f tools/microbench/valu_rate tools/microbench/valu_rate2 orb_slam_amd/cpp/example_lanes orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
 	rm -rf oracle/_ref
 
 .PHONY: all clean oracle_ref

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborbx.so")
+LIB_PATH = os.environ.get("ORBX_LIB") or os.path.join(_HERE, "liborbx.so")      # ORBX_LIB: a differently built library (tuning sweeps)
 
 ORBX_OK, ORBX_EMPTY = 0, 1
 ORBX_ERR_ARG, ORBX_ERR_DEVICE, ORBX_ERR_CAPACITY, ORBX_ERR_GEOMETRY = -1, -2, -3, -4

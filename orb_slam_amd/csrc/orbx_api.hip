@@ -207,7 +207,6 @@ int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int nfra
         b.out_n = d_n + f0;
         b.out_status = d_status ? d_status + f0 : nullptr;
         b.cap = cap;
-        { const char* d = getenv("ORBX_DBG"); b.dbg = d ? atoi(d) : 0; }
         rc = launch_extract(b, h->hg, stream, h->stop_after, &h->timer, &h->side);
         if (rc != ORBX_OK) { h->err = "kernel launch failed (no gfx950 code object for this device?)"; return rc; }
         h->last = b;
@@ -382,7 +381,7 @@ int orbx_debug_geometry(const orbx_params* p, int w, int hgt, int32_t* out, int 
     }
     if (cap_levels < hg.g.nlevels) return ORBX_ERR_CAPACITY;
     if (getenv("ORBX_DBG_GEOM"))
-        fprintf(stderr, "orbx geometry: fast_lds_bytes %d (max_px %d, chunks %d), sel_lds %d, bands %d, cells %d\n", hg.g.fast_lds_bytes, hg.g.fast_max_px,
+        fprintf(stderr, "orbx geometry: fast_lds_bytes %d (band image %d B, chunks %d), sel_lds %d, bands %d, cells %d\n", hg.g.fast_lds_bytes, hg.g.fast_max_img,
                 hg.g.fast_max_chunks, hg.g.sel_lds_cell, (int)hg.bands.size(), (int)hg.cells.size());
     for (int l = 0; l < hg.g.nlevels; l++) {
         const LevelGeom& L = hg.g.lv[l];

@@ -248,23 +248,23 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
             }
         }
     }
-    // LDS carve of k_fast_cells, sized by the largest cell
+    // LDS carve of k_fast_cells, sized by the largest band
     {
-        int max_px = 0, max_img = 0;
+        int max_px = 0, max_img = 0, max_chunks = 0;
         for (const BandGeom& c : out.bands) {
             const int cw = c.x1 - c.x0 + 1, ch = c.ey1 - c.ey0 + 1;
             if (cw <= 0 || ch <= 0) continue;
             max_px = std::max(max_px, cw * ch);
-            if (cw > shape.max_cw) { err = "grid cell wider than " + std::to_string(shape.max_cw) + " pixels"; return ORBX_ERR_CAPACITY; }   // k_fast_cells: the NMS lags one batch (>= 2048 px): a pixel row must be shorter than that
-            if ((cw * ch + threads * shape.ppt - 1) / (threads * shape.ppt) > 32) { err = "grid cell band needs more than 32 k_fast_cells rounds"; return ORBX_ERR_CAPACITY; }   // FastLds::n1[]
+            if (cw > shape.max_cw) { err = "grid cell wider than " + std::to_string(shape.max_cw) + " pixels"; return ORBX_ERR_CAPACITY; }   // row pitch of the staged band <= 2048 (exact float division in the kernel)
             const int nd = (3 + cw + 6 + 3) / 4;
             max_img = std::max(max_img, nd * 4 * (ch + 6));
+            max_chunks = std::max(max_chunks, (nd * 4 * (c.y1 - c.y0 + 1) + 63) / 64);
         }
-        if (max_px > 65535) { err = "grid cell larger than 65535 pixels"; return ORBX_ERR_CAPACITY; }
-        g.fast_max_px = align_up(std::max(max_px, 16), 16);
-        g.fast_max_chunks = align_up((max_px + 63) / 64 + 1, 4);
-        if (g.fast_max_chunks > threads) { err = "k_fast_cells work item above 32768 pixels"; return ORBX_ERR_CAPACITY; }   // list output: one lane per 64-pixel chunk
-        g.fast_lds_bytes = 272 /*sizeof(FastLds)*/ + g.fast_max_chunks * 12 + 3 * fast_qcap(shape) * 2 /*three u16 queues*/ + g.fast_max_px + align_up(max_img, 16) + 16;
+        // pixel offsets inside the staged band are 16-bit, dword indices 14-bit
+        if (max_px > 65535 || max_img > 65536) { err = "grid cell band larger than 64 KiB with its halo"; return ORBX_ERR_CAPACITY; }
+        g.fast_max_img = align_up(std::max(max_img, 16), 16);
+        g.fast_max_chunks = align_up(max_chunks + 1, 2);
+        g.fast_lds_bytes = 64 /*sizeof(FastHdr)*/ + g.fast_max_chunks * 8 + (threads / 64) * fast_wave_queue_bytes(shape.ppt) + 2 * g.fast_max_img + 16;
         if (g.fast_lds_bytes > 160 * 1024) { err = "grid cell does not fit the 160 KiB LDS"; return ORBX_ERR_CAPACITY; }
     }
     {
@@ -296,36 +296,39 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
 
 
 // Shape of k_fast_cells (orbx_internal.h: FAST_SMALL / FAST_LARGE).  VGA-class grids (largest cell view <= 12288 px and at most
-// 500 px wide) take the small shape: 256 threads over 8192-pixel bands with short queues — ~20 KB of LDS, 8 independent work
-// items per CU (0.907 -> 0.79 ms per 512 VGA frames; 720p / 1080p lose 2-7 % with it).  Everything else takes the large shape:
-// 512 threads over 10240-pixel bands, 4 work items per CU as long as one needs <= 40 KB; where the cell shape pushes it over,
-// slightly smaller bands restore the fourth.
+// 500 px wide) take the small shape: 256 threads over 8192-pixel bands.  Everything else takes the large shape: 512 threads over
+// 10240-pixel bands, 4 work items per CU as long as one needs <= 40 KB; where the cell shape pushes it over, slightly smaller
+// bands restore the fourth.
 int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::string& err) {
     constexpr int LDS_FOR_FOUR = (160 * 1024) / 4 - 64;
-    if (!getenv("ORBX_FAST512")) {
+    const FastShape small = FAST_SMALL, large = FAST_LARGE;
+    {
         HostGeom trial;
         std::string e2;
-        if (build_geometry_band(p, w, h, trial, e2, FAST_SMALL.band_px, FAST_SMALL) == ORBX_OK) {
+        if (build_geometry_band(p, w, h, trial, e2, small.band_px, small) == ORBX_OK) {
             int max_cell_px = 0;
             for (const CellGeom& c : trial.cells) max_cell_px = std::max(max_cell_px, (c.x1 - c.x0 + 1) * (c.y1 - c.y0 + 1));
             if (max_cell_px <= 12288) {
                 out = trial;
-                out.g.fast_threads = FAST_SMALL.threads;
+                out.g.fast_threads = small.threads;
+                out.g.fast_small = 1;
                 err.clear();
                 return ORBX_OK;
             }
         }
     }
-    int rc = build_geometry_band(p, w, h, out, err, FAST_LARGE.band_px, FAST_LARGE);
+    int rc = build_geometry_band(p, w, h, out, err, large.band_px, large);
     if (rc != ORBX_OK) return rc;
-    out.g.fast_threads = FAST_LARGE.threads;
+    out.g.fast_threads = large.threads;
+    out.g.fast_small = 0;
     if (out.g.fast_lds_bytes <= LDS_FOR_FOUR) return rc;
-    for (int band = FAST_LARGE.band_px - 512; band >= 8192; band -= 512) {
+    for (int band = large.band_px - 512; band >= 8192; band -= 512) {
         HostGeom trial;
         std::string e2;
-        if (build_geometry_band(p, w, h, trial, e2, band, FAST_LARGE) == ORBX_OK && trial.g.fast_lds_bytes <= LDS_FOR_FOUR) {
+        if (build_geometry_band(p, w, h, trial, e2, band, large) == ORBX_OK && trial.g.fast_lds_bytes <= LDS_FOR_FOUR) {
             out = trial;
-            out.g.fast_threads = FAST_LARGE.threads;
+            out.g.fast_threads = large.threads;
+            out.g.fast_small = 0;
             err.clear();
             return ORBX_OK;
         }

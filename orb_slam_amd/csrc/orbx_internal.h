@@ -72,20 +72,22 @@ constexpr int DESC_WAVES = ORBX_DESC_WAVES;   // k_describe: keypoints (waves) p
 #endif
 constexpr int BLUR_ROWS = ORBX_BLUR_ROWS;   // k_blur: output rows per wave strip
 constexpr int RZ_ROWS = ORBX_RZ_ROWS;       // k_resize: output rows per workgroup (a tall tile amortises the table -> source -> LDS latency chain)
-// The two launch shapes of k_fast_cells (threads per work item, pixels per lane per round, queue slack).  A round scans
-// threads * ppt pixels; the compass queue holds one round plus `slack` entries and a batch of rounds is flushed through the
-// later phases once it holds more than `slack` survivors.  Because the NMS lags one batch, a pixel row of the cell view must
-// be shorter than a round (checked on the host: FastShape::max_cw).
-struct FastShape { int threads, ppt, slack, band_px, max_cw; };
+// The two launch shapes of k_fast_cells: threads per work item, dwords (4 pixels) per lane and round, band size in pixels, widest
+// cell.  Per WAVE the kernel keeps a queue of flagged dwords (one round plus one slice of 64), of expanded pixel offsets (a slice of
+// 64 dwords = up to 256 pixels on top of a remainder < 64), of pair-test survivors (one step of 64 on top of a remainder < 64)
+// and of scored corners (the NMS work list; a band that overflows it takes a dense sweep instead).
+struct FastShape { int threads, ppt, band_px, max_cw; };
 #ifndef ORBX_FS
-#define ORBX_FS 256, 2, 256, 8192, 500
+#define ORBX_FS 256, 2, 8192, 500
 #endif
-constexpr FastShape FAST_SMALL = {ORBX_FS};     // VGA-class grids: ~20 KB of LDS, 8 work items per CU
 #ifndef ORBX_FL
-#define ORBX_FL 512, 4, 512, 10240, 2000
+#define ORBX_FL 512, 2, 10240, 2000
 #endif
-constexpr FastShape FAST_LARGE = {ORBX_FL};   // 720p / 1080p-class grids: ~38 KB, 4 work items per CU
-constexpr int fast_qcap(const FastShape& f) { return f.threads * f.ppt + f.slack; }
+constexpr FastShape FAST_SMALL = {ORBX_FS};   // VGA-class grids
+constexpr FastShape FAST_LARGE = {ORBX_FL};   // 720p / 1080p-class grids
+constexpr int FAST_Q1CAP = 320, FAST_Q2CAP = 128, FAST_Q3CAP = 256;
+constexpr int fast_q0cap(int ppt) { return 64 * ppt + 64; }
+constexpr int fast_wave_queue_bytes(int ppt) { return fast_q0cap(ppt) * 4 + FAST_Q1CAP * 2 + FAST_Q2CAP * 2 + FAST_Q3CAP * 2; }
 struct BandGeom {
     int16_t x0, x1;           // the cell's column range (inclusive)
     int16_t y0, y1;           // rows this band owns (inclusive)
@@ -109,8 +111,9 @@ struct DevGeom {
     int frame_cands;         // Cand slots per frame
     int frame_sel;           // sel slots per frame
     int sel_lds_cell, sel_lds_level, sel_lds_entries;   // LDS bytes of k_cell_select / k_level_select and the list entries they stage
-    int fast_max_px, fast_max_chunks, fast_lds_bytes;   // k_fast_cells LDS carve (largest cell of any level)
-    int fast_threads;        // k_fast_cells workgroup size chosen for this geometry (256 or 512)
+    int fast_max_img, fast_max_chunks, fast_lds_bytes;   // k_fast_cells LDS carve: staged image bytes (= score plane bytes) of the largest band, 64-byte chunks of a band's own rows
+    int fast_threads;        // k_fast_cells workgroup size chosen for this geometry
+    int fast_small;          // 1: the small launch shape (VGA-class grids), 0: the large one
     int umax[HALF_PATCH + 1];
     // per-level bases as compact arrays: one scalar load each, so a wave finds its level in a single round trip
     // (walking lv[l].xxx_base level by level was a chain of up to nlevels dependent scalar loads, ~1.5 us per wave)
@@ -144,7 +147,6 @@ struct Batch {
     int32_t* out_status;      // optional [frame]
     int cap;
     int nframes;
-    int dbg;                  // ablation switches for kernel tuning (ORBX_DBG env; 0 in production)
 };
 
 // Host-side geometry builder result.

@@ -14,6 +14,7 @@
 // taps <= 3 px, rotated BRIEF taps <= 2 px outside the ROI) are served by reflect-101 index math,
 // which is what copyMakeBorder(BORDER_REFLECT_101) materialises.
 #include <algorithm>
+#include <type_traits>
 
 #include "orb_math.h"
 #include "orbx_internal.h"
@@ -145,31 +146,9 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
     }
 }
 
-// ------------------------------------------------------------------------------------ FAST + NMS + cell lists
-// One workgroup = one grid cell of one level of one frame (or one row band of a big cell) — the unit the reference
-// calls cv::FAST on (src/ORBextractor.cc:599-614).  Because the NMS of cv::FAST never looks outside the cell view, a
-// cell-native workgroup needs no score halo towards other cells, no survivor plane in HBM and no compaction pass:
-//   1. stage the cell's pixels (+3 halo) in LDS with pipelined dword loads;
-//   2. rounds of 2048 pixels —
-//      A1: every lane tests 4 pixels against the 4 compass ring pixels (two of them, with one polarity, must be beyond the
-//          threshold: exact necessary condition); survivors are queued in LDS by __ballot/popcount;
-//      A2: dense over that queue, OpenCV's opposite-pair pre-test on the raw ring bytes; survivors queued again;
-//      B : dense over those, the exact FAST-9 score (9-arc extrema of the RAW ring bytes by two rounds of
-//          v_min3/v_max3: dark = v - min_arcs(max9), bright = max_arcs(min9) - v);
-//      N : 3x3 strict NMS, dense over the PREVIOUS round's scored pixels (all their neighbours are scored by then);
-//          survivors of the band's own rows set their bit in an LDS bitmask;
-//   3. a wave-level scan over the bitmask popcounts gives list offsets and the keypoint list comes out in cv::FAST's
-//      raster order together with its counts at fastTh and at 7.
-constexpr int FAST_MAX_ROUNDS = 32;   // cells hold < 65536 pixels (checked on the host)
-
 typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2v as_us2v(uint32_t v) { return __builtin_bit_cast(us2v, v); }
 
-struct FastLds {
-    int n1[FAST_MAX_ROUNDS];   // per round: pixels that passed the compass test
-    int n2[FAST_MAX_ROUNDS];   // per round: pixels that passed the opposite-pair test (get an exact score)
-    int n_hi, n_lo, n_all, pad;
-};
 
 __device__ __forceinline__ int fast_pair_test(const uint8_t* c, int S, int v, int t) {
     // ring offsets k=0..15 (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
@@ -191,274 +170,333 @@ __device__ __forceinline__ int fast_score_raw(const uint8_t* c, int S, int v, in
         hi3[k] = imax3(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
         lo3[k] = imin3(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
     }
-    int min_hi9 = 255, max_lo9 = 0;
+    int hi9[16], lo9[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        min_hi9 = imin(min_hi9, imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
-        max_lo9 = imax(max_lo9, imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
+        hi9[k] = imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+        lo9[k] = imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
     }
+    // 16 -> 1 with three-input ops (8 instead of 16 two-input ones)
+    const int min_hi9 = imin3(imin3(imin3(hi9[0], hi9[1], hi9[2]), imin3(hi9[3], hi9[4], hi9[5]), imin3(hi9[6], hi9[7], hi9[8])),
+                              imin3(imin3(hi9[9], hi9[10], hi9[11]), imin3(hi9[12], hi9[13], hi9[14]), hi9[15]), 255);
+    const int max_lo9 = imax3(imax3(imax3(lo9[0], lo9[1], lo9[2]), imax3(lo9[3], lo9[4], lo9[5]), imax3(lo9[6], lo9[7], lo9[8])),
+                              imax3(imax3(lo9[9], lo9[10], lo9[11]), imax3(lo9[12], lo9[13], lo9[14]), lo9[15]), 0);
     const int s = imax(v - min_hi9, max_lo9 - v) - 1;   // == OpenCV cornerScore for every corner
     return s >= tmin ? s : 0;
 }
 
-// wave-aggregated append of the lanes with `pass` to an LDS queue; returns nothing, order inside the queue is irrelevant
-__device__ __forceinline__ void queue_push(uint16_t* q, int* counter, int pass, int value, int lane, unsigned long long lt) {
-    const unsigned long long m = __ballot(pass);
-    if (m) {
-        int qb = 0;
-        if (lane == 0) qb = atomicAdd(counter, __popcll(m));
-        qb = __shfl(qb, 0, 64);
-        if (pass) q[qb + __popcll(m & lt)] = (uint16_t)value;
-    }
-}
+// ------------------------------------------------------------------------------------ FAST + NMS + cell lists
+// One workgroup = one grid cell of one level of one frame (or one row band of a big cell) — the unit the reference
+// calls cv::FAST on (src/ORBextractor.cc:599-614).  Because the NMS of cv::FAST never looks outside the cell view, a
+// cell-native workgroup needs no score halo towards other cells, no survivor plane in HBM and no compaction pass.
+// One score pass at min(fastTh, 7) serves the normal threshold and the reference's threshold-7 fallback (score >= t <=> corner at t).
+// Phases: stage the band (+3 halo) in LDS -> A1 dense compass test -> A2 opposite-pair test (sparse) -> B exact score (sparse)
+// -> N 3x3 strict NMS -> raster-ordered list with its counts at fastTh and at 7.  (Round 2 form; the round-1 kernel — flat pixel
+// index per lane, block-wide queues with a barrier per phase — took 1.51 ms per 1024 VGA frames, this one 1.11.)
+//   * everything is addressed by the pixel's BYTE OFFSET q inside the staged LDS image (pitch S): the score plane has the
+//     image's layout, so ring / neighbour addresses are q +- dy*S + dx with no division anywhere in the dense or sparse phases;
+//   * A1 is SWAR: a lane tests 4 horizontally adjacent pixels (one aligned dword) per step.  Bytes are unpacked to two
+//     16-bit-field dwords (even / odd pixels); with the bias K = 0x8000 - t - 1 per field, "x < v - t" is bit 15 of (v + K) - x
+//     and "x > v + t" is bit 15 of x + (K - v) — plain v_add / v_sub / v_and / v_or / v_bitop3, which issue at twice the rate of
+//     v_min / v_max / v_cmp on gfx950 (profiles/r01_valu_issue_rates.txt, r02_valu_issue_rates2.txt).  Rule: a 9-arc of the
+//     16-ring contains ring 0 or 8 AND ring 4 or 12, so a corner needs (N | S) & (E | W) beyond the threshold with one polarity —
+//     an exact necessary condition.  (gfx950 serves unaligned ds_read_b32, but slowly: reading the E / W dwords that way instead
+//     of two v_alignbyte cost +44 % on the kernel);
+//   * flagged dwords are queued per WAVE (ballot + mbcnt, no atomics), expanded to pixels, pair-tested and scored by the same
+//     wave in full-wave slices: no workgroup barrier between staging and the NMS;
+//   * every wave remembers the pixels it gave a score; the NMS visits those (a dense sweep over the score plane only where a
+//     wave's list overflowed: noise-like bands), survivors set bits in a q-space bitmask, the raster-ordered list comes from
+//     the same chunk scan as before.
+struct FastHdr { int n_hi, n_lo, overflow, pad1; int wsum[8]; int pad2[4]; };
+static_assert(sizeof(FastHdr) == 64, "LDS carve");
 
-// FAST_THREADS: 512 (8 waves: 1080p-class grids, ~40 KB LDS per work item, 4 items per CU) or 256 (VGA-class grids: smaller bands,
-// ~28 KB, 5 items per CU — more independent latency chains in flight)
-template <bool ALIGNED, int FAST_THREADS, int FAST_PPT, int FAST_SLACK>
+__device__ __forceinline__ int lane_rank(unsigned long long m) {   // number of set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+template <bool ALIGNED, int NT, int PPT>
 __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t* smem) {
-    constexpr int FAST_ROUND = FAST_THREADS * FAST_PPT;   // pixels per round
-    constexpr int FAST_QCAP = FAST_ROUND + FAST_SLACK;
+    constexpr int NW = NT / 64;
+    constexpr int Q0CAP = fast_q0cap(PPT), Q1CAP = FAST_Q1CAP, Q2CAP = FAST_Q2CAP, Q3CAP = FAST_Q3CAP;
+    constexpr int WQ_BYTES = fast_wave_queue_bytes(PPT);
     const DevGeom& g = b.g;
     const int frame = task / g.nbands_total;
     const int item = task - frame * g.nbands_total;
     const BandGeom bg = b.bands[item];
     const int level = bg.level;
     const LevelGeom& L = g.lv[level];
-    // the band scores rows ey0..ey1 (its own rows plus one halo row towards neighbouring bands of the same cell) and
-    // emits survivors of its own rows y0..y1 only; below, "cell" coordinates are relative to (x0, ey0)
-    struct { int x0, y0, x1, y1; } cg = {bg.x0, bg.ey0, bg.x1, bg.ey1};
-    const int own_lo = bg.y0 - bg.ey0, own_hi = bg.y1 - bg.ey0;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
-    const int cw = cg.x1 - cg.x0 + 1, ch = cg.y1 - cg.y0 + 1;
+    const int cw = bg.x1 - bg.x0 + 1, ch = bg.ey1 - bg.ey0 + 1;      // scored rectangle: own rows + halo rows towards sibling bands
     CellState* cst = b.cstate + (long long)frame * g.nbands_total + item;
     if (cw <= 0 || ch <= 0) {
         if (tid == 0) { CellState st; st.n_all = 0; st.n_hi = 0; st.n_lo = 0; *cst = st; }
         return;
     }
-    const int npx = cw * ch;
-    const int nchunks = (npx + 63) >> 6;
-    // LDS carve (all offsets multiples of 16): header | survivor bit masks | chunk offsets | queues | scores | image
-    FastLds* hdr = reinterpret_cast<FastLds*>(smem);
-    unsigned long long* cmask = reinterpret_cast<unsigned long long*>(smem + sizeof(FastLds));
-    int* coffs = reinterpret_cast<int*>(smem + sizeof(FastLds) + g.fast_max_chunks * 8);
-    uint16_t* q1 = reinterpret_cast<uint16_t*>(smem + sizeof(FastLds) + g.fast_max_chunks * 12);
-    uint16_t* q2 = q1 + FAST_QCAP;                  // two buffers: the NMS of batch i-1 runs after batch i has been scored
-    uint8_t* s_sc = reinterpret_cast<uint8_t*>(q2 + 2 * FAST_QCAP);
-    uint8_t* s_img = s_sc + g.fast_max_px;
-    // image region: rows y0-3..y1+3, columns from the dword-aligned start at or left of x0-3
-    const int gxb = (cg.x0 - 3) & ~3;
-    const int xoff = (cg.x0 - 3) - gxb;
+    const int own_lo = bg.y0 - bg.ey0, own_hi = bg.y1 - bg.ey0;
+    // staged image: rows ey0-3 .. ey1+3, columns from the dword-aligned start at or left of x0-3; pixel (x, y) of the band
+    // (relative to (x0, ey0)) lives at byte offset q = (y + 3) * S + x + xoff + 3
+    const int gxb = (bg.x0 - 3) & ~3;
+    const int xoff = (bg.x0 - 3) - gxb;
     const int nd = (xoff + cw + 6 + 3) >> 2;
     const int S = nd * 4;
-    long long stride;
-    const uint8_t* src = plain_plane(b, L, level, frame, stride);
-    {
-        // flattened (row, dword) items, 8 independent loads in flight per lane
-        const int total = (ch + 6) * nd;
-        const float inv_nd = 1.0f / (float)nd;
-        const uint8_t* src0 = src + (long long)(cg.y0 - 3) * stride + gxb;
-        const int xm = L.w - 1 - gxb;   // unaligned path: never read past the row end
-        for (int i0 = 0; i0 < ((b.dbg & 8) ? 0 : total); i0 += FAST_THREADS * 8) {
+    const int x_first = xoff + 3;
+    const int nrows = ch + 6;
+    // LDS carve: header | survivor bit masks | per-wave queues | image | scores (image layout)
+    FastHdr* hdr = reinterpret_cast<FastHdr*>(smem);
+    unsigned long long* cmask = reinterpret_cast<unsigned long long*>(smem + sizeof(FastHdr));
+    uint8_t* wq = smem + sizeof(FastHdr) + g.fast_max_chunks * 8 + wave * WQ_BYTES;
+    uint32_t* q0 = reinterpret_cast<uint32_t*>(wq);
+    uint16_t* q1 = reinterpret_cast<uint16_t*>(wq + Q0CAP * 4);
+    uint16_t* q2 = q1 + Q1CAP;
+    uint16_t* q3 = q2 + Q2CAP;
+    uint8_t* s_img = smem + sizeof(FastHdr) + g.fast_max_chunks * 8 + NW * WQ_BYTES;
+    uint8_t* s_sc = s_img + g.fast_max_img;
+    const int q_own_lo = (3 + own_lo) * S, q_own_hi = (3 + own_hi + 1) * S;      // byte offsets of the band's own rows
+    const int nchunks = (q_own_hi - q_own_lo + 63) >> 6;
+    long long stride64;
+    const uint8_t* src = plain_plane(b, L, level, frame, stride64);
+    auto clear_lds = [&]() {
+        for (int i = tid; i < ((nrows * S + 15) >> 4); i += NT) reinterpret_cast<uint4*>(s_sc)[i] = make_uint4(0, 0, 0, 0);
+        if (tid < (int)(sizeof(FastHdr) / 4)) reinterpret_cast<int*>(hdr)[tid] = 0;
+        for (int i = tid; i < nchunks; i += NT) cmask[i] = 0ull;
+    };
+    if (ALIGNED) {
+        // LDS-DMA staging: one global_load_lds_dword per (row, 64-dword piece) — lane i's dword lands at M0 + 4 i, i.e. in image
+        // order.  No VGPRs, no ds_write, no per-lane address arithmetic (row bases are scalars); a wave issues all its rows back
+        // to back and waits once.
+        typedef const void __attribute__((address_space(1))) * gptr_t;
+        typedef void __attribute__((address_space(3))) * lptr_t;
+        const uint8_t* src0 = src + (long long)(bg.ey0 - 3) * stride64 + gxb;
+        for (int c0 = 0; c0 < nd; c0 += 64) {
+            const bool on = c0 + lane < nd;
+            for (int r = wave; r < nrows; r += NW) {
+                const uint8_t* grow = src0 + (long long)r * stride64 + 4 * c0;      // wave-uniform
+                if (on) __builtin_amdgcn_global_load_lds((gptr_t)(grow + 4 * lane), (lptr_t)(s_img + 4 * (r * nd + c0)), 4, 0, 0);
+            }
+        }
+        clear_lds();                                    // rides on the latency of the loads just issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA writes of THIS wave have landed; the barrier below covers the others
+    } else {
+        // unaligned frames (level 0 only): flattened (row, dword) items assembled from byte loads, 8 in flight per lane
+        const int total = nrows * nd;
+        const float inv_nd0 = 1.0f / (float)nd;
+        const uint8_t* src0 = src + (long long)(bg.ey0 - 3) * stride64 + gxb;
+        const int xm = L.w - 1 - gxb;   // never read past the row end
+        for (int i0 = 0; i0 < total; i0 += NT * 8) {
             uint32_t v4[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int i = i0 + k * FAST_THREADS + tid;
+                const int i = i0 + k * NT + tid;
                 v4[k] = 0;
                 if (i < total) {
                     int r, d;
-                    split_px(i, nd, inv_nd, r, d);
-                    const uint8_t* row = src0 + (long long)r * stride;
-                    if (ALIGNED) v4[k] = *reinterpret_cast<const uint32_t*>(row + 4 * d);
-                    else v4[k] = (uint32_t)row[imin(4 * d, xm)] | (uint32_t)row[imin(4 * d + 1, xm)] << 8 | (uint32_t)row[imin(4 * d + 2, xm)] << 16 |
-                                 (uint32_t)row[imin(4 * d + 3, xm)] << 24;
+                    split_px(i, nd, inv_nd0, r, d);
+                    const uint8_t* row = src0 + (long long)r * stride64;
+                    v4[k] = (uint32_t)row[imin(4 * d, xm)] | (uint32_t)row[imin(4 * d + 1, xm)] << 8 | (uint32_t)row[imin(4 * d + 2, xm)] << 16 |
+                            (uint32_t)row[imin(4 * d + 3, xm)] << 24;
                 }
             }
-            if (i0 == 0) {
-                // the clears of the other LDS regions ride on the latency of the loads just issued
-                for (int i = tid; i < (g.fast_max_px >> 4); i += FAST_THREADS) reinterpret_cast<uint4*>(s_sc)[i] = make_uint4(0, 0, 0, 0);
-                for (int i = tid; i < (int)(sizeof(FastLds) / 4); i += FAST_THREADS) reinterpret_cast<int*>(hdr)[i] = 0;
-                for (int i = tid; i < nchunks; i += FAST_THREADS) cmask[i] = 0ull;
-            }
+            if (i0 == 0) clear_lds();
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int i = i0 + k * FAST_THREADS + tid;
-                if (i < total) reinterpret_cast<uint32_t*>(s_img)[i] = v4[k];   // row r, dword d  ==  r*nd + d  (S = 4*nd)
+                const int i = i0 + k * NT + tid;
+                if (i < total) reinterpret_cast<uint32_t*>(s_img)[i] = v4[k];
             }
-        }
-        if (b.dbg & 8) {   // development switch "no image staging": the clears still have to happen
-            for (int i = tid; i < (g.fast_max_px >> 4); i += FAST_THREADS) reinterpret_cast<uint4*>(s_sc)[i] = make_uint4(0, 0, 0, 0);
-            for (int i = tid; i < (int)(sizeof(FastLds) / 4); i += FAST_THREADS) reinterpret_cast<int*>(hdr)[i] = 0;
-            for (int i = tid; i < nchunks; i += FAST_THREADS) cmask[i] = 0ull;
         }
     }
     __syncthreads();
 
-    const float inv_cw = 1.0f / (float)cw;
     const int tmin = g.tmin;
-    const uint8_t* img0 = s_img + 3 * S + xoff + 3;         // pixel (0,0) of the cell
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    const float inv_nd = 1.0f / (float)nd;
+    int n0 = 0, n1 = 0, n2 = 0, n3 = 0;          // fill of this wave's queues (wave-uniform)
 
-    // 3x3 strict NMS of the scored pixels of one finished round (dense over its queue); survivors set their bit
-    auto nms_round = [&](const uint16_t* q, int n) {
-        for (int i = tid; i < n; i += FAST_THREADS) {
-            const int p = q[i];
-            const int s = s_sc[p];
-            if (s) {
-                int y, x;
-                split_px(p, cw, inv_cw, y, x);
-                const uint8_t* sp = s_sc + p;
-                // neighbours outside the cell count as 0 (cv::FAST on the cell view): offsets are clamped to stay inside
-                // the score array and the values masked, so the 8 LDS loads are independent and branch-free
-                const int dl = x > 0 ? -1 : 0, dr = x < cw - 1 ? 1 : 0, du = y > 0 ? -cw : 0, dd = y < ch - 1 ? cw : 0;
-                const int nl = sp[dl], nr = sp[dr], nu = sp[du], nd_ = sp[dd];
-                const int nul = sp[du + dl], nur = sp[du + dr], ndl = sp[dd + dl], ndr = sp[dd + dr];
-                int mx = imax3(dl ? nl : 0, dr ? nr : 0, du ? nu : 0);
-                mx = imax3(mx, dd ? nd_ : 0, (du && dl) ? nul : 0);
-                mx = imax3(mx, (du && dr) ? nur : 0, (dd && dl) ? ndl : 0);
-                mx = imax(mx, (dd && dr) ? ndr : 0);
-                if (s > mx && y >= own_lo && y <= own_hi) {
-                    atomicOr(&cmask[p >> 6], 1ull << (p & 63));
-                    if (s >= g.fast_th) atomicAdd(&hdr->n_hi, 1);   // survivors are rare: LDS atomics beat a wave reduction
-                    if (s >= 7) atomicAdd(&hdr->n_lo, 1);
-                }
-            }
+    // B: exact FAST score of m <= 64 queued pixels (all of them passed the pair test); scored corners are remembered in q3
+    auto score_step = [&](const uint16_t* q, int m) {
+        int p = 0, sc = 0;
+        if (lane < m) {
+            p = q[lane];
+            const uint8_t* c = s_img + p;
+            sc = fast_score_raw(c, S, c[0], tmin);
+            s_sc[p] = (uint8_t)sc;
+        }
+        const unsigned long long mk = __ballot(sc != 0);
+        if (mk) {
+            const int add = __popcll(mk);
+            if (n3 + add <= Q3CAP) { if (sc) q3[n3 + lane_rank(mk)] = (uint16_t)p; }
+            n3 += add;                              // beyond Q3CAP: the band takes the dense NMS sweep
         }
     };
+    // A2: OpenCV's opposite-pair pre-test of m <= 64 queued pixels; survivors go to q2, which is scored whenever it holds a full wave
+    auto pair_step = [&](const uint16_t* q, int m) {
+        int pass = 0, p = 0;
+        if (lane < m) {
+            p = q[lane];
+            const uint8_t* c = s_img + p;
+            pass = fast_pair_test(c, S, c[0], tmin);
+        }
+        const unsigned long long mk = __ballot(pass);
+        if (mk) {
+            if (pass) q2[n2 + lane_rank(mk)] = (uint16_t)p;
+            n2 += __popcll(mk);
+            if (n2 >= 64) { n2 -= 64; score_step(q2 + n2, 64); }
+        }
+    };
+    // expansion of m <= 64 flagged dwords into pixel offsets (pixels of the alignment / halo columns are dropped here)
+    auto expand_step = [&](const uint32_t* q, int m) {
+        uint32_t e = 0;
+        if (lane < m) e = q[lane];
+        const int idx = (int)(e & 0x3FFFu);
+        int r, d;
+        split_px(idx, nd, inv_nd, r, d);
+        const int col0 = 4 * d - x_first;                                   // band column of the dword's first pixel
+        // flag bits: pixel 0 -> bit 15, 1 -> bit 14, 2 -> bit 31, 3 -> bit 30
+        const int f[4] = {(int)((e >> 15) & 1u) & (int)((unsigned)col0 < (unsigned)cw), (int)((e >> 14) & 1u) & (int)((unsigned)(col0 + 1) < (unsigned)cw),
+                          (int)((e >> 31) & 1u) & (int)((unsigned)(col0 + 2) < (unsigned)cw), (int)((e >> 30) & 1u) & (int)((unsigned)(col0 + 3) < (unsigned)cw)};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long mk = __ballot(f[j]);
+            if (mk) {
+                if (f[j]) q1[n1 + lane_rank(mk)] = (uint16_t)(4 * idx + j);
+                n1 += __popcll(mk);
+            }
+        }
+        while (n1 >= 64) { n1 -= 64; pair_step(q1 + n1, 64); }
+    };
 
-    // Rounds of 2048 pixels run A1 and append to q1; the later phases run per BATCH of rounds, flushed once q1 holds more
-    // than FAST_QCAP - FAST_ROUND entries (or at the end): on ordinary images one or two flushes per cell instead of one
-    // per round, i.e. fewer barriers and full waves in A2 / B / N.  Batches cover whole rounds (> 1 pixel row each), so the
-    // neighbours of a batch's pixels lie in the previous, the same or the next batch: N lags by one batch.
-    int batch = 0, rnd = 0, qfill = 0;   // qfill: entries in q1 (block-uniform; every lane adds the final per-round counts)
-    const int npx_scan = (b.dbg & 4) ? imin(npx, 1) : npx;
-    for (int base = 0; base < npx_scan; base += FAST_ROUND, rnd++) {
-        uint16_t* q2cur = q2 + (batch & 1) * FAST_QCAP;
-        // A1: compass test on every pixel
-        {
-            int pass[FAST_PPT];
-            unsigned long long pm[FAST_PPT];
-            int cnt = 0;
-            // all 4 pixels' loads are issued before any test (addresses clamped into the cell, results masked)
-            // Any 9 contiguous ring positions contain at least TWO of the 4 compass positions (0,4,8,12), so a corner needs
-            // two compass pixels beyond the threshold with the same polarity: the 2nd smallest must be < v - t or the 2nd
-            // largest > v + t.  (With only ">= 1 compass pixel" 42 % of the S-blocks pixels passed — every pixel within
-            // 3 px of an edge; the pair rule rejects straight axis-aligned edges: 4x fewer pixels reach the pair test.)
-            int vv[FAST_PPT], s2[FAST_PPT], s3[FAST_PPT];
+    // A1: SWAR compass test, 4 pixels per lane and step (see the header of this section)
+    const uint32_t M8 = 0x00FF00FFu, HH = 0x80008000u;
+    const uint32_t KD = (uint32_t)(0x8000 - tmin - 1) * 0x00010001u;
+    auto compass4 = [&](uint32_t C, uint32_t E, uint32_t W, uint32_t Nn, uint32_t Ss) -> uint32_t {
+        uint32_t P[2];
 #pragma unroll
-            for (int k = 0; k < FAST_PPT; k++) {
-                const int p = imin(base + k * FAST_THREADS + tid, npx - 1);
-                int y, x;
-                split_px(p, cw, inv_cw, y, x);
-                const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
-                const int x0 = c[3 * S], x4 = c[3], x8 = c[-3 * S], x12 = c[-3];
-                vv[k] = c[0];
-                const int lo1 = imin(x0, x4), hi1 = imax(x0, x4), lo2 = imin(x8, x12), hi2 = imax(x8, x12);
-                const int a = imax(lo1, lo2), bq = imin(hi1, hi2);
-                s2[k] = imin(a, bq);     // 2nd smallest of the four
-                s3[k] = imax(a, bq);     // 2nd largest
-            }
+        for (int hlf = 0; hlf < 2; hlf++) {
+            const uint32_t c = hlf ? (C >> 8) & M8 : C & M8, n = hlf ? (Nn >> 8) & M8 : Nn & M8, s = hlf ? (Ss >> 8) & M8 : Ss & M8,
+                           e = hlf ? (E >> 8) & M8 : E & M8, w = hlf ? (W >> 8) & M8 : W & M8;
+            const uint32_t vd = c + KD, vb = KD - c;
+            const uint32_t dk = ((vd - n) | (vd - s)) & ((vd - e) | (vd - w));
+            const uint32_t br = ((n + vb) | (s + vb)) & ((e + vb) | (w + vb));
+            P[hlf] = dk | br;
+        }
+        return (P[0] & HH) | ((P[1] & HH) >> 1);
+    };
+    const int i_begin = 3 * nd, i_end = (ch + 3) * nd;          // dwords of the scored rows (all columns of the staged image)
+    constexpr int RG = NW * 64 * PPT;                            // dwords per round of the workgroup
+    auto round = [&](auto full_c, int base) {
+        constexpr bool FULL = decltype(full_c)::value;          // every lane's PPT dwords lie below i_end: constant LDS offsets, no masking
+        const int i0 = base + wave * 64 + lane;
+        uint32_t C[PPT], E[PPT], W[PPT], Nn[PPT], Ss[PPT];
 #pragma unroll
-            for (int k = 0; k < FAST_PPT; k++) {
-                const int p = base + k * FAST_THREADS + tid;
-                pass[k] = p < npx && ((vv[k] - s2[k] > tmin) | (s3[k] - vv[k] > tmin));
-                pm[k] = __ballot(pass[k]);
-                cnt += __popcll(pm[k]);
-            }
-            if (cnt) {
-                int qb = 0;
-                if (lane == 0) qb = qfill + atomicAdd(&hdr->n1[rnd], cnt);   // per-round counter: final once the barrier is passed
-                qb = __shfl(qb, 0, 64);
+        for (int k = 0; k < PPT; k++) {
+            const int ik = FULL ? i0 + k * NW * 64 : imin(i0 + k * NW * 64, i_end - 1);
+            const uint8_t* pk = s_img + 4 * ik;
+            C[k] = *reinterpret_cast<const uint32_t*>(pk);
+            E[k] = __builtin_amdgcn_alignbyte(*reinterpret_cast<const uint32_t*>(pk + 4), C[k], 3);   // pixels x+3 .. x+6
+            W[k] = __builtin_amdgcn_alignbyte(C[k], *reinterpret_cast<const uint32_t*>(pk - 4), 1);   // pixels x-3 .. x
+            Nn[k] = *reinterpret_cast<const uint32_t*>(pk - 3 * S);
+            Ss[k] = *reinterpret_cast<const uint32_t*>(pk + 3 * S);
+        }
 #pragma unroll
-                for (int k = 0; k < FAST_PPT; k++) {
-                    if (pass[k]) q1[qb + __popcll(pm[k] & lt)] = (uint16_t)(base + k * FAST_THREADS + tid);
-                    qb += __popcll(pm[k]);
-                }
+        for (int k = 0; k < PPT; k++) {
+            const int i = i0 + k * NW * 64;
+            uint32_t Q = compass4(C[k], E[k], W[k], Nn[k], Ss[k]);
+            if (!FULL && i >= i_end) Q = 0;
+            const unsigned long long mk = __ballot(Q != 0);
+            if (mk) {
+                if (Q) q0[n0 + lane_rank(mk)] = Q | (uint32_t)i;
+                n0 += __popcll(mk);
             }
         }
-        __syncthreads();
-        // A2: opposite-pair test, dense over the compass survivors.  n1 / n2 are block-uniform after the barriers, so
-        // rounds without candidates (flat image regions) skip the remaining phases and their barriers altogether.
-        qfill += hdr->n1[rnd];
-        const bool last_round = base + FAST_ROUND >= npx_scan;
-        if (qfill <= FAST_QCAP - FAST_ROUND && !last_round) continue;   // keep filling q1 (block-uniform decision)
-        const int n1 = (b.dbg & 1) ? 0 : qfill;
-        qfill = 0;
-        if (n1 > 0) {
-            for (int i0 = 0; i0 < n1; i0 += FAST_THREADS) {
-                const int i = i0 + tid;
-                int pass = 0, p = 0;
-                if (i < n1) {
-                    p = q1[i];
-                    int y, x;
-                    split_px(p, cw, inv_cw, y, x);
-                    const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
-                    pass = fast_pair_test(c, S, c[0], tmin);
-                }
-                queue_push(q2cur, &hdr->n2[batch], pass, p, lane, lt);
-            }
-            __syncthreads();
-            // B: exact FAST score, dense over the pair-test survivors
-            const int n2 = (b.dbg & 2) ? 0 : hdr->n2[batch];
-            if (n2 > 0) {
-                for (int i = tid; i < n2; i += FAST_THREADS) {
-                    const int p = q2cur[i];
-                    int y, x;
-                    split_px(p, cw, inv_cw, y, x);
-                    const uint8_t* c = img0 + __umul24((unsigned)y, (unsigned)S) + x;
-                    s_sc[p] = (uint8_t)fast_score_raw(c, S, c[0], tmin);
-                }
-                __syncthreads();
+        while (n0 >= 64) { n0 -= 64; expand_step(q0 + n0, 64); }
+    };
+    {
+        int base = i_begin;
+        for (; base + RG <= i_end; base += RG) round(std::true_type{}, base);
+        if (base < i_end) round(std::false_type{}, base);
+    }
+    // drain this wave's queues
+    if (n0) expand_step(q0, n0);
+    if (n1) pair_step(q1, n1);
+    if (n2) score_step(q2, n2);
+    if (n3 > Q3CAP && lane == 0) hdr->overflow = 1;
+    __syncthreads();
+
+    // N: 3x3 strict NMS of the scored pixels of the band's own rows.  Scores of the halo columns / rows and of every non-corner
+    // are 0, which is what cv::FAST's NMS sees outside the cell view.
+    auto nms_px = [&](int p, int s) {
+        const uint8_t* sp = s_sc + p;
+        const int mx = imax3(imax3(sp[-1], sp[1], sp[-S]), imax3(sp[S], sp[-S - 1], sp[-S + 1]), imax(sp[S - 1], sp[S + 1]));
+        if (s > mx) {
+            const int bit = p - q_own_lo;
+            atomicOr(&cmask[bit >> 6], 1ull << (bit & 63));
+            if (s >= g.fast_th) atomicAdd(&hdr->n_hi, 1);
+            if (s >= 7) atomicAdd(&hdr->n_lo, 1);
+        }
+    };
+    if (!hdr->overflow) {
+        for (int i = lane; i < n3; i += 64) {
+            const int p = q3[i];
+            if (p >= q_own_lo && p < q_own_hi) nms_px(p, s_sc[p]);
+        }
+    } else {
+        const int d_lo = q_own_lo >> 2, d_hi = q_own_hi >> 2;
+        for (int i = d_lo + tid; i < d_hi; i += NT) {
+            uint32_t sc4 = reinterpret_cast<const uint32_t*>(s_sc)[i];
+            while (sc4) {
+                const int j = (__ffs((int)sc4) - 1) >> 3;
+                const int s = (int)((sc4 >> (8 * j)) & 255u);
+                sc4 &= ~(255u << (8 * j));
+                nms_px(4 * i + j, s);
             }
         }
-        // N: every neighbour of the previous batch's pixels is scored now
-        if (batch > 0) nms_round(q2 + ((batch - 1) & 1) * FAST_QCAP, hdr->n2[batch - 1]);
-        batch++;
     }
-    if (b.dbg & 16) return;
-    if (batch > 0) nms_round(q2 + ((batch - 1) & 1) * FAST_QCAP, hdr->n2[batch - 1]);
     __syncthreads();
-    // The cell's keypoint list in raster order (cv::FAST's order): one LANE per 64-pixel chunk of the survivor bitmask.
-    // Block-wide exclusive scan of the chunk popcounts (wave scan + per-wave totals), then every lane walks the few set bits
-    // of its own chunk.  (A wave-per-chunk loop spent most of its time on empty chunks: 18 dependent LDS reads per wave.)
-    int* wsum = coffs;                                  // reuse: FAST_THREADS / 64 wave totals
-    unsigned long long m = 0ull;
-    if (tid < nchunks) m = cmask[tid];
-    int cnt = __popcll(m), incl = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int run = incl - cnt, total = 0;
-#pragma unroll
-    for (int wv = 0; wv < FAST_THREADS / 64; wv++) { const int t = wsum[wv]; if (wv < wave) run += t; total += t; }
+    // the band's keypoint list in raster order (cv::FAST's order): one lane per 64-byte chunk of the survivor bitmask
     Cand* out = b.cand + (long long)frame * g.frame_cands + L.cand_base + bg.cand_off;
-    while (m) {
-        const int bit = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int p = tid * 64 + bit;
-        int y, x;
-        split_px(p, cw, inv_cw, y, x);
-        Cand e;
-        e.pos = (uint32_t)(cg.x0 + x) | ((uint32_t)(cg.y0 + y) << 16);
-        e.resp = (float)s_sc[p];
-        out[run++] = e;
+    const float inv_S = 1.0f / (float)S;
+    int run_base = 0;
+    for (int c0 = 0; c0 < nchunks; c0 += NT) {
+        unsigned long long m = 0ull;
+        if (c0 + tid < nchunks) m = cmask[c0 + tid];
+        const int cnt = __popcll(m);
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (NW > 1) {
+            if (lane == 63) hdr->wsum[wave] = incl;
+            __syncthreads();
+        }
+        int run = run_base + incl - cnt, total = NW > 1 ? 0 : __shfl(incl, 63, 64);
+        if (NW > 1) {
+#pragma unroll
+            for (int wv = 0; wv < NW; wv++) { const int t = hdr->wsum[wv]; if (wv < wave) run += t; total += t; }
+        }
+        while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int p = q_own_lo + (c0 + tid) * 64 + bit;
+            int r, xr;
+            split_px(p, S, inv_S, r, xr);
+            Cand e;
+            e.pos = (uint32_t)(bg.x0 + xr - x_first) | ((uint32_t)(bg.ey0 + r - 3) << 16);
+            e.resp = (float)s_sc[p];
+            out[run++] = e;
+        }
+        run_base += total;
+        if (NW > 1 && c0 + NT < nchunks) __syncthreads();
     }
     if (tid == 0) {
         CellState st;
-        st.n_all = total; st.n_hi = hdr->n_hi; st.n_lo = hdr->n_lo;
+        st.n_all = run_base; st.n_hi = hdr->n_hi; st.n_lo = hdr->n_lo;
         *cst = st;
     }
 }
 
-// One workgroup per (frame, cell).  (A persistent variant — 4 workgroups per CU walking the cells with a static stride —
-// measured 35 % slower: the hardware dispatcher balances the very uneven cell sizes better than a static schedule.)
-template <bool ALIGNED, int FAST_THREADS, int FAST_PPT, int FAST_SLACK>
-__global__ __launch_bounds__(FAST_THREADS) void k_fast_cells(Batch b) {
+template <bool ALIGNED, int NT, int PPT>
+__global__ __launch_bounds__(NT) void k_fast_cells(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    fast_cell_task<ALIGNED, FAST_THREADS, FAST_PPT, FAST_SLACK>(b, blockIdx.x, smem);
+    fast_cell_task<ALIGNED, NT, PPT>(b, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------ quotas
@@ -1042,16 +1080,16 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         StageScope sc(timer, stream, ST_FAST_CELLS);
         const bool aligned = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
         const size_t lds = (size_t)g.fast_lds_bytes;
-        auto launch = [&](auto kern, int threads) {
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        auto launch = [&](auto kern, int threads) -> bool {
+            if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
             hipLaunchKernelGGL(kern, dim3(F * g.nbands_total), dim3(threads), lds, stream, b);
+            return true;
         };
         constexpr FastShape A = FAST_SMALL, B = FAST_LARGE;
-        if (g.fast_threads == A.threads) {
-            if (aligned) launch(k_fast_cells<true, A.threads, A.ppt, A.slack>, A.threads); else launch(k_fast_cells<false, A.threads, A.ppt, A.slack>, A.threads);
-        } else {
-            if (aligned) launch(k_fast_cells<true, B.threads, B.ppt, B.slack>, B.threads); else launch(k_fast_cells<false, B.threads, B.ppt, B.slack>, B.threads);
-        }
+        bool ok;
+        if (g.fast_small) ok = aligned ? launch(k_fast_cells<true, A.threads, A.ppt>, A.threads) : launch(k_fast_cells<false, A.threads, A.ppt>, A.threads);
+        else ok = aligned ? launch(k_fast_cells<true, B.threads, B.ppt>, B.threads) : launch(k_fast_cells<false, B.threads, B.ppt>, B.threads);
+        if (!ok) return ORBX_ERR_DEVICE;
         ORBX_LAUNCH_CHECK();
     }
     if (stop_after == ST_FAST_CELLS) return ORBX_OK;
