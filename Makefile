@@ -4,7 +4,8 @@ HIPCC      ?= /opt/rocm/bin/hipcc
 CXX        ?= g++
 CC         ?= gcc
 ARCH       ?= gfx950
-HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude -Iorb_slam_amd/csrc
+# -amdgpu-mfma-vgpr-form: the matcher's MFMA results feed VALU min / compare trees, so they should land in VGPRs (no v_accvgpr_read per value)
+HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -Wall -Wno-unused-function -Iinclude -Iorb_slam_amd/csrc
 ORBX_SRCS  := $(wildcard orb_slam_amd/csrc/*.hip)
 ORBX_HDRS  := $(wildcard orb_slam_amd/csrc/*.h orb_slam_amd/csrc/*.inc include/*.h)
 

@@ -111,7 +111,11 @@ int orbm_hamming256(const uint8_t* a, const uint8_t* b);
 /* For each of nq query descriptors (32 B each) scan all nt train descriptors:
  *   best[q], second[q] = the two smallest distances WITH multiplicity; best_idx[q] = FIRST index
  *   attaining best (strict '<' update order of the reference loops); nt==0 -> -1, INT_MAX, INT_MAX.
- * Host-pointer form (copies in/out, synchronous) and device-pointer form (async on `stream`). */
+ * Host-pointer form (copies in/out, synchronous) and device-pointer form (async on `stream`: its scratch — the partial
+ * results of the train splits — is allocated and freed in stream order (hipMallocAsync), so concurrent calls on different
+ * streams, also from one host thread, never share a buffer).  nt < 2^22.
+ * The kernels compute the distances on the matrix cores (int8 MFMA on +-1 encoded bits, exact); ORBX_MATCH_MFMA=0 in the
+ * environment selects the xor + popcount kernels instead (same results). */
 int orbm_match_top2(const uint8_t* Q, int nq, const uint8_t* T, int nt,
                     int32_t* best_idx, int32_t* best, int32_t* second, int device);
 int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
@@ -124,8 +128,9 @@ int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const u
 /* Candidate-set form — the shape every ORBmatcher search actually scans (GetFeaturesInArea windows,
  * src/Frame.cc:200-265; the features of one vocabulary node, src/ORBmatcher.cc:171-260): query q scans the train
  * descriptors with indices cand[seg_off[q] .. seg_off[q+1]) in LIST order; best_idx = the first listed candidate
- * attaining the best distance (a train index), -1 / INT_MAX / INT_MAX for an empty list.  seg_off has nq+1 entries;
- * candidate indices outside [0, nt) are skipped. */
+ * attaining the best distance (a train index), -1 / INT_MAX / INT_MAX for an empty list.  seg_off has nq+1 entries,
+ * non-decreasing, every segment shorter than 2^22 candidates (the key keeps the list position in 22 bits); candidate
+ * indices outside [0, nt) are skipped. */
 int orbm_match_top2_segments(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int32_t* seg_off, const int32_t* cand,
                              int32_t* best_idx, int32_t* best, int32_t* second, int device);
 int orbm_match_top2_segments_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt, const int32_t* d_seg_off,

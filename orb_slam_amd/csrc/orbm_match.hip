@@ -14,6 +14,7 @@
 // plain two-smallest reduction, the train set can be split across workgroups and merged in any order.
 #include <climits>
 #include <cstring>
+#include <type_traits>
 
 #include "orb_math.h"
 #include "orbx_internal.h"
@@ -159,6 +160,242 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match_batch(const uint32_t* __r
     }
 }
 
+// ------------------------------------------------------------------------------------ Hamming by MFMA
+// Encode bit b of a descriptor as an int8 (b ? +v : -v): for two descriptors the dot product is v_q * v_t * (#agreeing - #differing
+// bits) = v_q v_t (256 - 2 hamming), exact in the i32 accumulator.  v_mfma_i32_32x32x32_i8 does a 32 x 32 block of pairs per 8
+// instructions (K = 256): ~3.5 pairs per cycle and SIMD against ~0.2 for the xor + popcount form, and the matrix pipe runs beside
+// the VALU, which is left with the top-2 bookkeeping (v_med3 + v_min per pair).
+//   A (32 trains x 32 k): lane l supplies row l % 32, k-bytes 16 * (l / 32) .. + 15 of the chunk;  B (32 k x 32 queries): likewise
+//   with the query as column;  D: lane l holds column (query) l % 32, register r row (train) 8 * (r / 4) + 4 * (l / 32) + r % 4
+//   (tools/microbench/mfma_layout.hip checks this on the device).  Both operands use the same bit -> k map, so its order is free.
+// Workgroup = 4 waves; wave w keeps QT tiles of 32 queries as B operands (+-1) in registers for the whole scan.  Train tiles of
+// 32 descriptors are expanded cooperatively into LDS (-+64, i.e. negated and scaled) through a 256-entry byte -> 8 bytes table
+// and kept in a ring of four; rows are padded to 272 bytes so that the 16-byte operand reads of 16 consecutive lanes cover all
+// 64 banks.  Measured (100k x 100k): 2.27 ms = 4.4e12 pairs/s against 5.25 ms for the popcount kernels; 1024 x (1000 x 1000):
+// 0.265 against 0.57 ms.  What did not work: a min3 tree per tile with the key updates only behind a wave vote (the vote fires
+// for ~half the tiles at these chunk lengths and its branches keep the scheduler from pairing VALU with MFMAs: 3.2 ms).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+constexpr int MF_PITCH = 272;                      // bytes per expanded train row in LDS (256 + 16)
+constexpr int MF_TILE_BYTES = 32 * MF_PITCH;
+constexpr int MF_LDS_BYTES = 4096 + 4 * MF_TILE_BYTES;   // two tables + ring of four train tiles
+
+// Per-query-tile scan state as four named scalars per field: an array here is promoted to a vector register tuple, and every
+// conditional update then shuffles the whole tuple (v_mov_b64 x 4 per key).
+struct Top2State {
+    uint32_t a0, a1, a2, a3;
+    template <int I> __device__ __forceinline__ uint32_t& at() {
+        if constexpr (I == 0) return a0; else if constexpr (I == 1) return a1; else if constexpr (I == 2) return a2; else return a3;
+    }
+};
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+
+template <int QT>
+__device__ __forceinline__ void mfma_scan(const uint32_t* __restrict__ Qp, int nq, int qblock0, const uint32_t* __restrict__ Tp, int t0, int t1,
+                                          uint8_t* smem, Top2State& K1, Top2State& K2) {
+    static_assert(QT >= 1 && QT <= 4, "Top2State holds four tiles");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, kh = lane >> 5;
+    uint2* lut = reinterpret_cast<uint2*>(smem);                // lut[v]: byte j of the pair = bit j of v as +1 (0x01) / -1 (0xFF)   (queries)
+    uint2* lut64 = lut + 256;                                   // lut64[v]: ... as +64 (0x40) / -64 (0xC0)                           (trains, looked up with ~v)
+    uint8_t* tiles = smem + 4096;
+    {
+        const uint32_t v = (uint32_t)tid;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int bq = 0; bq < 4; bq++) {
+            lo |= (((v >> bq) & 1u) ? 0x01u : 0xFFu) << (8 * bq);
+            hi |= (((v >> (4 + bq)) & 1u) ? 0x01u : 0xFFu) << (8 * bq);
+        }
+        lut[tid] = make_uint2(lo, hi);
+        lut64[tid] = make_uint2((lo & 0x01010101u) << 6 | (lo & 0x80808080u), (hi & 0x01010101u) << 6 | (hi & 0x80808080u));   // 0x01 -> 0x40, 0xFF -> 0xC0
+    }
+    __syncthreads();
+    // B operands: QT x 8 chunks x 16 bytes per lane
+    i32x4_t breg[QT][8];
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) {
+        const int q = qblock0 + (wave * QT + qt) * 32 + n;
+        const bool qv = q < nq;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const uint32_t w = qv ? Qp[(long long)q * 8 + c] : 0u;
+            const uint32_t h16 = (w >> (16 * kh)) & 0xFFFFu;
+            const uint2 e0 = lut[h16 & 255u], e1 = lut[h16 >> 8];
+            breg[qt][c] = (i32x4_t){(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
+        }
+    }
+    K1.a0 = K1.a1 = K1.a2 = K1.a3 = KEY_NONE;
+    K2.a0 = K2.a1 = K2.a2 = K2.a3 = KEY_NONE;
+    const int ntiles = (t1 - t0 + 31) >> 5;
+    if (ntiles <= 0) return;
+    // expansion of one train dword per thread and tile: row m = tid / 8, dword wd = tid % 8 -> 32 bytes of -(+-1) (the lookup of ~byte)
+    const int m_st = tid >> 3, wd_st = tid & 7;
+    auto load_raw = [&](int tile_i) -> uint32_t {
+        const int t = t0 + tile_i * 32 + m_st;
+        return t < t1 ? Tp[(long long)t * 8 + wd_st] : 0u;
+    };
+    auto expand = [&](uint32_t raw, int buf) {
+        const uint32_t x = ~raw;
+        const uint2 a = lut64[x & 255u], bb = lut64[(x >> 8) & 255u], c = lut64[(x >> 16) & 255u], d = lut64[x >> 24];
+        uint4* dst = reinterpret_cast<uint4*>(tiles + buf * MF_TILE_BYTES + m_st * MF_PITCH + 32 * wd_st);
+        dst[0] = make_uint4(a.x, a.y, bb.x, bb.y);
+        dst[1] = make_uint4(c.x, c.y, d.x, d.y);
+    };
+    // The MFMA itself builds tile-local keys: with the train bytes scaled to +-64 the product is 64 * (2 * hamming - 256), and the
+    // accumulator of register r starts at 16384 + row(r, lane), so it ends as hamming * 128 + row — a 16-bit key whose order within
+    // the tile is the reference's (distance, then first index).  The VALU is left with med3 + min per pair; the tile's two smallest
+    // keys are widened to (hamming << 22) | index and merged into the running pair once per tile.
+    i32x16_t cinit;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cinit[r] = 16384 + 8 * (r / 4) + (r % 4) + 4 * kh;
+    auto load_a = [&](const uint8_t* p) -> i32x4_t {
+        const uint4 av = *reinterpret_cast<const uint4*>(p);
+        return (i32x4_t){(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+    };
+    // 8 * QT MFMAs of one train tile against the wave's query tiles (prologue form, nothing to overlap with)
+    auto mfma_tile = [&](i32x16_t (&acc)[QT], int buf) {
+        const uint8_t* tile = tiles + buf * MF_TILE_BYTES + n * MF_PITCH + 16 * kh;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const i32x4_t a = load_a(tile + 32 * c);
+#pragma unroll
+            for (int qt = 0; qt < QT; qt++) acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, breg[qt][c], c == 0 ? cinit : acc[qt], 0, 0, 0);
+        }
+    };
+    // tile-local pair (k1 <= k2, 16-bit keys) of the tile at tbase -> global keys, merged into the running pair
+    auto merge_tile = [&](uint32_t& G1, uint32_t& G2, uint32_t k1, uint32_t k2, uint32_t tbase) {
+        const uint32_t g1 = ((k1 >> 7) << KEY_SHIFT) + (k1 & 127u) + tbase;
+        const uint32_t g2 = k2 == KEY_NONE ? KEY_NONE : ((k2 >> 7) << KEY_SHIFT) + (k2 & 127u) + tbase;
+        const uint32_t hi = max(G1, g1);
+        G1 = min(G1, g1);
+        G2 = min(hi, min(G2, g2));
+    };
+    // ... of the last tile of the range: rows beyond t1 are zero padding, their keys must not compete
+    auto top2_last = [&](const i32x16_t (&acc)[QT], int it) {
+        const int tbase = t0 + it * 32;
+        static_for<QT>([&](auto qc) {
+            constexpr int qt = decltype(qc)::value;
+            uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (tbase + 8 * (r / 4) + (r % 4) + 4 * kh < t1) top2_update(k1, k2, (uint32_t)acc[qt][r]);
+            if (k1 != KEY_NONE) merge_tile(K1.at<qt>(), K2.at<qt>(), k1, k2, (uint32_t)tbase);
+        });
+    };
+    // Software pipeline over a ring of four LDS tiles.  In iteration `it` the wave ISSUES the MFMAs of tile it + 1 (A operands
+    // already in registers) and, while the matrix pipe works on them, runs the VALU top-2 of tile it: a wave issues in order, so
+    // VALU placed behind the MFMA block would wait for the pipe — every MFMA is followed by the top-2 steps of two accumulator
+    // registers of the PREVIOUS tile (4 VALU ops in the MFMA's ~36-cycle shadow; tools/microbench/mfma_valu_mix: up to 6 hide
+    // completely), pinned with sched_barrier.  Once a chunk's MFMAs are issued its A register is refilled from tile it + 2, a whole
+    // iteration ahead of its use; tile it + 3 is expanded and tile it + 4 loaded.  No branches: everything beyond the range is
+    // predicated or lands in ring slots nobody consumes.
+    expand(load_raw(0), 0);
+    expand(load_raw(1), 1);
+    expand(load_raw(2), 2);
+    uint32_t raw_next = load_raw(3);
+    __syncthreads();
+    i32x16_t accA[QT], accB[QT];
+    mfma_tile(accA, 0);
+    i32x4_t areg[8];
+    const uint8_t* lane_tile = tiles + n * MF_PITCH + 16 * kh;
+#pragma unroll
+    for (int c = 0; c < 8; c++) areg[c] = load_a(lane_tile + 1 * MF_TILE_BYTES + 32 * c);
+    auto body = [&](i32x16_t (&cur)[QT], i32x16_t (&nxt)[QT], int it) {      // requires it + 1 < ntiles; tile `it` is complete (not the padded one)
+        const uint8_t* next_tile = lane_tile + ((it + 2) & 3) * MF_TILE_BYTES;
+        uint32_t k1[QT], k2[QT];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            static_for<QT>([&](auto qc) {
+                constexpr int qt = decltype(qc)::value;
+                nxt[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[c], breg[qt][c], c == 0 ? cinit : nxt[qt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c == 0) {
+                    k1[qt] = min((uint32_t)cur[qt][0], (uint32_t)cur[qt][1]);
+                    k2[qt] = max((uint32_t)cur[qt][0], (uint32_t)cur[qt][1]);
+                } else {
+                    top2_update(k1[qt], k2[qt], (uint32_t)cur[qt][2 * c]);
+                    top2_update(k1[qt], k2[qt], (uint32_t)cur[qt][2 * c + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            areg[c] = load_a(next_tile + 32 * c);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        static_for<QT>([&](auto qc) {
+            constexpr int qt = decltype(qc)::value;
+            merge_tile(K1.at<qt>(), K2.at<qt>(), k1[qt], k2[qt], (uint32_t)(t0 + it * 32));
+        });
+        expand(raw_next, (it + 3) & 3);
+        raw_next = load_raw(it + 4);
+        __syncthreads();
+    };
+    int it = 0;
+    for (; it + 2 < ntiles; it += 2) { body(accA, accB, it); body(accB, accA, it + 1); }
+    if (it + 1 < ntiles) { body(accA, accB, it); top2_last(accB, it + 1); }
+    else top2_last(accA, it);
+    // lanes l and l + 32 hold the two row halves of the same query
+    static_for<QT>([&](auto qc) {
+        constexpr int qt = decltype(qc)::value;
+        uint32_t& k1 = K1.at<qt>();
+        uint32_t& k2 = K2.at<qt>();
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)k1, 32, 64), o2 = (uint32_t)__shfl_xor((int)k2, 32, 64);
+        const uint32_t lo = min(k1, o1), hi = max(k1, o1);
+        k2 = min(hi, min(k2, o2));
+        k1 = lo;
+    });
+}
+
+// Many small problems (frame-to-frame matching): blockIdx.y = problem, sizes read on the device.
+template <int QT>
+__global__ __launch_bounds__(256) void k_match_batch_mfma(const uint32_t* __restrict__ Q, const int32_t* __restrict__ nqs, const uint32_t* __restrict__ T,
+                                                          const int32_t* __restrict__ nts, int cap, int32_t* __restrict__ idx, int32_t* __restrict__ best,
+                                                          int32_t* __restrict__ second) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int prob = blockIdx.y;
+    const int nq = min(nqs[prob], cap), nt = min(nts[prob], cap);
+    const int qblock0 = blockIdx.x * (128 * QT);
+    if (qblock0 >= nq) return;
+    Top2State K1, K2;
+    mfma_scan<QT>(Q + (long long)prob * cap * 8, nq, qblock0, T + (long long)prob * cap * 8, 0, nt, smem, K1, K2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 32) {
+        static_for<QT>([&](auto qc) {
+            constexpr int qt = decltype(qc)::value;
+            const int q = qblock0 + (wave * QT + qt) * 32 + lane;
+            if (q < nq) {
+                const long long o = (long long)prob * cap + q;
+                write_result(K1.at<qt>(), K2.at<qt>(), idx + o, best + o, second + o);
+            }
+        });
+    }
+}
+
+// Large single problem: grid = (query blocks, train splits); partial (k1, k2) per (split, query) for k_match_merge.
+template <int QT>
+__global__ __launch_bounds__(256) void k_match_split_mfma(const uint32_t* __restrict__ Q, int nq, const uint32_t* __restrict__ T, int nt, int chunk,
+                                                          uint32_t* __restrict__ pk1, uint32_t* __restrict__ pk2) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int qblock0 = blockIdx.x * (128 * QT);
+    const int t0 = blockIdx.y * chunk, t1 = min(nt, t0 + chunk);
+    Top2State K1, K2;
+    mfma_scan<QT>(Q, nq, qblock0, T, t0, t1, smem, K1, K2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 32) {
+        static_for<QT>([&](auto qc) {
+            constexpr int qt = decltype(qc)::value;
+            const int q = qblock0 + (wave * QT + qt) * 32 + lane;
+            if (q < nq) {
+                pk1[(long long)blockIdx.y * nq + q] = K1.at<qt>();
+                pk2[(long long)blockIdx.y * nq + q] = K2.at<qt>();
+            }
+        });
+    }
+}
+
 // Candidate-set form (what every ORBmatcher search really scans: the grid window of GetFeaturesInArea or the features of
 // one vocabulary node): query q scans the train descriptors cand[seg_off[q] .. seg_off[q+1]) IN LIST ORDER.  One wave per
 // query, one candidate per lane and step; key = (distance << 22) | position-in-list keeps the reference's "first candidate
@@ -210,26 +447,6 @@ __global__ __launch_bounds__(256) void k_match_segments(const uint32_t* __restri
         second[q] = sd;
     }
 }
-
-struct MatchScratch {
-    uint32_t* buf = nullptr;
-    size_t bytes = 0;
-    int device = -1;
-};
-static thread_local MatchScratch t_scratch;
-
-static int ensure_scratch(size_t bytes) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return ORBX_ERR_DEVICE;
-    if (t_scratch.buf && t_scratch.bytes >= bytes && t_scratch.device == dev) return ORBX_OK;
-    if (t_scratch.buf) (void)hipFree(t_scratch.buf);
-    t_scratch.buf = nullptr;
-    if (hipMalloc(&t_scratch.buf, bytes) != hipSuccess) return ORBX_ERR_DEVICE;
-    t_scratch.bytes = bytes;
-    t_scratch.device = dev;
-    return ORBX_OK;
-}
-
 
 // MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:216-244), one wave per map point.  Lane i owns row i of
 // the N x N distance matrix: it never stores the row — the median (element (int)(0.5*(N-1)) of the sorted row) is found by
@@ -289,28 +506,45 @@ int orbm_count_accepted(const int32_t* best, const int32_t* second, int nq, int 
     return n;
 }
 
+// ORBX_MATCH_MFMA=0 selects the xor + popcount kernels (the A/B baseline of the MFMA form); read once per process.
+static bool use_mfma() {
+    static const bool v = [] { const char* e = getenv("ORBX_MATCH_MFMA"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt, int32_t* d_best_idx, int32_t* d_best,
                            int32_t* d_second, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (nq < 0 || nt < 0 || nt >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
     if (nq == 0) return ORBX_OK;
     if (((uintptr_t)dQ & 15) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
-    constexpr int QPL = 2, Q_PER_BLOCK = MATCH_BLOCK * QPL;   // big problems: 2 queries per lane halve the scalar T traffic
-    const int qblocks = (nq + Q_PER_BLOCK - 1) / Q_PER_BLOCK;
+    const bool mfma = use_mfma();
+    constexpr int QPL = 2, QT = 2;                            // popcount form: 2 queries per lane; MFMA form: 2 query tiles per wave
+    const int q_per_block = mfma ? 128 * QT : MATCH_BLOCK * QPL;
+    const int qblocks = (nq + q_per_block - 1) / q_per_block;
     // enough workgroups to fill 256 CUs several times over, but chunks of >= 256 train descriptors
-    int nsplit = std::max(1, std::min((nt + 255) / 256, (4096 + qblocks - 1) / qblocks));
-    const int chunk = nt > 0 ? (nt + nsplit - 1) / nsplit : 1;
+    const int target_wgs = mfma ? 2048 : 4096;
+    int nsplit = std::max(1, std::min((nt + 255) / 256, (target_wgs + qblocks - 1) / qblocks));
+    int chunk = nt > 0 ? (nt + nsplit - 1) / nsplit : 1;
+    if (mfma) chunk = (chunk + 31) / 32 * 32;                // whole train tiles
     nsplit = nt > 0 ? (nt + chunk - 1) / chunk : 1;
+    // Partial (k1, k2) per (split, query): stream-ordered allocation, so calls on different streams never share a buffer and the
+    // call stays asynchronous (the free is queued behind the merge kernel).
     const size_t need = (size_t)2 * nsplit * nq * sizeof(uint32_t);
-    if (ensure_scratch(need) != ORBX_OK) return ORBX_ERR_DEVICE;
-    uint32_t* pk1 = t_scratch.buf;
+    uint32_t* pk1 = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void**>(&pk1), need, stream) != hipSuccess) return ORBX_ERR_DEVICE;
     uint32_t* pk2 = pk1 + (size_t)nsplit * nq;
-    hipLaunchKernelGGL(k_match_split<QPL>, dim3(qblocks, nsplit), dim3(MATCH_BLOCK), 0, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt,
-                       chunk, pk1, pk2);
-    if (hipGetLastError() != hipSuccess) return ORBX_ERR_DEVICE;
-    hipLaunchKernelGGL(k_match_merge, dim3((nq + 255) / 256), dim3(256), 0, stream, pk1, pk2, nq, nsplit, d_best_idx, d_best, d_second);
-    if (hipGetLastError() != hipSuccess) return ORBX_ERR_DEVICE;
-    return ORBX_OK;
+    if (mfma) hipLaunchKernelGGL(k_match_split_mfma<QT>, dim3(qblocks, nsplit), dim3(256), MF_LDS_BYTES, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt,
+                                 chunk, pk1, pk2);
+    else hipLaunchKernelGGL(k_match_split<QPL>, dim3(qblocks, nsplit), dim3(MATCH_BLOCK), 0, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt,
+                            chunk, pk1, pk2);
+    int rc = hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+    if (rc == ORBX_OK) {
+        hipLaunchKernelGGL(k_match_merge, dim3((nq + 255) / 256), dim3(256), 0, stream, pk1, pk2, nq, nsplit, d_best_idx, d_best, d_second);
+        if (hipGetLastError() != hipSuccess) rc = ORBX_ERR_DEVICE;
+    }
+    if (hipFreeAsync(pk1, stream) != hipSuccess) rc = ORBX_ERR_DEVICE;
+    return rc;
 }
 
 int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const uint8_t* dT, const int32_t* d_nt, int nbatch, int cap,
@@ -319,7 +553,13 @@ int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const u
     if (nbatch < 0 || cap < 1 || cap >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
     if (nbatch == 0) return ORBX_OK;
     if (((uintptr_t)dQ & 15) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
-    // frame-sized problems (~1000 x 1000): 1 query per lane so that a batch of 256 still fills the chip (4 waves per SIMD)
+    if (use_mfma()) {
+        constexpr int QT = 2;                                    // 256 queries per workgroup: four workgroups per ~1000-feature frame
+        hipLaunchKernelGGL(k_match_batch_mfma<QT>, dim3((cap + 128 * QT - 1) / (128 * QT), nbatch), dim3(256), MF_LDS_BYTES, stream, (const uint32_t*)dQ, d_nq,
+                           (const uint32_t*)dT, d_nt, cap, d_best_idx, d_best, d_second);
+        return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+    }
+    // popcount form, frame-sized problems (~1000 x 1000): 1 query per lane so that a batch of 256 still fills the chip (4 waves per SIMD)
 #ifndef ORBX_MATCH_QPL
 #define ORBX_MATCH_QPL 1
 #endif
@@ -345,9 +585,9 @@ int orbm_match_top2_segments(const uint8_t* Q, int nq, const uint8_t* T, int nt,
     if (nq < 0 || nt < 0 || !seg_off || (nq > 0 && seg_off[nq] > 0 && !cand)) return ORBX_ERR_ARG;
     if (nq == 0) return ORBX_OK;
     const int ncand = seg_off[nq];
-    if (ncand < 0 || ncand >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
-    for (int q = 0; q < nq; q++)
-        if (seg_off[q] > seg_off[q + 1] || seg_off[q] < 0) return ORBX_ERR_ARG;
+    if (ncand < 0) return ORBX_ERR_ARG;
+    for (int q = 0; q < nq; q++)      // monotone offsets; the key keeps the position inside ONE segment in 22 bits
+        if (seg_off[q] > seg_off[q + 1] || seg_off[q] < 0 || seg_off[q + 1] - seg_off[q] >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
     if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
     uint8_t *dQ = nullptr, *dT = nullptr;
     int32_t *dseg = nullptr, *dcand = nullptr, *dout = nullptr;
