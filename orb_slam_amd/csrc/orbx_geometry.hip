@@ -86,7 +86,7 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
 
     // --- per-level geometry
     const float imageRatio = (float)w / h;   // level 0 cols/rows (:526)
-    int plane_off = 0, cell_base = 0, cand_base = 0, sel_base = 0, slot_base = 0;
+    int plane_off = 0, cell_base = 0, cand_base = 0, sel_base = 0, slot_base = 0, quad_base = 0;
     int btile_base = 0;
     for (int l = 0; l < nl; l++) {
         LevelGeom& L = g.lv[l];
@@ -190,6 +190,8 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
         sel_base += L.sel_cap;
         L.slot_base = slot_base;
         slot_base += L.ndesired;
+        L.quad_base = quad_base;
+        quad_base += (L.ndesired + 3) / 4;
 
         // blur work items
         L.btiles_x = (L.w + 247) / 248;        // blur: 248-px column strips x 32-row bands, one wave each
@@ -281,13 +283,14 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
     for (int l = 0; l < MAX_LEVELS; l++) {
         const bool live = l < nl;
         g.cell_bases[l] = live ? g.lv[l].cell_base : INT_MAX;
-        g.slot_bases[l] = live ? g.lv[l].slot_base : INT_MAX;
+        g.quad_bases[l] = live ? g.lv[l].quad_base : INT_MAX;
         g.btile_bases[l] = live ? g.lv[l].btile_base : INT_MAX;
     }
     g.ncells_total = cell_base;
     g.nbands_total = (int)out.bands.size();
     g.nbtiles_total = btile_base;
     g.nslots = slot_base;
+    g.nquads = quad_base;
     g.frame_plane_bytes = align_up(plane_off, 256);
     g.frame_cands = cand_base;
     g.frame_sel = sel_base;

@@ -36,7 +36,8 @@ struct LevelGeom {
     int cell_base;         // first cell index of this level in per-frame cell arrays
     int cand_base;         // first Cand slot of this level in one frame's candidate block
     int sel_base, sel_cap; // selected-keypoint list of this level in one frame's sel block
-    int slot_base;         // prefix of ndesired over levels (descriptor-kernel slot -> level map)
+    int slot_base;         // prefix of ndesired over levels (output slot of the level's first keypoint when every level is full)
+    int quad_base;         // prefix of ceil(ndesired / 4) over levels: k_describe forms its waves (4 keypoints each) per level
     int tabx_off, taby_off;// offsets into the ResizeX / ResizeY tables (level >= 1)
     int rz_pitch, rz_rows; // k_resize: LDS source tile of one 256x16 output tile (bytes per row, rows), maxima over the level's tiles
     int btile_base, btiles_x, btiles_y;// blur wave tasks: 248-px strips x 32-row bands of the whole plane
@@ -106,6 +107,7 @@ struct DevGeom {
     int nbands_total;        // k_fast_cells work items per frame (>= ncells_total)
     int nbtiles_total;
     int nslots;              // sum of ndesired (max keypoints per frame)
+    int nquads;              // sum of ceil(ndesired / 4): k_describe waves per frame
     int score_type, fast_th, tmin;
     int frame_plane_bytes;   // bytes of one frame's pyramid block (== blur block == nms block)
     int frame_cands;         // Cand slots per frame
@@ -117,7 +119,7 @@ struct DevGeom {
     int umax[HALF_PATCH + 1];
     // per-level bases as compact arrays: one scalar load each, so a wave finds its level in a single round trip
     // (walking lv[l].xxx_base level by level was a chain of up to nlevels dependent scalar loads, ~1.5 us per wave)
-    int cell_bases[MAX_LEVELS], slot_bases[MAX_LEVELS], btile_bases[MAX_LEVELS];
+    int cell_bases[MAX_LEVELS], quad_bases[MAX_LEVELS], btile_bases[MAX_LEVELS];
     LevelGeom lv[MAX_LEVELS];
 };
 

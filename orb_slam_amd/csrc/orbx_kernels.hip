@@ -892,16 +892,50 @@ __global__ __launch_bounds__(BLUR_WAVES * 64) void k_blur(Batch b) {
 }
 
 // ------------------------------------------------------------------------------------ orientation + rBRIEF + output
-// One wave per output keypoint.  IC_Angle: 2 patch rows per step, lanes over u; wave reduction of the
-// integer moments.  Descriptor: lane i evaluates tests i, i+64, i+128, i+192; each __ballot is 8
-// descriptor bytes (test t is bit t%8 of byte t/8, LSB first — the reference's packing).
+// Four keypoints per wave, 16 lanes each (round 2; one wave per keypoint before: every lane of a wave then repeated the same
+// fastAtan2 + double-precision sin / cos, ~28 % of the kernel's instructions, and 47 v_readfirstlane + 64-bit tap addresses).
+//   IC_Angle (reference :124-151): the 31 x 31 box is cut into 31 rows x 8 dwords (u = -15 .. 16); a lane owns dword column
+//     lane & 7 and the rows of one parity: 16 (unaligned) dword loads, the circle as byte masks from an LDS table (constant LDS
+//     offsets), two v_dot4_u32_u8 per dword (sum of (u + 15) I and sum of I), the row weight as a multiply-add; 4-step reduction.
+//   rBRIEF (:154-194): lane i of a group evaluates tests i, i + 16, ..., i + 240.  The 37 x 37 window the rotated pattern can reach
+//     (|offset| <= 18) is first copied from the blurred level into LDS with row-contiguous dword loads (10 per row): 512 scattered
+//     byte gathers per keypoint straight from global memory kept the kernel bound by the L1's cache-line rate (one wave-load
+//     touched 40-64 lines), the LDS serves them at bank speed.  The pattern comes from an LDS table of floats (one 16-byte read
+//     per test, no unpacking); the rotated coordinates are rounded with v_rndne and the tap offset iy * pitch + ix is formed in
+//     float (exact) and converted once.  A __ballot holds 16 bits (2 descriptor bytes) of each of the wave's four keypoints.
+//   Keypoints closer than 19 px to an edge may read the level's UNBLURRED reflect-101 border: their group of lanes
+//     takes its taps from global memory with the reflection in the index math.
+// Waves are formed per level (slots padded to multiples of 4), so the level is wave-uniform and its geometry scalar.
+constexpr int DESC_KPW = 4;
+constexpr int DESC_WIN_PITCH = 40, DESC_WIN_ROWS = 37, DESC_WIN_BYTES = DESC_WIN_PITCH * DESC_WIN_ROWS;   // 37 px + up to 3 px of dword alignment per row
+
 __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
+    __shared__ __attribute__((aligned(16))) float s_pat[256 * 4];     // test t: x0, y0, x1, y1
+    __shared__ uint32_t s_mask[256];                                   // circle byte masks of the 31 x 8 patch dwords (slots 248.. = 0)
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[DESC_WAVES * DESC_KPW * DESC_WIN_BYTES];   // per keypoint: 37 rows x 40 bytes of the blurred level
     const DevGeom& g = b.g;
     const int frame = blockIdx.y;
-    const int slot = blockIdx.x * DESC_WAVES + wave_id();
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = lane >> 4, li = lane & 15;
     const int32_t* counts = b.level_count + frame * MAX_LEVELS;
-    if (slot == 0 && lane == 0) {
+    for (int t = tid; t < 256; t += DESC_WAVES * 64) {
+        const uint32_t pk = c_pattern[t];
+        reinterpret_cast<float4*>(s_pat)[t] = make_float4((float)(int)(int8_t)pk, (float)(int)(int8_t)(pk >> 8), (float)(int)(int8_t)(pk >> 16), (float)(int)(int8_t)(pk >> 24));
+        // umax[] (reference :495-510) depends only on HALF_PATCH_SIZE = 15: nibble v of UMAX_NIBBLES (the host checks it against the computed table)
+        const int r = t >> 3, c = t & 7;
+        const int v = r - HALF_PATCH, av = v < 0 ? -v : v;
+        const int um = r < 31 ? (int)((UMAX_NIBBLES >> (4 * (av & 15))) & 15ull) : -1;
+        uint32_t mask = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int u = 4 * c + k - HALF_PATCH;
+            if ((u < 0 ? -u : u) <= um) mask |= 0xFFu << (8 * k);
+        }
+        s_mask[t] = mask;
+    }
+    __syncthreads();
+    const int quad = blockIdx.x * DESC_WAVES + wave_id();
+    if (quad == 0 && lane == 0) {
         int total = 0;
         for (int l = 0; l < g.nlevels; l++) total += counts[l];
         int st = b.status[frame];
@@ -909,59 +943,55 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
         b.out_n[frame] = st == ORBX_OK ? total : 0;
         if (b.out_status) b.out_status[frame] = st;
     }
-    if (slot >= g.nslots) return;
-    const int level = find_level(g.slot_bases, slot);
-    const LevelGeom& L = g.lv[level];
-    const int k = slot - L.slot_base;
-    if (k >= counts[level]) return;
-    int out_idx = k, total = 0;
-    for (int l = 0; l < g.nlevels; l++) { if (l < level) out_idx += counts[l]; total += counts[l]; }
+    if (quad >= g.nquads) return;
+    const int level = __builtin_amdgcn_readfirstlane(find_level(g.quad_bases, quad));
+    // the level's geometry as scalars (wave-uniform by construction; pinned so that nothing is re-read through per-lane addresses)
+    const LevelGeom& LG = g.lv[level];
+    struct { int w, h, stride, plane_off, sel_base, quad_base; float scale, kp_size; } L = {
+        __builtin_amdgcn_readfirstlane(LG.w), __builtin_amdgcn_readfirstlane(LG.h), __builtin_amdgcn_readfirstlane(LG.stride),
+        __builtin_amdgcn_readfirstlane(LG.plane_off), __builtin_amdgcn_readfirstlane(LG.sel_base), __builtin_amdgcn_readfirstlane(LG.quad_base),
+        __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, LG.scale))),
+        __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, LG.kp_size)))};
+    const int cnt = __builtin_amdgcn_readfirstlane(counts[level]);
+    const int k0 = (quad - L.quad_base) * DESC_KPW;
+    if (k0 >= cnt) return;
+    int out_base = 0, total = 0;
+    for (int l = 0; l < g.nlevels; l++) { if (l < level) out_base += counts[l]; total += counts[l]; }
     if (total > b.cap || b.status[frame] != ORBX_OK) return;
-
+    const bool valid = k0 + grp < cnt;
+    const int k = valid ? k0 + grp : k0;                    // idle groups shadow the wave's first keypoint (results dropped)
     const Cand kp = b.sel[(long long)frame * g.frame_sel + L.sel_base + k];
     const int x = kp.pos & 0xFFFF, y = kp.pos >> 16;
-    long long pstride64;
-    const uint8_t* plain = plain_plane(b, L, level, frame, pstride64);
-    const unsigned pstride = (unsigned)pstride64;   // rows < 2^24 bytes, planes < 2^31 bytes (host-checked): 24-bit multiplies
+    const uint8_t* plain;
+    unsigned pstride;                                        // rows < 2^24 bytes, planes < 2^31 bytes (host-checked)
+    if (level == 0) { pstride = (unsigned)b.img_row_stride; plain = b.img + (long long)frame * b.img_frame_stride; }
+    else { pstride = (unsigned)L.stride; plain = b.pyr + (long long)frame * g.frame_plane_bytes + L.plane_off; }
 
-    // the 4 BRIEF tests of this lane (independent of everything below: issue the loads now)
-    uint32_t pat[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) pat[r] = c_pattern[r * 64 + lane];
-
-    // IC_Angle on the unblurred level (:705-706 run before the blur).  umax[] (reference :495-510) depends only on
-    // HALF_PATCH_SIZE = 15, so it is a constant: nibble v of UMAX_NIBBLES (the host checks it against the computed table).
-    int m10 = 0, m01 = 0;
+    // IC_Angle on the unblurred level (:705-706 run before the blur)
+    int m10, m01;
     {
-        // The 31 x 31 box is cut into 31 rows x 8 dwords (u = -15 .. 16; the 32nd byte is masked off): 248 slots, 4 per lane.
-        // Per slot ONE (unaligned) dword load, the circle mask as a byte mask, and two v_dot4_u32_u8: sum of (u + 15) * I and
-        // sum of I — m10 = sum((u + 15) I) - 15 sum(I), m01 = sum(v * rowsum(I)).  The masks and weights depend only on the lane.
-        int a_su = 0, a_si = 0, a_v = 0;
+        const int c = li & 7, par = li >> 3;
+        uint32_t uw = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int sl = lane + 64 * i;
-            const int r = sl >> 3, c = sl & 7;                   // row 0..30 (31 = idle), dword column
-            const int v = r - HALF_PATCH, av = v < 0 ? -v : v;
-            const int um = r < 31 ? (int)((UMAX_NIBBLES >> (4 * (av & 15))) & 15ull) : -1;
-            uint32_t mask = 0, uw = 0;
+        for (int kk = 0; kk < 4; kk++) uw |= (uint32_t)(4 * c + kk) << (8 * kk);          // u + 15 of the dword's four pixels
+        const unsigned off0 = (unsigned)(x + 4 * c - HALF_PATCH) + __umul24((unsigned)(y - HALF_PATCH + par), pstride);
+        uint32_t I[16];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int u = 4 * c + k - HALF_PATCH;
-                const int au = u < 0 ? -u : u;
-                if (au <= um) mask |= 0xFFu << (8 * k);
-                uw |= (uint32_t)(4 * c + k) << (8 * k);          // u + 15
-            }
-            const int rr = r < 31 ? r : 30;                       // idle slots re-read the last row (mask = 0)
-            uint32_t I;
-            __builtin_memcpy(&I, plain + (unsigned)(x + 4 * c - HALF_PATCH) + __umul24((unsigned)(y - HALF_PATCH + rr), pstride), 4);
-            I &= mask;
-            const int si = (int)__builtin_amdgcn_udot4(I, 0x01010101u, 0u, false);
-            a_su = (int)__builtin_amdgcn_udot4(I, uw, (uint32_t)a_su, false);
+        for (int i = 0; i < 16; i++) __builtin_memcpy(&I[i], plain + (off0 + (unsigned)(2 * i) * pstride), 4);   // rows par, par + 2, ...: row 31 (par = 1, i = 15) is masked, still inside the level
+        uint32_t a_su = 0, a_si = 0, a_i = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t Im = I[i] & s_mask[li + 16 * i];
+            const uint32_t si = __builtin_amdgcn_udot4(Im, 0x01010101u, 0u, false);
+            a_su = __builtin_amdgcn_udot4(Im, uw, a_su, false);
             a_si += si;
-            a_v += v * si;
+            a_i = __umul24(si, (uint32_t)i) + a_i;             // sum of i * rowsum: the row is v = par - 15 + 2 i
         }
-        m10 = wave_sum(a_su - HALF_PATCH * a_si);
-        m01 = wave_sum(a_v);
+        int p10 = (int)a_su - HALF_PATCH * (int)a_si;
+        int p01 = (par - HALF_PATCH) * (int)a_si + 2 * (int)a_i;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { p10 += __shfl_xor(p10, off, 64); p01 += __shfl_xor(p01, off, 64); }
+        m10 = p10; m01 = p01;
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
@@ -970,33 +1000,51 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
     float sn, cs;
     sincosf_orb(angle * factorPI, &sn, &cs);
     const uint8_t* blur = b.blur + (long long)frame * g.frame_plane_bytes + L.plane_off;
-    unsigned long long words[4];
-    // rounded pattern offsets never exceed 18 px (|(-13,-13)| = 18.4): keypoints at least 19 px from every edge — all
-    // but the outermost ring of candidates — take a branch-free path; the test is wave-uniform (scalar branch)
+    // rounded pattern offsets never exceed 18 px (|(-13,-13)| = 18.4): keypoints at least 19 px from every edge — all but the
+    // outermost ring of candidates — take the branch-free path
     const bool interior = x >= 19 && y >= 19 && x < L.w - 19 && y < L.h - 19;
+    const float4* pat = reinterpret_cast<const float4*>(s_pat) + li;
+    uint32_t mybits = 0;                                        // bit j: test li + 16 j
     if (interior) {
-        const uint8_t* ctr = blur + __umul24((unsigned)y, (unsigned)L.stride) + (unsigned)x;
+        // window rows y-18 .. y+18, bytes from the aligned start at or left of x-18; the last dword of a row may be clamped to
+        // the level's last dword (its out-of-row bytes lie beyond x+18 and are never tapped)
+        uint8_t* win = s_win + (wave_id() * DESC_KPW + grp) * DESC_WIN_BYTES;
+        const int xa = (x - 18) & ~3;
+        const int dmax = ((L.w - 1) & ~3) - xa;                 // last readable dword, as a byte offset from xa
+        const uint8_t* src = blur + __umul24((unsigned)(y - 18), (unsigned)L.stride) + (unsigned)xa;
+        int row = li >= 10 ? 1 : 0, col = li >= 10 ? li - 10 : li;          // dword e = li + 16 i of the 37 x 10 window: e / 10, e % 10
+        uint32_t wv[24];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            int val[2];
+        for (int i = 0; i < 24; i++) {
+            const int rr = imin(row, DESC_WIN_ROWS - 1);
+            wv[i] = *reinterpret_cast<const uint32_t*>(src + __umul24((unsigned)rr, (unsigned)L.stride) + (unsigned)imin(4 * col, dmax));
+            col += 6; row += 1;
+            if (col >= 10) { col -= 10; row += 1; }
+        }
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const float px = (float)(int)(int8_t)(pat[r] >> (16 * e));
-                const float py = (float)(int)(int8_t)(pat[r] >> (16 * e + 8));
-                const int iy = cv_round_f(px * sn + py * cs);
-                const int ix = cv_round_f(px * cs - py * sn);
-                val[e] = ctr[__mul24(iy, L.stride) + ix];
-            }
-            words[r] = __ballot(val[0] < val[1]);
+        for (int i = 0; i < 24; i++)
+            if (li + 16 * i < DESC_WIN_ROWS * 10) reinterpret_cast<uint32_t*>(win)[li + 16 * i] = wv[i];
+        wave_lds_fence();                                       // the window is private to this wave: no workgroup barrier
+        const uint8_t* ctr = win + 18 * DESC_WIN_PITCH + (x - xa);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float4 P = pat[16 * j];
+            const float fy0 = P.x * sn + P.y * cs, fx0 = P.x * cs - P.y * sn;
+            const float fy1 = P.z * sn + P.w * cs, fx1 = P.z * cs - P.w * sn;
+            // cvRound (ties to even) of both coordinates, then iy * pitch + ix exactly in float (the fused multiply-add rounds nothing here)
+            const int o0 = (int)__builtin_fmaf(__builtin_rintf(fy0), (float)DESC_WIN_PITCH, __builtin_rintf(fx0));
+            const int o1 = (int)__builtin_fmaf(__builtin_rintf(fy1), (float)DESC_WIN_PITCH, __builtin_rintf(fx1));
+            const int v0 = ctr[o0], v1 = ctr[o1];
+            mybits |= (uint32_t)(v0 < v1) << j;
         }
     } else {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
+#pragma unroll 1
+        for (int j = 0; j < 16; j++) {
+            const float4 P = pat[16 * j];
             int val[2];
 #pragma unroll
             for (int e = 0; e < 2; e++) {
-                const float px = (float)(int)(int8_t)(pat[r] >> (16 * e));
-                const float py = (float)(int)(int8_t)(pat[r] >> (16 * e + 8));
+                const float px = e ? P.z : P.x, py = e ? P.w : P.y;
                 const int iy = cv_round_f(px * sn + py * cs);
                 const int ix = cv_round_f(px * cs - py * sn);
                 int X = x + ix, Y = y + iy;
@@ -1009,16 +1057,26 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
                 const unsigned st = inside ? (unsigned)L.stride : pstride;
                 val[e] = base[__umul24((unsigned)Y, st) + (unsigned)X];
             }
-            words[r] = __ballot(val[0] < val[1]);
+            mybits |= (uint32_t)(val[0] < val[1]) << j;
         }
     }
-    if (lane < 4) {
-        unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
-        uint8_t* d = b.out_desc + ((long long)frame * b.cap + out_idx) * 32 + lane * 8;
+    unsigned long long words[16];
 #pragma unroll
-        for (int i = 0; i < 8; i++) d[i] = (uint8_t)(w >> (8 * i));
+    for (int j = 0; j < 16; j++) words[j] = __ballot((mybits >> j) & 1u);
+    if (!valid) return;
+    const int out_idx = out_base + k;
+    {
+        // test t = li + 16 j is bit li of descriptor halfword j: halfword j of group grp = bits 16 grp .. of ballot j; lane li stores halfword li
+        uint32_t half = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t w32 = grp >= 2 ? (uint32_t)(words[j] >> 32) : (uint32_t)words[j];
+            if (li == j) half = w32;
+        }
+        half = (half >> (16 * (grp & 1))) & 0xFFFFu;
+        reinterpret_cast<uint16_t*>(b.out_desc + ((long long)frame * b.cap + out_idx) * 32)[li] = (uint16_t)half;
     }
-    if (lane == 0) {
+    if (li == 0) {
         orbx_keypoint o;
         o.x = (float)x; o.y = (float)y;
         if (level != 0) { o.x = o.x * L.scale; o.y = o.y * L.scale; }   // :769-775
@@ -1130,7 +1188,7 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     if (stop_after == ST_BLUR) return ORBX_OK;
     {
         StageScope sc(timer, stream, ST_DESCRIBE);
-        hipLaunchKernelGGL(k_describe, dim3((g.nslots + DESC_WAVES - 1) / DESC_WAVES, F), dim3(DESC_WAVES * 64), 0, stream, b);
+        hipLaunchKernelGGL(k_describe, dim3((g.nquads + DESC_WAVES - 1) / DESC_WAVES, F), dim3(DESC_WAVES * 64), 0, stream, b);
         ORBX_LAUNCH_CHECK();
     }
     return ORBX_OK;
