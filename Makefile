@@ -11,8 +11,10 @@ ORBX_HDRS  := $(wildcard orb_slam_amd/csrc/*.h orb_slam_amd/csrc/*.inc include/*
 
 all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so oracle_ref orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/cpp/example_lanes tools/microbench/valu_rate tools/microbench/valu_rate2
 
+# the hash of the kernel sources travels inside the library (orbx_build_id): counters replayed by bench.py must come from THIS build
+SRC_HASH   := $(shell cat $(sort $(ORBX_SRCS) $(ORBX_HDRS)) | sha256sum | cut -c1-16)
 orb_slam_amd/liborbx.so: $(ORBX_SRCS) $(ORBX_HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared $(ORBX_SRCS) -o $@
+	$(HIPCC) $(HIPFLAGS) -DORBX_SRC_HASH='"$(SRC_HASH)"' -shared $(ORBX_SRCS) -o $@
 
 orb_slam_amd/libsynthframes.so: orb_slam_amd/csrc/synth_frames.c
 	$(CC) -O2 -fPIC -shared $< -o $@

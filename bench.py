@@ -1,39 +1,54 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the ORB front-end hot path on MI355X.
 
-A step = one pass of the hot path over one batch of synthetic frames already resident in HBM:
-  extract (pyramid -> FAST/NMS -> selection -> blur -> orientation + rBRIEF) for `batch` 640x480 frames,
-  then brute-force Hamming top-2 matching of every frame's descriptors against the previous frame's.
-Workload = BASELINE.json `metric` ("frames/s ORB extract+match @640x480, 1000 kp"): configs[1] (single MI355X,
-640x480 stream, 8 levels, nFeatures 1000) plus the frame-to-frame match of the metric.
+A step = one pass of the hot path over one batch of synthetic input already resident in HBM.  `--config` names the workload
+(BASELINE.json `configs`):
+  vga          (default; the configuration BASELINE.json's `metric` is quoted on) 640x480 stream, 8 levels, nFeatures 1000:
+               extract (pyramid -> FAST/NMS -> selection -> blur -> orientation + rBRIEF) for `batch` frames, then brute-force
+               Hamming top-2 matching of every frame's descriptors against the previous frame's
+  vga_extract  configs[1] verbatim: the same stream, extract only
+  hd1080       configs[2]: 1920x1080 stream, nFeatures 2000, extract + match
+  match100k    configs[4]: one 100,000 x 100,000 top-2 match of 256-bit descriptors per step
 
 A step's `batch` consecutive frames go through `--lanes` (default 4) lanes of batch/lanes consecutive frames, each lane with its
 own extractor handle and HIP stream; a lane matches its own frames, and lanes meet only where the frame-to-frame match crosses
-a lane border (event-ordered hand-off of one frame's descriptors).  So the latency-bound kernels of one lane run next to the
-VALU-bound kernels of another, and consecutive steps overlap.
-The per-kernel roofline numbers come from a short serial pass after the timed region (every kernel alone on the chip).
+a lane border (event-ordered hand-off of one frame's descriptors).  The per-kernel roofline numbers come from a short serial
+pass after the timed region (every kernel alone on the chip).
 
   python bench.py --gpus N --steps K --warmup W
-For N>1 launch under torch.distributed.run (one rank per GPU); every rank extracts its own stream
-(weak scaling, no data-path collective), RCCL only reduces the timing / counters.
-Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU, every rank works on its own stream (weak scaling, no data-path collective); RCCL only takes the MAX of
+the timing and gathers the counters.  Run as a plain command it spawns its N ranks itself; under torch.distributed.run it uses
+the ranks it is given.  The timed region is `repeats` x K steps, with `repeats` chosen so that it lasts at least
+`--min-seconds` (default 2 s; 0 = exactly K steps).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0  # ... 6.29 TB/s measured (float4 copy)
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
+I8_MFMA_PEAK_TOPS = 5000.0   # dense int8 = 2x the 2.5 PFLOP/s bf16 dense peak (MI355X_MICROARCH.md, matrix-core table)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+CONFIGS = {
+    "vga": dict(width=640, height=480, nfeatures=1000, batch=1024, ring=2048, match=True, baseline_config=1),
+    "vga_extract": dict(width=640, height=480, nfeatures=1000, batch=1024, ring=2048, match=False, baseline_config=1),
+    "hd1080": dict(width=1920, height=1080, nfeatures=2000, batch=128, ring=256, match=True, baseline_config=2),
+    "match100k": dict(n=100000, baseline_config=4),
+}
 
 
+# ------------------------------------------------------------------------------------------------ helpers
 def level_sizes(w, h, nlevels=8, sf=1.2):
+    import numpy as np
     inv = [np.float32(1.0)]
     isf = np.float32(1.0 / np.float64(np.float32(sf)))
     for _ in range(1, nlevels):
@@ -57,69 +72,123 @@ def algorithmic_bytes(w, h, nkp, nlevels=8):
     return a_extract, a_match, per_stage
 
 
-def cpu_baseline(w, h, nfeat, seconds=15.0):
-    """Oracle (scalar CPU restatement of the reference algorithm) timed on this host, 1 core, bounded sample.
-    The reference runs its extractor on the single Tracking thread (src/Tracking.cc:199-202), hence cores=1."""
+def effective_cores():
+    """(threads this process may run on, cores the container's CPU quota allows): the GPU boxes expose 256 hardware threads but
+    the pod's cgroup caps the CPU time (cpu.max = 1600000 100000 -> 16 cores), which is what an all-core run can use."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    return aff, quota
+
+
+def _cpu_worker(args):
+    """One oracle instance (instances are not re-entrant, like the reference's extractor) on its own frames."""
+    idx, w, h, nfeat, seconds, do_match = args
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
     from orb_slam_amd import synth
     o = orc.OracleExtractor(nfeatures=nfeat)
-    imgs = synth.frames(w, h, synth.BLOCKS, 6000, 32)      # synthesis is outside the timed loop
-    prev = o(imgs[0])[1]                                    # warm-up frame (page faults), not timed
-    done = 0
-    t = time.perf_counter()
+    imgs = synth.frames(w, h, synth.BLOCKS, 6000 + 64 * idx, 8)      # synthesis is outside the timed loop
+    prev = o(imgs[0])[1]                                              # warm-up frame (page faults), not timed
+    done, t = 0, time.perf_counter()
     while time.perf_counter() - t < seconds:
         _, d = o(imgs[(done + 1) % len(imgs)])
-        if len(d) and len(prev):
+        if do_match and len(d) and len(prev):
             orc.match_top2(d, prev)
         prev = d
         done += 1
-    el = time.perf_counter() - t
+    return done, time.perf_counter() - t
+
+
+def cpu_baseline(w, h, nfeat, do_match, seconds):
+    """Oracle (scalar CPU restatement of the reference algorithm) timed on this host, 1 core, bounded sample.
+    The reference runs its extractor on the single Tracking thread (src/Tracking.cc:199-202), hence cores=1."""
+    done, el = _cpu_worker((0, w, h, nfeat, seconds, do_match))
     return {"value": round(done / el, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d S-blocks %dx%d frames, oracle extract (nFeatures %d) + scalar top-2 match vs previous frame, %.1f s"
-                      % (done, w, h, nfeat, el)}
+            "sample": "%d S-blocks %dx%d frames, oracle extract (nFeatures %d)%s, %.1f s"
+                      % (done, w, h, nfeat, " + scalar top-2 match vs previous frame" if do_match else "", el)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU")
-    ap.add_argument("--ring", type=int, default=2048, help="distinct frames resident per GPU (>= 1024 VGA frames exceeds the 256 MiB Infinity Cache)")
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--nfeatures", type=int, default=1000)
-    ap.add_argument("--family", type=int, default=1, help="0 noise, 1 blocks (default), 3 lowtex")
-    ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE configs[1] verbatim)")
-    ap.add_argument("--lanes", type=int, default=4,
-                    help="a step's frames go through this many concurrent lanes (own extractor handle + HIP stream each); 1 = one stream")
-    ap.add_argument("--region-timing", action="store_true",
-                    help="also time every kernel inside the timed region (HIP events between the kernels of every lane: costs a few percent)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo")
-    ap.add_argument("--share-device", action="store_true", help="functional smoke of the N>1 path on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
-    a = ap.parse_args()
+def cpu_baseline_allcores(w, h, nfeat, do_match, seconds):
+    """The same on every core this process may use: one oracle instance per worker process, frames sharded."""
+    import multiprocessing as mp
+    aff, quota = effective_cores()
+    workers = max(1, min(aff, int(math.ceil(quota)) if quota else aff))
+    with mp.get_context("spawn").Pool(workers) as pool:
+        res = pool.map(_cpu_worker, [(i, w, h, nfeat, seconds, do_match) for i in range(workers)])
+    fps = sum(n / t for n, t in res)
+    return {"value": round(fps, 1), "unit": "frames/s", "cores": workers, "kind": "port", "host_threads": aff,
+            "cgroup_cpu_quota_cores": quota,
+            "sample": "%d worker processes x %.0f s, one oracle extractor each, %d frames in all" % (workers, seconds, sum(n for n, _ in res))}
 
-    from orb_slam_amd import dist_util
-    world, rank, local_rank = dist_util.env_ranks()
-    if world == 1 or a.share_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist = dist_util.init(a.backend, world, rank, local_rank)    # "nccl" is RCCL on ROCm
-    assert a.gpus == world, "--gpus %d but WORLD_SIZE %d (launch with torch.distributed.run for N>1)" % (a.gpus, world)
+
+def load_replayed_counters(build_id):
+    """profiles/traffic.json (rocprofv3 --pmc passes over the serial command) and profiles/valu_mix.json (static opcode mix) carry
+    the hash of the kernel sources they were measured on; they are used only when it equals the loaded library's."""
+    out = {"traffic": None, "mix": None, "note": None}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if tj.get("src_hash") == build_id:
+            out["traffic"] = tj
+        else:
+            out["note"] = "profiles/traffic.json was measured on other kernel sources (hash %s, library %s): not replayed" % (tj.get("src_hash"), build_id)
+    except Exception as e:
+        out["note"] = "profiles/traffic.json unreadable: %s" % e
+    try:
+        mj = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
+        if mj.get("src_hash") == build_id:
+            out["mix"] = mj["kernels"]
+    except Exception:
+        pass
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` as a plain command: start the N ranks (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+    torch.distributed.run would set them); rank 0 inherits stdout and prints the JSON line."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ the extraction configs
+def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
+    from orb_slam_amd import capi, dist_util, synth
+    from orb_slam_amd.pipeline import LanePipeline
     dev = torch.device("cuda", local_rank)
-
-    from orb_slam_amd import capi, synth
-    w, h, B = a.width, a.height, a.batch
-    ring = max(a.ring // B, 1) * B
+    w, h, B, nfeat, do_match = cfg["width"], cfg["height"], cfg["batch"], cfg["nfeatures"], cfg["match"]
+    ring = max(cfg["ring"] // B, 1) * B
     frames = synth.frames(w, h, a.family, dist_util.stream_first_index(rank, ring), ring)          # one independent image stream per rank
     d_img = torch.from_numpy(frames).to(dev)
     del frames
-    do_match = not a.no_match
-    from orb_slam_amd.pipeline import LanePipeline
-    pipe = LanePipeline(w, h, B, lanes=a.lanes, nfeatures=a.nfeatures, device=local_rank, do_match=do_match)   # orb_slam_amd/pipeline.py
+    pipe = LanePipeline(w, h, B, lanes=a.lanes, nfeatures=nfeat, device=local_rank, do_match=do_match)   # orb_slam_amd/pipeline.py
     G, b, cap = pipe.G, pipe.b, pipe.cap
 
     def step(i, timed):
@@ -128,11 +197,23 @@ def main():
     for i in range(a.warmup):
         step(i, False)
     torch.cuda.synchronize(dev)
+    # repeats of the K-step block so that the timed region lasts >= --min-seconds: one untimed calibration block tells how long a
+    # block takes (the warm-up steps carry first-call costs); every rank must run the same count
+    repeats = 1
+    if a.min_seconds > 0:
+        tc = time.perf_counter()
+        for i in range(a.steps):
+            step(a.warmup + i, False)
+        torch.cuda.synchronize(dev)
+        tc = time.perf_counter() - tc
+        repeats = max(1, int(math.ceil(a.min_seconds / max(tc, 1e-6))))
+    repeats = int(dist_util.agree_max(dist, repeats, dev if a.backend == "nccl" else torch.device("cpu")))
+    nsteps = repeats * a.steps
     pipe.stage_timing(2 if a.region_timing else 0)
     dist_util.barrier(dist, a.backend, local_rank)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    for i in range(nsteps):
         step(a.warmup + i, a.region_timing)
     torch.cuda.synchronize(dev)
     dist_util.barrier(dist, a.backend, local_rank)
@@ -151,14 +232,14 @@ def main():
         nq = int(last.n[b].item())
         accepted = capi.count_accepted(best[:nq], sec[:nq], 50, 0.6)
 
-    def serial_pass(nsteps):
+    def serial_pass(nser):
         """The same step with every kernel alone on the chip: one extractor over all B frames, one launch per kernel, the match
         on the same stream.  Per-kernel roofline numbers come from here; in the timed region above the lanes co-run, so a
         kernel's duration there includes sharing the CUs with the kernels of the other lanes."""
         keep = os.environ.get("ORBX_OVERLAP")
         os.environ["ORBX_OVERLAP"] = "0"          # read by orbx_create: no blur side stream either, every kernel alone on the chip
         try:
-            ex1 = capi.ORBextractor(nfeatures=a.nfeatures, device=local_rank, max_batch=B)
+            ex1 = capi.ORBextractor(nfeatures=nfeat, device=local_rank, max_batch=B)
         finally:
             if keep is None:
                 del os.environ["ORBX_OVERLAP"]
@@ -170,7 +251,7 @@ def main():
         n1 = torch.zeros(B + 1, dtype=torch.int32, device=dev)
         match1 = torch.zeros((3, B, cap), dtype=torch.int32, device=dev)
         evs = []
-        for i in range(2 + nsteps):
+        for i in range(2 + nser):
             if i == 2:
                 torch.cuda.synchronize(dev)
                 ex1.stage_timing(2)
@@ -197,102 +278,254 @@ def main():
         return ms1
 
     # RCCL: the only collectives of the run (MAX of the timing, all-gather of the counters)
-    tmax, counters, _ = dist_util.reduce_run(dist, elapsed, [a.steps * B, kp_mean * a.steps * B, bad_status],
-                                             dev if a.backend == "nccl" else torch.device("cpu"))
+    tmax, counters, rows = dist_util.reduce_run(dist, elapsed, [nsteps * B, kp_mean * nsteps * B, bad_status, elapsed],
+                                                dev if a.backend == "nccl" else torch.device("cpu"))
+    if rank != 0:
+        return None
     total_frames = float(counters[0])
+    a_extract, a_match, per_stage = algorithmic_bytes(w, h, nfeat)
+    region_ms = {k: (ms / n if n else 0.0) for k, (ms, n) in stage.items()}      # per LAUNCH: one lane's slice of b frames
+    concurrent = G > 1 or not a.region_timing        # without in-region timing the serial pass is the only per-kernel timing
+    stage_ms = serial_pass(10) if concurrent else dict(region_ms)
+    dom = max(stage_ms, key=lambda k: stage_ms[k])
+    dom_frame_bytes = per_stage.get(dom, a_match if dom == "match" else 0)
+    dom_bytes = dom_frame_bytes * B
+    dom_gbs = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+    kernel_ms = sum(stage_ms.values())
+    pipe_bytes = (a_extract + (a_match if do_match else 0)) * B
+    step_ms = tmax / nsteps * 1e3
+    pipe_gbs = pipe_bytes / (step_ms * 1e-3) / 1e9
+    value = total_frames / tmax
 
-    if rank == 0:
-        a_extract, a_match, per_stage = algorithmic_bytes(w, h, a.nfeatures)
-        region_ms = {k: (ms / n if n else 0.0) for k, (ms, n) in stage.items()}      # per LAUNCH: one lane's slice of b frames
-        concurrent = G > 1 or not a.region_timing        # without in-region timing the serial pass is the only per-kernel timing
-        stage_ms = serial_pass(min(a.steps, 10)) if concurrent else dict(region_ms)
-        dom = max(stage_ms, key=lambda k: stage_ms[k])
-        dom_frame_bytes = per_stage.get(dom, a_match if dom == "match" else 0)
-        dom_bytes = dom_frame_bytes * B
-        dom_gbs = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
-        region_frames = b
-        region_gbs = dom_frame_bytes * region_frames / (region_ms[dom] * 1e-3) / 1e9 if region_ms.get(dom, 0) > 0 else 0.0
-        kernel_ms = sum(stage_ms.values())
-        pipe_bytes = (a_extract + (a_match if do_match else 0)) * B
-        step_ms = tmax / a.steps * 1e3
-        pipe_gbs = pipe_bytes / (step_ms * 1e-3) / 1e9
-        traffic, valu_busy, valu_insts = None, None, None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")      # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                if tj.get("workload") == "vga_640x480_nf1000" and (w, h, a.nfeatures, a.family) == (640, 480, 1000, 1):
-                    if tj.get("batch") == B:
-                        traffic = tj.get("per_launch_bytes", {}).get(dom)
-                    valu_busy = tj.get("sq_activity", {}).get(dom, {}).get("valu_busy")
-                    pf = tj.get("valu_wave_insts_per_frame", {})
-                    if pf and (not do_match or "match" in pf):
-                        valu_insts = {k: v for k, v in pf.items() if do_match or k != "match"}
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "frames/s ORB %s @%dx%d, %d kp" % ("extract+match" if do_match else "extract", w, h, a.nfeatures),
-            "value": round(total_frames / tmax, 1),
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": round(tmax / a.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": "%dx%d grayscale stream, 8 levels, nFeatures %d, %s frames, extract%s" % (
-                           w, h, a.nfeatures, {0: "S-noise", 1: "S-blocks", 3: "S-lowtex"}.get(a.family, str(a.family)),
-                           " + Hamming top-2 match vs previous frame" if do_match else " only"),
-                       "frames_per_step_per_gpu": B, "resident_frames_per_gpu": ring,
-                       "parallelism": "one image stream per GPU; a step's %d frames go through %d lanes of %d consecutive frames "
-                                      "(own extractor handle + HIP stream each), frame-to-frame matches across lane borders via event-ordered hand-off" % (B, G, b),
-                       "lanes": G,
-                       "mean_keypoints_per_frame": round(float(counters[1]) / total_frames, 2),
-                       "frames_with_error_status": int(counters[2]), "accepted_matches_last_frame": accepted},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(dom_gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "valu_busy": valu_busy,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(stage_ms[dom], 4), "frames_per_launch": B,
-                         "timing": ("serial pass after the timed region: %d steps, one launch per kernel over all %d frames, nothing else on the chip "
-                                    "(HIP events on the launch stream)" % (min(a.steps, 10), B)) if concurrent else "timed region (one stream)",
-                         "timed_region": {"lanes": G, "frames_per_launch": region_frames, "avg_launch_ms": round(region_ms[dom], 4) if a.region_timing else None,
-                                          "achieved": round(region_gbs, 2) if a.region_timing else None,
-                                          "note": "the lanes co-run, a kernel shares the CUs with the kernels of the other lanes; --region-timing measures the "
-                                                  "per-launch durations there (event pairs between all kernels cost 2-6 % of the throughput)"}},
-            "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(pipe_gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": pipe_bytes,
-                                  "ms_per_step": round(step_ms, 4), "kernel_ms_per_step_serial": round(kernel_ms, 4)},
-            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
-        }
-        if valu_insts:
-            # the resource that actually binds this integer path: VALU issue.  A wave64 op occupies one of the 1024 SIMDs for 4 cycles.
-            # Measured on gfx950 (tools/microbench/valu_rate): 2 cycles for mov/add/sub/and/or/xor/ashr, 4 for the rest; the kernels'
-            # mix is priced from their static opcode histograms (tools/valu_mix.py -> profiles/valu_mix.json), unmeasured opcodes at 2 (lo) / 4 (hi).
-            simd_cycles = 256 * 4 * 2.4e9
-            n_inst = sum(valu_insts.values())
-            ach = out["value"] / world * n_inst
-            rv = {"bound": "valu_issue", "achieved": round(ach / 1e9, 2), "unit": "G wave-insts/s", "wave_insts_per_frame": round(n_inst),
-                  "peak_if_every_inst_took_4_cycles": round(simd_cycles / 4 / 1e9, 2), "frac_if_every_inst_took_4_cycles": round(ach / (simd_cycles / 4), 4),
-                  "source": "SQ_INSTS_VALU of every kernel of the step per frame (rocprofv3 --pmc pass, profiles/traffic.json) x measured frames/s per GPU"}
-            try:
-                mix = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))["kernels"]
-                lo = sum(v * mix[k]["cycles_per_inst_lo"] for k, v in valu_insts.items())
-                hi = sum(v * mix[k]["cycles_per_inst_hi"] for k, v in valu_insts.items())
-                rv.update({"peak": round(simd_cycles / (lo / n_inst) / 1e9, 2), "frac": round(out["value"] / world * lo / simd_cycles, 4),
-                           "frac_range": [round(out["value"] / world * lo / simd_cycles, 4), round(out["value"] / world * hi / simd_cycles, 4)],
-                           "cycles_per_inst_range": [round(lo / n_inst, 3), round(hi / n_inst, 3)],
-                           "pricing": "2 cycles per wave64 inst for mov/add/sub/and/or/xor/ashr/fma_f32, 4 for every other measured opcode "
-                                      "(profiles/r01_valu_issue_rates.txt), static opcode mix per kernel (profiles/valu_mix.json); peak and frac use the low end"})
-            except Exception:
-                pass
-            out["roofline_valu"] = rv
-        if a.region_timing:
-            out["stage_ms_per_launch_timed_region"] = {k: round(v, 4) for k, v in region_ms.items()}
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, h, a.nfeatures, a.cpu_seconds)
-        print(json.dumps(out))
+    # counters replayed from profiles/ (PMC passes cannot run inside this process): only when measured on THIS build
+    rep = load_replayed_counters(capi.build_id())
+    traffic, valu_insts, valu_launch = None, None, None
+    tj = rep["traffic"]
+    same_workload = tj is not None and tj.get("workload") == "vga_640x480_nf1000" and (w, h, nfeat, a.family) == (640, 480, 1000, 1)
+    if same_workload:
+        if tj.get("batch") == B:
+            traffic = tj.get("per_launch_bytes", {}).get(dom)
+        pf = tj.get("valu_wave_insts_per_frame", {})
+        if pf and (not do_match or "match" in pf):
+            valu_insts = {k: v for k, v in pf.items() if do_match or k != "match"}
+            valu_launch = pf.get(dom, 0) * B
+    hbm = {"bound": "hbm", "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 5),
+           "frac_of_achievable": round(dom_gbs / HBM_ACHIEVABLE_GBS, 5), "achievable_peak": HBM_ACHIEVABLE_GBS, "traffic": traffic,
+           "algorithmic_bytes_per_launch": dom_bytes,
+           "traffic_note": "HBM-side (FETCH_SIZE + WRITE_SIZE) * 1024 per launch of this kernel, rocprofv3 --pmc passes over the serial command "
+                           "(profiles/traffic.json; replayed only when its source hash equals the library's)" if traffic else rep["note"]}
+    timing = ("serial pass after the timed region: 10 steps, one launch per kernel over all %d frames, nothing else on the chip "
+              "(HIP events on the launch stream)" % B) if concurrent else "timed region (one stream)"
+    roofline = dict(hbm)
+    roofline.update({"kernel": dom, "avg_launch_ms": round(stage_ms[dom], 4), "frames_per_launch": B, "timing": timing})
+    mix = rep["mix"]
+    if valu_launch and mix and dom in mix:
+        # The resource that binds this integer path is VALU issue, not HBM (SURVEY.md §8d predicted it, the counters confirm it): the
+        # dominant kernel's wave-level VALU instructions per launch / its duration, against 1024 SIMDs x 2.4 GHz / (cycles per instruction).
+        cpi = mix[dom]["cycles_per_inst_lo"]
+        ach = valu_launch / (stage_ms[dom] * 1e-3)
+        peak = SIMD_CYCLES_PER_S / cpi
+        roofline = {"bound": "valu_issue", "kernel": dom, "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-insts/s",
+                    "frac": round(ach / peak, 4), "wave_insts_per_launch": int(valu_launch), "cycles_per_inst": cpi,
+                    "avg_launch_ms": round(stage_ms[dom], 4), "frames_per_launch": B, "timing": timing,
+                    "pricing": "SQ_INSTS_VALU of the kernel (profiles/traffic.json) priced with its static opcode mix (profiles/valu_mix.json): 2 cycles per "
+                               "wave64 instruction for mov/add/sub/and/or/xor/bitop3/right shifts/f32 add-mul-fma, 4 for every other measured opcode "
+                               "(profiles/r01_valu_issue_rates.txt, r02_valu_issue_rates2.txt)",
+                    "hbm": hbm}
+    out = {
+        "metric": "frames/s ORB %s @%dx%d, %d kp" % ("extract+match" if do_match else "extract", w, h, nfeat),
+        "value": round(value, 1),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "repeats": repeats,
+        "timed_steps": nsteps,
+        "timed_seconds": round(tmax, 3),
+        "ms_per_step": round(step_ms, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "%s: %dx%d grayscale stream, 8 levels, nFeatures %d, %s frames, extract%s (BASELINE.json configs[%d]%s)" % (
+                       a.config, w, h, nfeat, {0: "S-noise", 1: "S-blocks", 3: "S-lowtex"}.get(a.family, str(a.family)),
+                       " + Hamming top-2 match vs previous frame" if do_match else " only", cfg["baseline_config"],
+                       " + the frame-to-frame match of the metric" if a.config == "vga" else ""),
+                   "frames_per_step_per_gpu": B, "resident_frames_per_gpu": ring,
+                   "parallelism": "one image stream per GPU; a step's %d frames go through %d lanes of %d consecutive frames "
+                                  "(own extractor handle + HIP stream each), frame-to-frame matches across lane borders via event-ordered hand-off" % (B, G, b),
+                   "lanes": G, "lane_placement": pipe.placement,
+                   "mean_keypoints_per_frame": round(float(counters[1]) / total_frames, 2),
+                   "frames_with_error_status": int(counters[2]), "accepted_matches_last_frame": accepted,
+                   "library_build_id": capi.build_id()},
+        "per_rank": [{"rank": r, "frames": int(row[0]), "elapsed_s": round(row[3], 4), "frames_per_s": round(row[0] / row[3], 1)} for r, row in enumerate(rows)],
+        "roofline": roofline,
+        "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(pipe_gbs / HBM_PEAK_GBS, 5), "frac_of_achievable": round(pipe_gbs / HBM_ACHIEVABLE_GBS, 5),
+                              "algorithmic_bytes_per_step": pipe_bytes, "ms_per_step": round(step_ms, 4), "kernel_ms_per_step_serial": round(kernel_ms, 4)},
+        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+    }
+    if valu_insts and mix and all(k in mix for k in valu_insts):
+        n_inst = sum(valu_insts.values())
+        ach = value / world * n_inst
+        lo = sum(v * mix[k]["cycles_per_inst_lo"] for k, v in valu_insts.items())
+        hi = sum(v * mix[k]["cycles_per_inst_hi"] for k, v in valu_insts.items())
+        out["roofline_valu"] = {
+            "bound": "valu_issue", "achieved": round(ach / 1e9, 2), "unit": "G wave-insts/s", "wave_insts_per_frame": round(n_inst),
+            "peak": round(SIMD_CYCLES_PER_S / (lo / n_inst) / 1e9, 2), "frac": round(value / world * lo / SIMD_CYCLES_PER_S, 4),
+            "frac_range": [round(value / world * lo / SIMD_CYCLES_PER_S, 4), round(value / world * hi / SIMD_CYCLES_PER_S, 4)],
+            "cycles_per_inst_range": [round(lo / n_inst, 3), round(hi / n_inst, 3)],
+            "source": "whole step in the timed region: SQ_INSTS_VALU of every kernel per frame (profiles/traffic.json, same source hash as the library) "
+                      "x measured frames/s per GPU; the match kernel's MFMA work is not VALU and not counted"}
+    elif rep["note"]:
+        out["roofline_valu"] = None
+        out["roofline_note"] = rep["note"]
+    if a.region_timing:
+        out["stage_ms_per_launch_timed_region"] = {k: round(v, 4) for k, v in region_ms.items()}
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w, h, nfeat, do_match, a.cpu_seconds)
+        if a.cpu_allcores_seconds > 0:
+            out["cpu_baseline_allcores"] = cpu_baseline_allcores(w, h, nfeat, do_match, a.cpu_allcores_seconds)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ config 5: 100k x 100k top-2
+def run_match(a, cfg, world, rank, local_rank, dist, torch):
+    """BASELINE.json configs[4].  N > 1: queries sharded by rank, train set replicated — every rank matches its
+    own n/world queries against all n train descriptors; no exchange of partial results."""
+    from orb_slam_amd import capi, dist_util, synth
+    dev = torch.device("cuda", local_rank)
+    n = cfg["n"]
+    nq = (n + world - 1) // world
+    q0 = rank * nq
+    nq = max(0, min(nq, n - q0))
+    Qall = synth.descriptors(n, 1)
+    Q = torch.from_numpy(Qall[q0:q0 + nq].copy()).to(dev)
+    T = torch.from_numpy(synth.descriptors(n, 2)).to(dev)
+    out3 = torch.zeros((3, max(nq, 1)), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream(dev)
+
+    def step():
+        capi.match_top2_device(Q.data_ptr(), nq, T.data_ptr(), n, out3[0].data_ptr(), out3[1].data_ptr(), out3[2].data_ptr(), s.cuda_stream)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    repeats = 1
+    if a.min_seconds > 0:
+        tc = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        tc = time.perf_counter() - tc
+        repeats = max(1, int(math.ceil(a.min_seconds / max(tc, 1e-6))))
+    repeats = int(dist_util.agree_max(dist, repeats, dev if a.backend == "nccl" else torch.device("cpu")))
+    nsteps = repeats * a.steps
+    dist_util.barrier(dist, a.backend, local_rank)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(s)
+    for _ in range(nsteps):
+        step()
+    e1.record(s)
+    torch.cuda.synchronize(dev)
+    dist_util.barrier(dist, a.backend, local_rank)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / nsteps            # split + merge kernels of one call, HIP events on the launch stream
+    checksum = int(out3[1, :nq].sum().item()) if nq else 0
+    tmax, counters, rows = dist_util.reduce_run(dist, elapsed, [float(nq) * n * nsteps, checksum, elapsed],
+                                                dev if a.backend == "nccl" else torch.device("cpu"))
+    if rank != 0:
+        return None
+    pairs = float(counters[0])
+    value = pairs / tmax
+    a_match = 32 * (nq + n) + 12 * nq
+    gbs = a_match / (kernel_ms * 1e-3) / 1e9
+    tops = 2.0 * 256.0 * nq * n / (kernel_ms * 1e-3) / 1e12
+    mfma = os.environ.get("ORBX_MATCH_MFMA", "1") != "0"
+    roofline = {"bound": "mfma" if mfma else "valu_issue", "kernel": "k_match_split_mfma" if mfma else "k_match_split",
+                "achieved": round(tops, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s (int8 multiply-accumulates x 2)", "frac": round(tops / I8_MFMA_PEAK_TOPS, 4),
+                "peak_note": "dense int8 MFMA = 2 x the 2.5 PFLOP/s bf16 dense peak; tools/microbench/valu_rate2 measures 4470 TOP/s for v_mfma_i32_32x32x32_i8",
+                "avg_launch_ms": round(kernel_ms, 4), "pairs_per_launch": float(nq) * n,
+                "timing": "HIP events on the launch stream around the %d calls of the timed region (split + merge kernel per call)" % nsteps,
+                "hbm": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 6),
+                        "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 6), "algorithmic_bytes_per_launch": a_match, "traffic": None}}
+    out = {
+        "metric": "pairs/s Hamming top-2, %d x %d 256-bit descriptors" % (n, n),
+        "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "repeats": repeats, "timed_steps": nsteps,
+        "timed_seconds": round(tmax, 3), "ms_per_step": round(tmax / nsteps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "i8 (+-1 encoded bits, i32 accumulate)" if mfma else "u32 xor + popcount", "data": "synthetic",
+        "config": {"workload": "match100k: batched N-to-M descriptor match, %d x %d random 256-bit descriptors, dense top-2 (BASELINE.json configs[4])" % (n, n),
+                   "queries_per_gpu": nq, "train_descriptors": n, "parallelism": "queries sharded by rank, train set replicated, no exchange",
+                   "best_distance_checksum": int(counters[1]), "library_build_id": capi.build_id()},
+        "per_rank": [{"rank": r, "pairs": row[0], "elapsed_s": round(row[2], 4)} for r, row in enumerate(rows)],
+        "roofline": roofline,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as orc
+        Tn = synth.descriptors(n, 2)
+        done, t = 0, time.perf_counter()
+        blk = 64
+        while time.perf_counter() - t < a.cpu_seconds:
+            orc.match_top2(Qall[done:done + blk], Tn)
+            done += blk
+        el = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": round(done * float(n) / el, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": "%d queries x %d train descriptors, oracle scalar top-2 scan (popcount per word), %.1f s" % (done, n, el)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="vga", choices=sorted(CONFIGS), help="BASELINE.json workload (see the module docstring)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per step per GPU (default: the config's)")
+    ap.add_argument("--ring", type=int, default=None, help="distinct frames resident per GPU (>= 1024 VGA frames exceeds the 256 MiB Infinity Cache)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--nfeatures", type=int, default=None)
+    ap.add_argument("--family", type=int, default=1, help="0 noise, 1 blocks (default), 3 lowtex")
+    ap.add_argument("--no-match", action="store_true", help="extract only (same as --config vga_extract for the VGA stream)")
+    ap.add_argument("--lanes", type=int, default=4,
+                    help="a step's frames go through this many concurrent lanes (own extractor handle + HIP stream each); 1 = one stream")
+    ap.add_argument("--region-timing", action="store_true",
+                    help="also time every kernel inside the timed region (HIP events between the kernels of every lane: costs a few percent)")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="repeat the --steps block until the timed region lasts at least this long (0: exactly --steps steps)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-allcores-seconds", type=float, default=8.0, help="0 disables the all-core CPU baseline")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo")
+    ap.add_argument("--share-device", action="store_true", help="functional smoke of the N>1 path on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
+    a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
+
+    import torch
+    from orb_slam_amd import dist_util
+    world, rank, local_rank = dist_util.env_ranks()
+    if world == 1 or a.share_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dist = dist_util.init(a.backend, world, rank, local_rank)    # "nccl" is RCCL on ROCm
+    if a.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (a.gpus, world))
+    cfg = dict(CONFIGS[a.config])
+    for k in ("batch", "ring", "width", "height", "nfeatures"):
+        if getattr(a, k) is not None and k in cfg:
+            cfg[k] = getattr(a, k)
+    if a.no_match and "match" in cfg:
+        cfg["match"] = False
+    out = run_match(a, cfg, world, rank, local_rank, dist, torch) if a.config == "match100k" else run_frontend(a, cfg, world, rank, local_rank, dist, torch)
+    if out is not None:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

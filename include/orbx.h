@@ -87,6 +87,9 @@ float orbx_get_scale_factor(const orbx_extractor* h);
 /* upper bound on keypoints per frame (= sum of the per-level quotas; == nfeatures for sane parameters) */
 int   orbx_max_keypoints(const orbx_extractor* h);
 const char* orbx_last_error(const orbx_extractor* h);
+/* 16 hex digits: hash of the kernel sources this library was built from (the Makefile passes it in).  bench.py compares it with
+ * the hash recorded in profiles/traffic.json / valu_mix.json and refuses to replay counters measured on other kernels. */
+const char* orbx_build_id(void);
 
 /* One frame, host buffers (the operator() drop-in).  img: 8-bit single channel, `stride` bytes per row.
  * kps[cap], desc[cap*32] are caller buffers, cap >= orbx_max_keypoints().  *n_out = number of features.

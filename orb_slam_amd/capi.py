@@ -24,7 +24,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 # every symbol include/orbx.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "orbx_default_params", "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_scale_factor",
-    "orbx_max_keypoints", "orbx_last_error", "orbx_extract", "orbx_extract_batch_device",
+    "orbx_max_keypoints", "orbx_last_error", "orbx_build_id", "orbx_extract", "orbx_extract_batch_device",
     "orbm_hamming256", "orbm_match_top2", "orbm_match_top2_device", "orbm_match_top2_batch_device",
     "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbm_distinctive", "orbm_distinctive_device",
     "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_device_download",
@@ -123,6 +123,8 @@ def lib():
         L.orbx_max_keypoints.argtypes = [vp]
         L.orbx_last_error.argtypes = [vp]
         L.orbx_last_error.restype = ctypes.c_char_p
+        L.orbx_build_id.argtypes = []
+        L.orbx_build_id.restype = ctypes.c_char_p
         L.orbx_extract.argtypes = [vp, vp, ci, ci, pd, vp, vp, ci, ctypes.POINTER(ci)]
         L.orbx_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, pd, pd, vp, vp, vp, ci, vp, vp]
         L.orbm_hamming256.argtypes = [vp, vp]
@@ -322,6 +324,11 @@ def match_top2_segments(Q, T, seg_off, cand, device=0):
     if rc != ORBX_OK:
         raise OrbxError(rc, "orbm_match_top2_segments")
     return idx, best, sec
+
+
+def build_id():
+    """hash of the kernel sources the loaded library was built from (Makefile -> orbx_build_id)"""
+    return lib().orbx_build_id().decode()
 
 
 def match_top2_device(dQ, nq, dT, nt, d_idx, d_best, d_second, stream=0):

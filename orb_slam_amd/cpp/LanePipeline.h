@@ -11,6 +11,7 @@
 #ifndef ORB_SLAM_AMD_LANE_PIPELINE_H
 #define ORB_SLAM_AMD_LANE_PIPELINE_H
 
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
 #include <stdexcept>
@@ -38,7 +39,7 @@ public:
         bool consumed_valid[2] = {false, false};
     };
 
-    LanePipeline(int width, int height, int batch, int lanes, const orbx_params& params, bool do_match = true)
+    LanePipeline(int width, int height, int batch, int lanes, const orbx_params& params, bool do_match = true, bool autotune = true)
         : w_(width), h_(height), B_(batch), device_(params.device), do_match_(do_match) {
         G_ = lanes < 1 ? 1 : (lanes > batch ? batch : lanes);
         while (B_ % G_) --G_;
@@ -48,12 +49,21 @@ public:
         // the stream is created: new queues until 4 exist, then the least-loaded one.  Streams on one hardware queue are
         // launched in order.  Measured best (rocprofv3 Queue_Id column): every lane stream on a hardware queue of
         // its own, the blur side streams (created inside the extractor handles) sharing those queues.  Creating the G handles
-        // first and the G lane streams after them, back to back, gives that placement; the other way round two lanes share a
-        // queue and the gain of the lanes is lost.
+        // first and the G lane streams after them gives that placement in a fresh process, but streams other libraries created
+        // earlier shift it: three candidate sets of lane streams are created (behind 0, 1 and 2 spacer streams), the first call
+        // of step() times two steps on each and keeps the fastest (placement_ms(), placement_chosen()).
         orbx_params p = params;
         p.max_batch = b_;
         for (Lane& L : lanes_) check(orbx_create(&p, &L.ex), "orbx_create");
-        for (Lane& L : lanes_) check(orbx_stream_create(device_, &L.stream), "orbx_stream_create");
+        const int ncand = (autotune && G_ > 1) ? 3 : 1;
+        sets_.resize(ncand);
+        for (int k = 0; k < ncand; ++k) {
+            for (int sp = 0; sp < k; ++sp) { void* st = nullptr; check(orbx_stream_create(device_, &st), "orbx_stream_create"); spacers_.push_back(st); }
+            sets_[k].resize(G_);
+            for (int g = 0; g < G_; ++g) check(orbx_stream_create(device_, &sets_[k][g]), "orbx_stream_create");
+        }
+        for (int g = 0; g < G_; ++g) lanes_[g].stream = sets_[0][g];
+        tuned_ = ncand == 1;
         for (Lane& L : lanes_) {
             cap_ = orbx_max_keypoints(L.ex);
             alloc(L.kps, (size_t)b_ * cap_);
@@ -78,9 +88,10 @@ public:
             (void)orbx_device_free(device_, L.kps); (void)orbx_device_free(device_, L.desc); (void)orbx_device_free(device_, L.n);
             (void)orbx_device_free(device_, L.status); (void)orbx_device_free(device_, L.match); (void)orbx_device_free(device_, L.h_desc);
             (void)orbx_device_free(device_, L.h_n);
-            (void)orbx_stream_destroy(device_, L.stream);
             orbx_destroy(L.ex);
         }
+        for (auto& set : sets_) for (void* st : set) (void)orbx_stream_destroy(device_, st);
+        for (void* st : spacers_) (void)orbx_stream_destroy(device_, st);
     }
     LanePipeline(const LanePipeline&) = delete;
     LanePipeline& operator=(const LanePipeline&) = delete;
@@ -89,6 +100,7 @@ public:
     void step(const uint8_t* d_frames, ptrdiff_t frame_stride = 0, ptrdiff_t row_stride = 0) {
         if (row_stride == 0) row_stride = w_;
         if (frame_stride == 0) frame_stride = row_stride * h_;
+        if (!tuned_) autotune(d_frames, frame_stride, row_stride);
         const long i = steps_done_;
         const int par = (int)(i & 1);
         for (int g = 0; g < G_; ++g) {
@@ -134,6 +146,8 @@ public:
     }
 
     int lanes() const { return G_; }
+    int placement_chosen() const { return chosen_; }
+    const std::vector<double>& placement_ms() const { return probe_ms_; }      // per candidate stream set: ms per step of the probe
     int frames_per_lane() const { return b_; }
     int frames_per_step() const { return B_; }
     int cap() const { return cap_; }
@@ -146,14 +160,51 @@ private:
         check(orbx_device_alloc(device_, count * sizeof(T), &v), "orbx_device_alloc");
         p = static_cast<T*>(v);
     }
+    // Two timed steps (after one untimed) on every candidate stream set; the fastest stays.  The state the probes touch (step
+    // counter, hand-off slots, counts) is reset, so the first real step starts exactly as without them.
+    void reset_handoff() {
+        steps_done_ = 0;
+        const std::vector<int32_t> zeros((size_t)b_ + 1, 0);
+        for (Lane& L : lanes_) {
+            L.consumed_valid[0] = L.consumed_valid[1] = false;
+            check(orbx_device_upload(device_, L.n, zeros.data(), ((size_t)b_ + 1) * 4), "upload");
+            check(orbx_device_upload(device_, L.h_n, zeros.data(), 2 * 4), "upload");
+        }
+    }
+    void autotune(const uint8_t* d_frames, ptrdiff_t frame_stride, ptrdiff_t row_stride) {
+        tuned_ = true;
+        probe_ms_.clear();
+        for (size_t k = 0; k < sets_.size(); ++k) {
+            for (int g = 0; g < G_; ++g) lanes_[g].stream = sets_[k][g];
+            synchronize();
+            reset_handoff();
+            step(d_frames, frame_stride, row_stride);
+            synchronize();
+            const auto t0 = std::chrono::steady_clock::now();
+            step(d_frames, frame_stride, row_stride);
+            step(d_frames, frame_stride, row_stride);
+            synchronize();
+            probe_ms_.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 500.0);
+        }
+        chosen_ = 0;
+        for (size_t k = 1; k < probe_ms_.size(); ++k) if (probe_ms_[k] < probe_ms_[chosen_]) chosen_ = (int)k;
+        for (int g = 0; g < G_; ++g) lanes_[g].stream = sets_[chosen_][g];
+        synchronize();
+        reset_handoff();
+    }
     static void check(int rc, const char* what) {
         if (rc != ORBX_OK) throw std::runtime_error(std::string(what) + " failed with orbx status " + std::to_string(rc));
     }
 
     int w_, h_, B_, G_ = 1, b_ = 1, cap_ = 0, device_;
     bool do_match_;
+    bool tuned_ = true;
+    int chosen_ = 0;
     long steps_done_ = 0;
     std::vector<Lane> lanes_;
+    std::vector<std::vector<void*>> sets_;      // candidate lane-stream sets
+    std::vector<void*> spacers_;
+    std::vector<double> probe_ms_;
 };
 
 }  // namespace ORB_SLAM

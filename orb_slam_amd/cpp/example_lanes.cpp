@@ -39,7 +39,10 @@ int main(int argc, char** argv) {
             for (int i = 0; i < steps; ++i) pipe.step(static_cast<const uint8_t*>(d_frames) + (size_t)i * B * fbytes);
             pipe.synchronize();
             pipe.download(n[run], kps[run], desc[run], match[run]);
-            if (run == 0) std::printf("lanes %d x %d frames, cap %d\n", pipe.lanes(), pipe.frames_per_lane(), cap);
+            if (run == 0) {
+                std::printf("lanes %d x %d frames, cap %d\n", pipe.lanes(), pipe.frames_per_lane(), cap);
+                for (size_t k = 0; k < pipe.placement_ms().size(); ++k) std::printf("  stream set %zu: %.3f ms per step%s\n", k, pipe.placement_ms()[k], (int)k == pipe.placement_chosen() ? "  <- chosen" : "");
+            }
             if (run == 0 && bench_steps > 0) {
                 const auto t0 = std::chrono::steady_clock::now();
                 for (int i = 0; i < bench_steps; ++i) pipe.step(static_cast<const uint8_t*>(d_frames) + (size_t)(i % steps) * B * fbytes);

@@ -172,6 +172,10 @@ void orbx_destroy(orbx_extractor* h) {
 int orbx_get_levels(const orbx_extractor* h) { return h ? h->p.nlevels : 0; }
 float orbx_get_scale_factor(const orbx_extractor* h) { return h ? (float)(double)h->p.scale_factor : 0.f; }
 const char* orbx_last_error(const orbx_extractor* h) { return h ? h->err.c_str() : "null handle"; }
+#ifndef ORBX_SRC_HASH
+#define ORBX_SRC_HASH "unknown"
+#endif
+const char* orbx_build_id(void) { return ORBX_SRC_HASH; }
 
 int orbx_max_keypoints(const orbx_extractor* h) {
     if (!h) return 0;

@@ -33,6 +33,15 @@ def barrier(dist, backend, local_rank=0):
         dist.barrier()
 
 
+def agree_max(dist, value, device):
+    """MAX of an integer over the ranks (e.g. the repeat count of the timed block: every rank must run the same number of steps)."""
+    if dist is None:
+        return value
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
 def stream_first_index(rank, ring):
     """First synthetic-frame index of this rank's stream: ranks never share frames."""
     return rank * ring

@@ -4,6 +4,8 @@ consecutive frames, each lane with its own extractor handle and HIP stream, ever
 Lanes never join.  The only cross-lane dependency is the one frame per lane whose predecessor lies in the lane to its left
 (lane 0: in the last lane's slice of the previous step): that frame's descriptors travel through a two-slot hand-off buffer
 ordered by HIP events.  torch is used for device memory, streams and events only."""
+import time
+
 import torch
 
 from . import capi
@@ -30,7 +32,7 @@ class _Lane:
 
 
 class LanePipeline:
-    def __init__(self, width, height, batch, lanes=4, nfeatures=1000, device=0, do_match=True, **extractor_kw):
+    def __init__(self, width, height, batch, lanes=4, nfeatures=1000, device=0, do_match=True, autotune=True, **extractor_kw):
         G = max(1, min(lanes, batch))
         while batch % G:
             G -= 1
@@ -40,18 +42,63 @@ class LanePipeline:
         # stream is created: new queues until 4 exist, then the least-loaded one.  Streams on one hardware queue are launched in
         # order.  Measured best (rocprofv3 Queue_Id column): every lane stream on a hardware queue of its own, the
         # blur side streams (created inside the extractor handles) sharing those queues.  Creating the G handles first and the G
-        # lane streams after them, back to back, gives that placement; the other way round two lanes share a queue and the gain
-        # of the lanes is lost.  Raw HIP streams from the C ABI (torch creates its pool streams lazily, i.e. in an order of its own).
+        # lane streams after them, back to back, gives that placement in a fresh process — but any library that created streams
+        # earlier (torch's pool, an RCCL communicator) shifts it.  So the pipeline does not trust the creation order: it creates
+        # three candidate sets of lane streams (with 0, 1 and 2 spacer streams in front, i.e. rotated against the side streams'
+        # queues), times two steps on each at the first call of step() and keeps the fastest (`self.placement` reports the
+        # timings and the choice).  Raw HIP streams from the C ABI (torch creates its pool streams lazily, in an order of its own).
         dev = torch.device("cuda", device)
         handles = [capi.ORBextractor(nfeatures=nfeatures, device=device, max_batch=self.b, **extractor_kw) for _ in range(G)]
-        self._raw_streams = [capi.stream_create(device) for _ in range(G)]
-        streams = [torch.cuda.ExternalStream(p, device=dev) for p in self._raw_streams]
-        self.lanes = [_Lane(handles[g], device, self.b, streams[g]) for g in range(G)]
+        self._raw_sets, self._spacers = [], []
+        for spacer in ((0, 1, 2) if (autotune and G > 1) else (0,)):
+            self._spacers += [capi.stream_create(device) for _ in range(spacer)]
+            self._raw_sets.append([capi.stream_create(device) for _ in range(G)])
+        self._sets = [[torch.cuda.ExternalStream(p, device=dev) for p in raw] for raw in self._raw_sets]
+        self.lanes = [_Lane(handles[g], device, self.b, self._sets[0][g]) for g in range(G)]
         self.device = device
         self.cap = self.lanes[0].ex.max_keypoints
         self.steps_done = 0
         self.match_events = []
+        self.placement = {"candidates": len(self._sets), "chosen": 0, "probe_ms_per_step": None,
+                          "note": "candidate k = lane streams created behind k spacer streams (and behind the handles' side streams)"}
+        self._tuned = len(self._sets) == 1
         torch.cuda.synchronize(dev)      # the zero-fills above ran on the default stream; the lane streams do not wait for it
+
+    def _use_set(self, k):
+        for g, ln in enumerate(self.lanes):
+            ln.stream = self._sets[k][g]
+
+    def _reset_handoff(self):
+        self.steps_done = 0
+        self.match_events = []
+        for ln in self.lanes:
+            ln.h_written, ln.h_consumed = [None, None], [None, None]
+            ln.n.zero_()
+            ln.h_n.zero_()
+
+    def _autotune(self, d_frames_ptr, frame_stride, row_stride):
+        """Two timed steps (after one untimed) on every candidate stream set; the fastest stays.  State touched by the probes (step
+        counter, hand-off slots, counts) is reset, so the first real step starts exactly as without the probes."""
+        dev = torch.device("cuda", self.device)
+        self._tuned = True
+        ms = []
+        for k in range(len(self._sets)):
+            self._use_set(k)
+            self._reset_handoff()
+            torch.cuda.synchronize(dev)
+            self.step(d_frames_ptr, frame_stride, row_stride)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            self.step(d_frames_ptr, frame_stride, row_stride)
+            self.step(d_frames_ptr, frame_stride, row_stride)
+            torch.cuda.synchronize(dev)
+            ms.append((time.perf_counter() - t) * 500.0)
+        best = min(range(len(ms)), key=lambda k: ms[k])
+        self._use_set(best)
+        torch.cuda.synchronize(dev)
+        self._reset_handoff()
+        torch.cuda.synchronize(dev)
+        self.placement.update({"chosen": best, "probe_ms_per_step": [round(v, 4) for v in ms]})
 
     def step(self, d_frames_ptr, frame_stride=None, row_stride=None, timed=False):
         """d_frames_ptr: device address of the step's first frame (B frames, frame_stride bytes apart).  Asynchronous: lane g
@@ -60,6 +107,8 @@ class LanePipeline:
         w, h, b, G, cap = self.w, self.h, self.b, self.G, self.cap
         row_stride = row_stride or w
         frame_stride = frame_stride or row_stride * h
+        if not self._tuned:
+            self._autotune(d_frames_ptr, frame_stride, row_stride)
         i = self.steps_done
         par = i & 1
         for g, ln in enumerate(self.lanes):
@@ -131,6 +180,6 @@ class LanePipeline:
         torch.cuda.synchronize(self.device)
         for ln in self.lanes:
             ln.ex.close()
-        for p in self._raw_streams:
+        for p in [q for raw in self._raw_sets for q in raw] + self._spacers:
             capi.stream_destroy(self.device, p)
-        self._raw_streams = []
+        self._raw_sets, self._spacers = [], []

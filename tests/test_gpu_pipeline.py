@@ -96,3 +96,33 @@ def test_cpp_lane_pipeline(tmp_path):
         assert kps[f, :n[f]].tobytes() == k2[f, :n[f]].tobytes(), f
         assert desc[f, :n[f]].tobytes() == d2[f, :n[f]].tobytes(), f
         np.testing.assert_array_equal(match[:, f, :n[f]], m2[:, f, :n[f]], err_msg="frame %d" % f)
+
+
+def test_lane_placement_is_probed_and_survives_foreign_streams():
+    """Streams created by other libraries before the pipeline shift the runtime's stream -> hardware-queue placement; the pipeline
+    times its candidate stream sets at the first step, reports the choice, and the probes leave no trace in the results."""
+    torch = pytest.importorskip("torch")
+    foreign = [capi.stream_create(0) for _ in range(6)]
+    try:
+        B, w, h, nf, steps = 24, 320, 240, 300, 2
+        frames = synth.frames(w, h, synth.BLOCKS, 40, B * steps)
+        one = _run(frames, B, 1, nf, steps)
+        many = _run(frames, B, 4, nf, steps)
+        for (i, n1, k1, d1, m1), (_, n2, k2, d2, m2) in zip(one, many):
+            np.testing.assert_array_equal(n1, n2)
+            for f in range(B):
+                n = n1[f]
+                assert k1[f, :n].tobytes() == k2[f, :n].tobytes() and d1[f, :n].tobytes() == d2[f, :n].tobytes()
+                np.testing.assert_array_equal(m1[:, f, :n], m2[:, f, :n])
+        from orb_slam_amd.pipeline import LanePipeline
+        d_img = torch.from_numpy(frames).cuda()
+        pipe = LanePipeline(w, h, B, lanes=4, nfeatures=nf)
+        pipe.step(d_img.data_ptr())
+        torch.cuda.synchronize()
+        p = pipe.placement
+        assert p["candidates"] == 3 and len(p["probe_ms_per_step"]) == 3 and 0 <= p["chosen"] < 3
+        assert p["probe_ms_per_step"][p["chosen"]] == min(p["probe_ms_per_step"])
+        pipe.close()
+    finally:
+        for s in foreign:
+            capi.stream_destroy(0, s)

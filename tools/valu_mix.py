@@ -9,21 +9,25 @@ ends (2 and 4) and give the [lo, hi] interval.  Writes profiles/valu_mix.json, r
 The histogram is static (all code of the kernel counts once), so the result is an estimate of the dynamic mix."""
 import collections, json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from orb_slam_amd import capi
 FAST = {"v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_ashrrev_i32", "v_lshrrev_b32",
-        "v_fma_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32"}
+        "v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_bitop3_b32", "v_add_u16", "v_max_u16"}   # + round 2: tools/microbench/valu_rate2
 SLOW = {"v_and_or_b32", "v_min_u32", "v_max_u32", "v_min_i32", "v_max_i32", "v_lshlrev_b32", "v_bcnt_u32_b32", "v_perm_b32", "v_dot4_u32_u8",
         "v_dot2_u32_u16", "v_alignbyte_b32", "v_mul_lo_u32", "v_mad_u32_u24", "v_mad_i32_i24", "v_sad_u8", "v_cndmask_b32", "v_max3_u32", "v_min3_u32",
         "v_xad_u32", "v_lshl_or_b32", "v_add3_u32", "v_bfe_u32", "v_bfe_i32", "v_lshl_add_u32", "v_mul_i32_i24", "v_mul_u32_u24", "v_or3_b32", "v_med3_u32",
         "v_med3_i32", "v_mul_hi_u32", "v_cvt_f32_i32", "v_cvt_i32_f32", "v_cvt_f32_u32", "v_cvt_u32_f32", "v_rndne_f32", "v_cvt_f32_ubyte0",
-        "v_cvt_f32_ubyte1", "v_cvt_f32_ubyte2", "v_cvt_f32_ubyte3", "v_readfirstlane_b32"}
-STAGE = {"k_resize<true>": "pyramid", "k_fast_cells<true, 256, 2, 256>": "fast_cells", "k_quota": "quota", "k_cell_select": "cell_select",
-         "k_level_select": "level_select", "k_blur<true>": "blur", "k_describe": "describe", "k_match_batch<1>": "match"}
+        "v_cvt_f32_ubyte1", "v_cvt_f32_ubyte2", "v_cvt_f32_ubyte3", "v_readfirstlane_b32",
+        "v_pk_add_u16", "v_pk_sub_i16", "v_pk_min_u16", "v_pk_max_u16", "v_pk_lshrrev_b16", "v_lerp_u8", "v_min_f32", "v_max_f32", "v_mbcnt_lo_u32_b32",
+        "v_mbcnt_hi_u32_b32", "v_add_co_u32", "v_bfi_b32", "v_alignbit_b32", "v_cvt_pk_u8_f32", "v_xnor_b32", "v_dot4_i32_i8", "v_dot8_i32_i4"}   # round 2 measurements
+STAGE = {"k_resize<true>": "pyramid", "k_fast_cells<true, 256, 2>": "fast_cells", "k_quota": "quota", "k_cell_select": "cell_select",
+         "k_level_select": "level_select", "k_blur<true>": "blur", "k_describe": "describe", "k_match_batch_mfma<2>": "match"}
 hist = {}
 with tempfile.TemporaryDirectory() as td:
     for src in ("orbx_kernels.hip", "orbm_match.hip"):
         asm = os.path.join(td, src + ".s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-I" + ROOT + "/include",
-                        "-I" + ROOT + "/orb_slam_amd/csrc", "--cuda-device-only", "-S", ROOT + "/orb_slam_amd/csrc/" + src, "-o", asm],
+                        "-mllvm", "-amdgpu-mfma-vgpr-form", "-I" + ROOT + "/orb_slam_amd/csrc", "--cuda-device-only", "-S", ROOT + "/orb_slam_amd/csrc/" + src, "-o", asm],
                        check=True, stderr=subprocess.DEVNULL)
         cur = None
         for line in open(asm):
@@ -42,7 +46,7 @@ with tempfile.TemporaryDirectory() as td:
                 if op.startswith("v_cmp"):
                     op = "v_cmp"
                 hist.setdefault(cur, collections.Counter())[op] += 1
-out = {"issue_cycles": {"fast_class": 2, "slow_class": 4, "measured_by": "tools/microbench/valu_rate (profiles/r01_valu_issue_rates.txt)"}, "kernels": {}}
+out = {"src_hash": capi.build_id(), "issue_cycles": {"fast_class": 2, "slow_class": 4, "measured_by": "tools/microbench/valu_rate, valu_rate2 (profiles/r01_valu_issue_rates.txt, r02_valu_issue_rates2.txt)"}, "kernels": {}}
 for st, h in hist.items():
     n = sum(h.values())
     fast = sum(c for o, c in h.items() if o in FAST)
