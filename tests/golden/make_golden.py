@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
-"""Create the committed golden fixtures under tests/golden/ from the CPU oracle.
+"""Create the committed golden fixtures under tests/golden/ from the REFERENCE'S OWN src/ORBextractor.cc.
 
-The reference has no tests / golden vectors of its own and cannot be built here, so these
-vectors are OUR oracle's outputs on exact-integer synthetic frames: they pin the oracle against drift and
-let the GPU tests run without the oracle.  Re-run only when the oracle definition changes on purpose."""
+The reference ships no tests / golden vectors, but its extractor translation unit compiles where it lies against
+the stand-in OpenCV headers (oracle/Makefile -> oracle/_ref/libref_orbextractor.so).  The keypoints and
+descriptors stored here are that library's outputs on exact-integer synthetic frames: tests/test_golden.py has the oracle
+reproduce them on the CPU and the HIP path reproduce them on the GPU with no oracle in the chain — product against reference
+output, like tests/golden/make_golden_matcher.py does for ORBmatcher.cc.  (The OpenCV pixel primitives behind the stand-in
+headers are restatements; the per-level pyramid hashes are stage artefacts of the oracle, which this script first
+checks against the reference's final outputs.)  Runs only where /root/reference exists; the outputs are committed."""
 import hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -24,12 +28,16 @@ sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 out = {}
 gold = os.path.join(ROOT, "tests", "golden")
 os.makedirs(gold, exist_ok=True)
+assert orc.ref_available(), "oracle/_ref/libref_orbextractor.so missing: run `make -C oracle ref` where /root/reference exists"
 for name, w, h, fam, idx, kw, full in CASES:
     img = synth.frame(w, h, fam, idx)
+    k, d = orc.RefExtractor(**kw)(img)                    # /root/reference/src/ORBextractor.cc itself
     o = orc.OracleExtractor(dumps=True, **kw)
-    k, d = o(img)
+    ok, od = o(img)
+    assert k.tobytes() == ok.tobytes() and d.tobytes() == od.tobytes(), "oracle and reference disagree on " + name
     nl = kw.get("nlevels", 8)
     rec = {"w": w, "h": h, "family": fam, "index": idx, "kwargs": kw, "n": int(len(k)),
+           "made_by": "/root/reference/src/ORBextractor.cc (oracle/_ref/libref_orbextractor.so)",
            "frame_sha256": sha(img), "kps_sha256": sha(k), "desc_sha256": sha(d),
            "pyramid_sha256": [sha(o.level_plane(l, 0)) for l in range(nl)],
            "per_level": np.bincount(k["octave"], minlength=nl).tolist() if len(k) else [0] * nl}

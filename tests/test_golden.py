@@ -1,5 +1,6 @@
-"""Committed golden vectors (tests/golden/, made by tests/golden/make_golden.py from the oracle):
-CPU: the oracle still reproduces them (pins the oracle); GPU: the HIP path reproduces them without the oracle."""
+"""Committed golden vectors (tests/golden/, made by tests/golden/make_golden.py from the reference's own src/ORBextractor.cc
+compiled against the stand-in OpenCV headers): CPU: the oracle reproduces them; GPU: the HIP path reproduces them with no
+oracle in the chain."""
 import hashlib
 import json
 import os

@@ -81,6 +81,34 @@ def test_full_size_properties():
     assert capi.count_accepted(gb, gs, 50, 0.6) == orc.lib().orc_count_accepted(gb.ctypes.data, gs.ctypes.data, n, 50, 0.6)
 
 
+def test_full_size_every_row_against_the_oracle():
+    """100k x 100k (BASELINE config 5), EVERY query row: the scalar oracle scan runs on all host cores (ctypes releases the
+    GIL; 1e10 pairs at ~1.6e8 pairs/s per core), with planted duplicates so that first-index ties and the multiplicity of the
+    second-best distance occur at this size too."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    n = 100_000
+    Q, T = synth.descriptors(n, 78), synth.descriptors(n, 79)
+    T[5000:90000:1777] = T[123]                        # repeated train descriptors (ties on the best distance)
+    Q[::4999] = T[40000:40000 + len(Q[::4999])]        # exact matches (distance 0)
+    Q[7::9973] = T[123]                                 # best = 0 with multiplicity: second = 0
+    gi, gb, gs = capi.match_top2(Q, T)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        cores = int(float(q) / float(p)) if q != "max" else len(os.sched_getaffinity(0))
+    except Exception:
+        cores = len(os.sched_getaffinity(0))
+    cores = max(1, min(cores, 64))
+    blocks = [(a, min(a + 500, n)) for a in range(0, n, 500)]
+    with ThreadPoolExecutor(cores) as ex:
+        res = list(ex.map(lambda ab: orc.match_top2(Q[ab[0]:ab[1]], T), blocks))
+    ri = np.concatenate([r[0] for r in res]); rb = np.concatenate([r[1] for r in res]); rs = np.concatenate([r[2] for r in res])
+    np.testing.assert_array_equal(gi, ri)
+    np.testing.assert_array_equal(gb, rb)
+    np.testing.assert_array_equal(gs, rs)
+    assert (gs[7::9973] == 0).all() and (gb[::4999] == 0).all()
+
+
 def _random_segments(rng, nq, nt, max_len):
     lens = rng.integers(0, max_len + 1, nq)
     lens[rng.integers(0, nq, max(nq // 10, 1))] = 0                       # empty candidate sets
