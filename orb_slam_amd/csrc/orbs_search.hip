@@ -103,7 +103,9 @@ __device__ __forceinline__ int rot_bin(float a1, float a2) {
     if (rot < 0.0f) rot += 360.0f;
     int bin = (int)roundf(rot * factor);
     if (bin == HISTO_LENGTH) bin = 0;
-    return bin;
+    // angles outside [0, 360) (e.g. -1 = "no orientation") or NaN would leave [0, HISTO_LENGTH): the reference asserts here
+    // (ROS_ASSERT(bin >= 0 && bin < HISTO_LENGTH)); such a match simply takes no part in the rotation vote (255 = no bin)
+    return (unsigned)bin < (unsigned)HISTO_LENGTH ? bin : 255;
 }
 
 // ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1748-1789) on bin sizes
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
     if (!list_mode) for (int i = tid; i <= ORBF_GRID_CELLS; i += GROUP) off16[i] = (uint16_t)min(coff[i], a.cap);
     const int m = list_mode ? max(min(a.nlist[p], a.cap), 0) : min(coff[ORBF_GRID_CELLS], a.cap);
     for (int j = tid; j < m; j += GROUP) {
-        const int f = cfeat[j];
+        const int f = min(max(cfeat[j], 0), max(nt - 1, 0));          // a malformed list must not index outside the frame
         const orbx_keypoint kp = kps[f];
         tx[j] = kp.x;
         ty[j] = kp.y;
@@ -312,7 +314,6 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
 
     const bool rot_on = (prm.check_orientation & 1) != 0 && rule != ORBS_RULE_MAPPOINTS && rule != ORBS_RULE_FREE;
     const bool claims = rule != ORBS_RULE_FREE;              // FREE: every query independent, nothing is ever claimed
-    const int dbg = prm.check_orientation >> 8;            // development switches (ORBS_DBG): 1 = no speculative scan, 2 = no commit
 
     for (int q0 = 0, group = 0; q0 < nq; q0 += GROUP, ++group) {
         // ---- one query per thread
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
             qr = INFINITY; ql0 = -1; ql1 = -1;
             if (qi < nq && qv) { wy0 = min(max(a.qrange[(qb + qi) * 2], 0), m); wy1 = min(max(a.qrange[(qb + qi) * 2 + 1], wy0), m); wx1 = 0; }
         } else if (qv && !orbf::window_cells(b, qx, qy, qr, &wx0, &wx1, &wy0, &wy1)) { wx0 = 0; wx1 = -1; }
-        if (!qv || (dbg & 1)) wx1 = -1;
+        if (!qv) wx1 = -1;
         uint32_t e0 = KEY_NONE, e1 = KEY_NONE, e2 = KEY_NONE, e3 = KEY_NONE;
         bool any = false;
         for (int col = wx0; col <= wx1; ++col) {
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
 
         // ---- (2) commit: wave after wave, rounds inside a wave
         for (int w = 0; w < GROUP / 64; ++w) {
-            if (wave == w && !(dbg & 2)) {
+            if (wave == w) {
                 int cursor = 0;
                 for (int round = 0;; ++round) {
                     // alive = entries still admissible under the current claim state
@@ -549,14 +550,10 @@ __global__ __launch_bounds__(256) void k_agreement(const int32_t* __restrict__ m
 
 }  // namespace orbs
 
-// the kernel may use up to the whole 160 KiB of LDS: raise the dynamic-LDS limit once per process (per device context)
+// the kernel may use up to the whole 160 KiB of LDS: raise the dynamic-LDS limit of the current device
 static int orbs_set_lds(size_t) {
-    static std::once_flag once;
-    static int rc = ORBX_OK;
-    std::call_once(once, [] {
-        if (hipFuncSetAttribute((const void*)orbs::k_window_search, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) rc = ORBX_ERR_DEVICE;
-    });
-    return rc;
+    // the attribute belongs to the CURRENT device: set it on every launch path (a cheap runtime call), not once per process
+    return hipFuncSetAttribute((const void*)orbs::k_window_search, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
 
 extern "C" {
@@ -595,7 +592,6 @@ int orbs_window_search_batch_device(const orbf_bounds* b, const orbs_params* prm
     if (orbs_set_lds(lds) != ORBX_OK) return ORBX_ERR_DEVICE;
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
-    if (const char* e = getenv("ORBS_DBG")) prm2.check_orientation |= atoi(e) << 8;
     orbs::Args a{d_kps_un, d_desc, d_cell_off, d_cell_feat, d_nt, d_claimed, d_qxyr, d_qlev, d_qdesc, d_qangle, d_qvalid, d_nq,
                  d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
     hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, *b, prm2, a);
@@ -617,7 +613,6 @@ int orbs_list_search_batch_device(const orbs_params* prm, const orbx_keypoint* d
     if (orbs_set_lds(lds) != ORBX_OK) return ORBX_ERR_DEVICE;
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
-    if (const char* e = getenv("ORBS_DBG")) prm2.check_orientation |= atoi(e) << 8;
     orbs::Args a{d_kps, d_desc, nullptr, d_list, d_nt, d_claimed, nullptr, nullptr, d_qdesc, d_qangle, d_qvalid, d_nq,
                  d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, d_nlist, d_qrange, d_qindex, nullptr, nullptr, {}};
     orbf_bounds nob{};
@@ -641,7 +636,6 @@ int orbs_triangulation_search_batch_device(const orbs_params* prm, const float* 
     if (orbs_set_lds(lds) != ORBX_OK) return ORBX_ERR_DEVICE;
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
-    if (const char* e = getenv("ORBS_DBG")) prm2.check_orientation |= atoi(e) << 8;
     orbs::Args a{d_kps2, d_desc2, nullptr, d_list, d_nt, d_claimed, nullptr, nullptr, d_qdesc, nullptr, d_qvalid, d_nq,
                  d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, d_nlist, d_qrange, d_qindex, d_kps1, d_F12, {}};
     for (int i = 0; i < ORBS_MAX_LEVELS; ++i) a.epi_thr[i] = orbs_epipolar_bound(level_sigma2[i < nlevels ? i : nlevels - 1]);

@@ -450,13 +450,9 @@ int orbv_transform_batch_device(orbv_vocabulary* v, const uint8_t* d_desc, const
     while (P < cap) P <<= 1;
     const int norm_mode = v->scoring == ORBV_DOT_PRODUCT ? 0 : (v->scoring == ORBV_L2_NORM ? 2 : 1);   // ScoringObject.h:74-89
     const size_t lds = (size_t)P * 16;
-    static std::once_flag once;
-    static int attr_rc = ORBX_OK;
-    std::call_once(once, [] {
-        if (hipFuncSetAttribute((const void*)orbv::k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, ORBV_MAX_FEATURES * 16) != hipSuccess)
-            attr_rc = ORBX_ERR_DEVICE;
-    });
-    if (attr_rc != ORBX_OK) return attr_rc;
+    // the dynamic-LDS limit is an attribute of the CURRENT device: set per launch, not once per process
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)orbv::k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, ORBV_MAX_FEATURES * 16) != hipSuccess)
+        return ORBX_ERR_DEVICE;
     hipLaunchKernelGGL(orbv::k_assemble, dim3(nframes), dim3(orbv::ASM_BLOCK), lds, st, d_n, cap, P, v->weighting, norm_mode,
                        v->s_word, v->s_weight, v->s_node, d_bow_id, d_bow_val, d_n_bow, d_fv_node, d_fv_off, d_fv_feat, d_n_fv);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;

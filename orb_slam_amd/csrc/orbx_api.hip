@@ -23,6 +23,7 @@ struct orbx_extractor {
     BandGeom* d_bands = nullptr;
     ResizeX* d_tabx = nullptr;
     ResizeY* d_taby = nullptr;
+    int* d_pyr_tab = nullptr;
     // per-batch working set (max_batch frames)
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;
     Cand *d_cand = nullptr, *d_sel = nullptr;
@@ -63,7 +64,7 @@ static void dev_free(T*& p) {
 }
 
 static void free_geometry(orbx_extractor* h) {
-    dev_free(h->d_cells); dev_free(h->d_bands); dev_free(h->d_tabx); dev_free(h->d_taby);
+    dev_free(h->d_cells); dev_free(h->d_bands); dev_free(h->d_tabx); dev_free(h->d_taby); dev_free(h->d_pyr_tab);
     dev_free(h->d_pyr); dev_free(h->d_blur);
     dev_free(h->d_cand); dev_free(h->d_sel); dev_free(h->d_cstate); dev_free(h->d_csel);
     dev_free(h->d_level_total); dev_free(h->d_level_count); dev_free(h->d_status);
@@ -93,6 +94,7 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
     if ((rc = upload(h, h->d_bands, h->hg.bands)) != ORBX_OK) return rc;
     if ((rc = upload(h, h->d_tabx, h->hg.tabx)) != ORBX_OK) return rc;
     if ((rc = upload(h, h->d_taby, h->hg.taby)) != ORBX_OK) return rc;
+    if ((rc = upload(h, h->d_pyr_tab, h->hg.pyr_tab)) != ORBX_OK) return rc;
     HIPCHK(h, hipMalloc(&h->d_pyr, B * g.frame_plane_bytes));
     HIPCHK(h, hipMalloc(&h->d_blur, B * g.frame_plane_bytes));
     HIPCHK(h, hipMalloc(&h->d_cand, B * std::max(g.frame_cands, 1) * sizeof(Cand)));
@@ -111,7 +113,7 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
 }
 
 static void fill_batch(orbx_extractor* h, Batch& b) {
-    b.g = h->hg.g; b.cells = h->d_cells; b.bands = h->d_bands; b.tabx = h->d_tabx; b.taby = h->d_taby;
+    b.g = h->hg.g; b.cells = h->d_cells; b.bands = h->d_bands; b.tabx = h->d_tabx; b.taby = h->d_taby; b.pyr_tab = h->d_pyr_tab;
     b.pyr = h->d_pyr; b.blur = h->d_blur;
     b.cand = h->d_cand; b.sel = h->d_sel; b.cstate = h->d_cstate; b.csel = h->d_csel;
     b.level_total = h->d_level_total; b.level_count = h->d_level_count; b.status = h->d_status;

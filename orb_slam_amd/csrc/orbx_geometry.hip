@@ -250,6 +250,70 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
             }
         }
     }
+    // fused pyramid launches: groups of levels, per-tile regions of every level of a group (see PyrGroup)
+    {
+        constexpr int tile[2] = {ORBX_PYR_TILE};
+        g.npyr_groups = 0;
+        out.pyr_tab.clear();
+        bool ok = scaleFactor <= 2.0 && nl > 1 && !getenv("ORBX_PYR_PER_LEVEL");      // beyond 2 the bilinear taps of neighbouring pixels leave gaps
+        int l0 = 0;
+        while (ok && l0 < nl - 1) {
+            if (g.npyr_groups == PYR_MAX_GROUPS) { ok = false; break; }
+            PyrGroup pg;
+            memset(&pg, 0, sizeof(pg));
+            pg.l0 = l0;
+            pg.depth = std::min(l0 == 0 ? 3 : PYR_MAX_DEPTH, nl - 1 - l0);
+            const LevelGeom& LD = g.lv[l0 + pg.depth];
+            pg.ntx = (LD.w + tile[0] - 1) / tile[0];
+            pg.nty = (LD.h + tile[1] - 1) / tile[1];
+            // regions[k][i] = {first, last} column of tile i on level l0 + k; entry ntx is the end sentinel {W, W}
+            auto chain = [&](int n, int tsz, bool is_x, std::vector<int>& tab) {
+                const int base = (int)tab.size();
+                tab.resize(base + (size_t)(pg.depth + 1) * (n + 1) * 2);
+                auto at = [&](int k, int i, int e) -> int& { return tab[base + ((size_t)k * (n + 1) + i) * 2 + e]; };
+                const int dim_d = is_x ? LD.w : LD.h;
+                for (int i = 0; i <= n; i++) { at(pg.depth, i, 0) = std::min(i * tsz, dim_d); at(pg.depth, i, 1) = std::min((i + 1) * tsz, dim_d) - 1; }
+                at(pg.depth, n, 1) = dim_d;
+                for (int k = pg.depth; k >= 1; k--) {
+                    const LevelGeom& Lk = g.lv[l0 + k];
+                    const LevelGeom& Ls = g.lv[l0 + k - 1];
+                    const int dk = is_x ? Lk.w : Lk.h, ds = is_x ? Ls.w : Ls.h;
+                    // starts first (they define ownership), then the ends: what the region's last pixel needs, at least up to the next start
+                    for (int i = 0; i <= n; i++) {
+                        const int s0 = at(k, i, 0);
+                        int src = ds;
+                        if (s0 < dk) src = is_x ? (out.tabx[Lk.tabx_off + s0].sx & ~3) : out.taby[Lk.taby_off + s0].sy0;
+                        at(k - 1, i, 0) = src;
+                    }
+                    for (int i = 0; i < n; i++) {
+                        const int e0 = std::min(at(k, i, 1), dk - 1);
+                        int need = is_x ? out.tabx[Lk.tabx_off + e0].sx1 : out.taby[Lk.taby_off + e0].sy1;
+                        need = std::max(need, at(k - 1, i + 1, 0) - 1);
+                        if (is_x) need = std::min(need | 3, ds - 1);
+                        at(k - 1, i, 1) = std::max(need, at(k - 1, i, 0));
+                    }
+                    at(k - 1, n, 1) = ds;
+                }
+                return base;
+            };
+            pg.xtab = chain(pg.ntx, tile[0], true, out.pyr_tab);
+            pg.ytab = chain(pg.nty, tile[1], false, out.pyr_tab);
+            int off = 0;
+            for (int k = 0; k < pg.depth; k++) {
+                int maxw = 4, maxh = 1;
+                for (int i = 0; i < pg.ntx; i++) maxw = std::max(maxw, out.pyr_tab[pg.xtab + ((size_t)k * (pg.ntx + 1) + i) * 2 + 1] - out.pyr_tab[pg.xtab + ((size_t)k * (pg.ntx + 1) + i) * 2] + 1);
+                for (int i = 0; i < pg.nty; i++) maxh = std::max(maxh, out.pyr_tab[pg.ytab + ((size_t)k * (pg.nty + 1) + i) * 2 + 1] - out.pyr_tab[pg.ytab + ((size_t)k * (pg.nty + 1) + i) * 2] + 1);
+                pg.pitch[k] = align_up(maxw, 4) + 4;
+                pg.lds_off[k] = off;
+                off += align_up(pg.pitch[k] * maxh, 16);
+            }
+            pg.lds_bytes = off;
+            if (off > 64 * 1024) { ok = false; break; }
+            g.pyr[g.npyr_groups++] = pg;
+            l0 += pg.depth;
+        }
+        if (!ok) { g.npyr_groups = 0; out.pyr_tab.clear(); }
+    }
     // LDS carve of k_fast_cells, sized by the largest band
     {
         int max_px = 0, max_img = 0, max_chunks = 0;

@@ -98,6 +98,24 @@ struct BandGeom {
     int32_t cand_cap;
 };
 
+// Fused pyramid (k_pyramid): one launch produces `depth` consecutive levels l0+1 .. l0+depth from level l0.  A workgroup owns a
+// tw x th tile of the DEEPEST level and everything above it: the region of every intermediate level it needs lives in LDS.
+// Regions and ownership come from host tables (pyr_tab): per level k = 0 .. depth (k = 0: the source level) and tile index,
+// the first / last column (row) of the tile's region; a tile OWNS (= writes to HBM) the columns from its region start up to the
+// next tile's region start, which partitions every level.  Region starts are multiples of 4 (dword stores never straddle owners).
+constexpr int PYR_MAX_GROUPS = 4, PYR_MAX_DEPTH = 4;
+struct PyrGroup {
+    int l0, depth;               // source level, number of levels produced
+    int ntx, nty;                // tiles of the deepest level
+    int xtab, ytab;              // offsets into pyr_tab: x regions [(depth + 1)][ntx + 1][2], then y regions [(depth + 1)][nty + 1][2]
+    int lds_off[PYR_MAX_DEPTH];  // LDS byte offset of the buffer of level l0 + k (k = 0 .. depth-1; the deepest level goes to HBM only)
+    int pitch[PYR_MAX_DEPTH];    // ... its row pitch (multiple of 4)
+    int lds_bytes;
+};
+#ifndef ORBX_PYR_TILE
+#define ORBX_PYR_TILE 64, 32
+#endif
+
 struct CellState { int32_t n_all, n_hi, n_lo; };     // survivors total, with score>=fastTh, with score>=7
 struct CellSel { int32_t thr, nkeys, nretain, out_off; };
 
@@ -116,6 +134,8 @@ struct DevGeom {
     int fast_max_img, fast_max_chunks, fast_lds_bytes;   // k_fast_cells LDS carve: staged image bytes (= score plane bytes) of the largest band, 64-byte chunks of a band's own rows
     int fast_threads;        // k_fast_cells workgroup size chosen for this geometry
     int fast_small;          // 1: the small launch shape (VGA-class grids), 0: the large one
+    int npyr_groups;         // 0: one k_resize launch per level (scale factors > 2 or regions that do not fit the LDS)
+    PyrGroup pyr[PYR_MAX_GROUPS];
     int umax[HALF_PATCH + 1];
     // per-level bases as compact arrays: one scalar load each, so a wave finds its level in a single round trip
     // (walking lv[l].xxx_base level by level was a chain of up to nlevels dependent scalar loads, ~1.5 us per wave)
@@ -132,6 +152,7 @@ struct Batch {
     const BandGeom* bands;
     const ResizeX* tabx;
     const ResizeY* taby;
+    const int* pyr_tab;       // region tables of the fused pyramid launches (PyrGroup)
     const uint8_t* img;       // level 0 (caller's frames)
     long long img_row_stride, img_frame_stride;
     uint8_t* pyr;             // [frame][frame_plane_bytes]  levels >= 1 (level-0 slot unused)
@@ -158,6 +179,7 @@ struct HostGeom {
     std::vector<BandGeom> bands;
     std::vector<ResizeX> tabx;
     std::vector<ResizeY> taby;
+    std::vector<int> pyr_tab;
     std::vector<int> features_per_level;
     std::vector<float> scale, inv_scale;
 };

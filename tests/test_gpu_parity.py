@@ -321,3 +321,38 @@ def test_wide_grid_cells(gpu_extractor_factory, w, h, nf, nl, sf):
         gk, gd = gpu_extractor_factory(nfeatures=nf, scaleFactor=sf, nlevels=nl, fastTh=th)(img)
         _assert_kps_equal(gk, ok)
         np.testing.assert_array_equal(gd, od)
+
+
+@pytest.mark.parametrize("unaligned", [False, True])
+def test_large_batch_takes_the_per_level_pyramid(gpu_extractor_factory, unaligned):
+    """launch groups of >= 32 frames build the pyramid with one k_resize launch per level, smaller ones with the fused k_pyramid
+    launches: both against the oracle, on one set of frames (aligned and byte-offset device buffers)"""
+    torch = pytest.importorskip("torch")
+    B, w, h, nf = 40, 322, 246, 400
+    frames = np.concatenate([synth.frames(w, h, synth.BLOCKS, 500, 30), synth.frames(w, h, synth.NOISE, 600, 6), synth.frames(w, h, synth.LOWTEX, 700, 4)])
+    pad = 1 if unaligned else 0
+    row_stride = w + (3 if unaligned else 2)
+    frame_stride = row_stride * h + (5 if unaligned else 4)
+    buf = np.zeros(pad + B * frame_stride + 8, np.uint8)
+    for f in range(B):
+        buf[pad + f * frame_stride: pad + f * frame_stride + row_stride * h].reshape(h, row_stride)[:, :w] = frames[f]
+    d_buf = torch.from_numpy(buf).cuda()
+    o = orc.OracleExtractor(nfeatures=nf)
+    want = [o(frames[f]) for f in range(B)]
+    for max_batch in (40, 8):                                     # one per-level launch group of 40; five fused groups of 8
+        ex = gpu_extractor_factory(nfeatures=nf, max_batch=max_batch)
+        cap = ex.max_keypoints
+        d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+        ex.extract_batch_device(d_buf.data_ptr() + pad, B, w, h, row_stride, frame_stride, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+                                0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        n = d_n.cpu().numpy()
+        kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+        desc = d_desc.cpu().numpy()
+        for f in range(B):
+            ok, od = want[f]
+            assert n[f] == len(ok), (max_batch, f)
+            _assert_kps_equal(kps[f, :n[f]].copy().view(capi.KP_DTYPE).reshape(-1), ok)
+            np.testing.assert_array_equal(desc[f, :n[f]], od)

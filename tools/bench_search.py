@@ -57,4 +57,4 @@ for _ in range(a.iters): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 print(json.dumps({"ms": round(ms, 4), "problems": P, "n": n, "window": a.window, "rule": a.rule, "queries_per_s": round(P * n / ms * 1e3),
-                  "mean_matches": round(float(nm.float().mean()), 1), "dbg": os.environ.get("ORBS_DBG", "")}))
+                  "mean_matches": round(float(nm.float().mean()), 1)}))
