@@ -32,11 +32,14 @@ constexpr int HISTO_LENGTH = 30;             // src/ORBmatcher.cc:42
 
 struct Layout { uint32_t off16, tx, ty, tang, tmeta, tdesc, state, claim, t2q, q2t, binv, hist, epi, total; };
 
-__host__ __device__ inline Layout make_layout(int cap, int qcap) {
+// desc_in_lds: the train descriptors (32 of the ~57 bytes a staged feature costs) are staged too; frames too large for that
+// (beyond ~2850 features) leave them in global memory — the candidates of a window then gather 32 bytes each through L2 — which
+// carries the capacity to ~6500 features per problem (an initialisation extractor of 4000 features fits).
+__host__ __device__ inline Layout make_layout(int cap, int qcap, bool desc_in_lds) {
     auto al = [](uint32_t x) { return (x + 15u) & ~15u; };
     Layout L;
     uint32_t o = 0;
-    L.tdesc = o; o += al((uint32_t)cap * 32);
+    L.tdesc = o; o += desc_in_lds ? al((uint32_t)cap * 32) : 0u;
     L.tx = o; o += al((uint32_t)cap * 4);
     L.ty = o; o += al((uint32_t)cap * 4);
     L.tang = o; o += al((uint32_t)cap * 4);
@@ -72,6 +75,7 @@ struct Args {
     int32_t* second;
     int32_t* nmatches;
     int cap, qcap;
+    int desc_in_lds;
     // list mode (orbs_list_search_batch_device): cell_feat is the candidate list, nlist its length, qrange the per-query runs
     const int32_t* nlist;
     const int32_t* qrange;
@@ -130,10 +134,16 @@ struct Staged {
     const float* tx;
     const float* ty;
     const uint32_t* tmeta;
-    const uint4* tdesc;
+    const uint4* tdesc;        // staged descriptors in grid / list order (only when desc_lds)
     const uint16_t* state;
     const float* epi_thr;
+    const uint8_t* gdesc;      // the problem's train descriptors in global memory (read by feature index when !desc_lds)
+    bool desc_lds;
 };
+__device__ __forceinline__ void staged_desc(const Staged& S, int j, uint32_t meta, uint4& t0, uint4& t1) {
+    if (S.desc_lds) { t0 = S.tdesc[2 * j]; t1 = S.tdesc[2 * j + 1]; }
+    else { const uint4* d = (const uint4*)(S.gdesc + (size_t)(meta & 0xFFFFu) * 32); t0 = d[0]; t1 = d[1]; }
+}
 
 // ORBmatcher::CheckDistEpipolarLine (src/ORBmatcher.cc:136-153) split in two: the query's line l = x1' F12 once per query ...
 struct EpiLine { float a, b, c, den; int th; };
@@ -171,7 +181,9 @@ __device__ __forceinline__ uint32_t candidate_key(const Staged& S, int rule, int
     if (rule == ORBS_RULE_TRIANGULATION) {
         inwin = true;
         if (S.state[meta & 0xFFFFu]) return KEY_NONE;                               // `if(vbMatched2[idx2] || pMP2) continue;`
-        const uint32_t dist = hamming_key(S.tdesc[2 * j], S.tdesc[2 * j + 1], q0, q1);
+        uint4 t0, t1;
+        staged_desc(S, j, meta, t0, t1);
+        const uint32_t dist = hamming_key(t0, t1, q0, q1);
         if ((int)dist > E.th) return KEY_NONE;                                      // `if(dist>TH_LOW) continue;`
         const uint32_t on_line = epi_ok(E, S.tx[j], S.ty[j], S.epi_thr[min((int)(meta >> 16), ORBS_MAX_LEVELS - 1)]) ? 0x8000u : 0u;
         return (dist << 16) | on_line | (uint32_t)j;
@@ -180,7 +192,9 @@ __device__ __forceinline__ uint32_t candidate_key(const Staged& S, int rule, int
     if (!inwin) return KEY_NONE;
     const uint32_t st = S.state[meta & 0xFFFFu];
     if (rule != ORBS_RULE_INIT && st) return KEY_NONE;                              // `if(F.mvpMapPoints[idx]) continue;`
-    const uint32_t dist = hamming_key(S.tdesc[2 * j], S.tdesc[2 * j + 1], q0, q1);
+    uint4 t0, t1;
+    staged_desc(S, j, meta, t0, t1);
+    const uint32_t dist = hamming_key(t0, t1, q0, q1);
     if (rule == ORBS_RULE_INIT && st <= dist) return KEY_NONE;                      // `if(vMatchedDistance[i2]<=dist) continue;`
     return (dist << 16) | (uint32_t)j;
 }
@@ -255,13 +269,14 @@ constexpr int GROUP = 256;
 
 __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_params prm, Args a) {
     extern __shared__ __align__(16) uint8_t lds[];
-    const Layout L = make_layout(a.cap, a.qcap);
+    const Layout L = make_layout(a.cap, a.qcap, a.desc_in_lds != 0);
     uint16_t* off16 = (uint16_t*)(lds + L.off16);
     float* tx = (float*)(lds + L.tx);
     float* ty = (float*)(lds + L.ty);
     float* tang = (float*)(lds + L.tang);
     uint32_t* tmeta = (uint32_t*)(lds + L.tmeta);
     uint4* tdesc = (uint4*)(lds + L.tdesc);
+    const bool desc_lds = a.desc_in_lds != 0;
     uint16_t* state = (uint16_t*)(lds + L.state);
     uint32_t* claim_by = (uint32_t*)(lds + L.claim);
     int16_t* t2q = (int16_t*)(lds + L.t2q);
@@ -269,12 +284,11 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
     uint8_t* binv = lds + L.binv;
     int* hist = (int*)(lds + L.hist);
     float* epi_thr = (float*)(lds + L.epi);
-    const Staged S{off16, tx, ty, tmeta, tdesc, state, epi_thr};
-
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int nt = min(a.nt[p], a.cap), nq = min(a.nq[p], a.qcap);
     const int rule = prm.rule;
     const size_t tb = (size_t)p * a.cap, qb = (size_t)p * a.qcap;
+    const Staged S{off16, tx, ty, tmeta, tdesc, state, epi_thr, a.desc + tb * 32, desc_lds};
     const bool list_mode = a.qrange != nullptr;
     const int32_t* coff = a.cell_off + (size_t)p * (ORBF_GRID_CELLS + 1);
     const int32_t* cfeat = a.cell_feat + tb;
@@ -290,9 +304,11 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
         ty[j] = kp.y;
         tang[j] = kp.angle;
         tmeta[j] = (uint32_t)f | ((uint32_t)kp.octave << 16);
-        const uint4* d = (const uint4*)(a.desc + (tb + f) * 32);
-        tdesc[2 * j] = d[0];
-        tdesc[2 * j + 1] = d[1];
+        if (desc_lds) {
+            const uint4* d = (const uint4*)(a.desc + (tb + f) * 32);
+            tdesc[2 * j] = d[0];
+            tdesc[2 * j + 1] = d[1];
+        }
     }
     for (int i = tid; i < nt; i += GROUP) {
         state[i] = rule == ORBS_RULE_INIT ? (uint16_t)0xFFFF : (uint16_t)((a.claimed && a.claimed[tb + i]) ? 1 : 0);
@@ -558,9 +574,17 @@ static int orbs_set_lds(size_t) {
 
 extern "C" {
 
+// the layout a problem of this size gets: descriptors staged when that fits the 160 KiB of a workgroup
+static size_t orbs_choose_layout(int cap, int qcap, int& desc_in_lds) {
+    const size_t with = orbs::make_layout(cap, qcap, true).total;
+    desc_in_lds = with <= 160 * 1024;
+    return desc_in_lds ? with : orbs::make_layout(cap, qcap, false).total;
+}
+
 size_t orbs_lds_bytes(int cap, int qcap) {
     if (cap < 1 || qcap < 1) return 0;
-    return orbs::make_layout(cap, qcap).total;
+    int d;
+    return orbs_choose_layout(cap, qcap, d);
 }
 
 float orbs_epipolar_bound(float sigma2) {
@@ -587,13 +611,14 @@ int orbs_window_search_batch_device(const orbf_bounds* b, const orbs_params* prm
     if (!d_kps_un || !d_desc || !d_cell_off || !d_cell_feat || !d_nt || !d_qxyr || !d_qlev || !d_qdesc || !d_nq || !d_q2t || !d_t2q || !d_nmatches)
         return ORBX_ERR_ARG;
     if (prm->check_orientation && prm->rule != ORBS_RULE_MAPPOINTS && !d_qangle) return ORBX_ERR_ARG;
-    const size_t lds = orbs::make_layout(cap, qcap).total;
+    int desc_in_lds = 1;
+    const size_t lds = orbs_choose_layout(cap, qcap, desc_in_lds);
     if (lds > 160 * 1024) return ORBX_ERR_CAPACITY;
     if (orbs_set_lds(lds) != ORBX_OK) return ORBX_ERR_DEVICE;
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
     orbs::Args a{d_kps_un, d_desc, d_cell_off, d_cell_feat, d_nt, d_claimed, d_qxyr, d_qlev, d_qdesc, d_qangle, d_qvalid, d_nq,
-                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
+                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, desc_in_lds, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
     hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, *b, prm2, a);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
@@ -608,13 +633,14 @@ int orbs_list_search_batch_device(const orbs_params* prm, const orbx_keypoint* d
     if (nproblems == 0) return ORBX_OK;
     if (!d_kps || !d_desc || !d_list || !d_nlist || !d_nt || !d_qrange || !d_qdesc || !d_nq || !d_q2t || !d_t2q || !d_nmatches) return ORBX_ERR_ARG;
     if (prm->check_orientation && prm->rule != ORBS_RULE_MAPPOINTS && !d_qangle) return ORBX_ERR_ARG;
-    const size_t lds = orbs::make_layout(cap, qcap).total;
+    int desc_in_lds = 1;
+    const size_t lds = orbs_choose_layout(cap, qcap, desc_in_lds);
     if (lds > 160 * 1024) return ORBX_ERR_CAPACITY;
     if (orbs_set_lds(lds) != ORBX_OK) return ORBX_ERR_DEVICE;
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
     orbs::Args a{d_kps, d_desc, nullptr, d_list, d_nt, d_claimed, nullptr, nullptr, d_qdesc, d_qangle, d_qvalid, d_nq,
-                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, d_nlist, d_qrange, d_qindex, nullptr, nullptr, {}};
+                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, desc_in_lds, d_nlist, d_qrange, d_qindex, nullptr, nullptr, {}};
     orbf_bounds nob{};
     hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, nob, prm2, a);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
@@ -631,13 +657,14 @@ int orbs_triangulation_search_batch_device(const orbs_params* prm, const float* 
     if (nproblems == 0) return ORBX_OK;
     if (!d_F12 || !d_kps2 || !d_desc2 || !d_list || !d_nlist || !d_nt || !d_qrange || !d_kps1 || !d_qdesc || !d_nq || !d_q2t || !d_t2q || !d_nmatches)
         return ORBX_ERR_ARG;
-    const size_t lds = orbs::make_layout(cap, qcap).total;
+    int desc_in_lds = 1;
+    const size_t lds = orbs_choose_layout(cap, qcap, desc_in_lds);
     if (lds > 160 * 1024) return ORBX_ERR_CAPACITY;
     if (orbs_set_lds(lds) != ORBX_OK) return ORBX_ERR_DEVICE;
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
     orbs::Args a{d_kps2, d_desc2, nullptr, d_list, d_nt, d_claimed, nullptr, nullptr, d_qdesc, nullptr, d_qvalid, d_nq,
-                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, d_nlist, d_qrange, d_qindex, d_kps1, d_F12, {}};
+                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, desc_in_lds, d_nlist, d_qrange, d_qindex, d_kps1, d_F12, {}};
     for (int i = 0; i < ORBS_MAX_LEVELS; ++i) a.epi_thr[i] = orbs_epipolar_bound(level_sigma2[i < nlevels ? i : nlevels - 1]);
     orbf_bounds nob{};
     hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, nob, prm2, a);

@@ -161,7 +161,12 @@ def test_large_frames_and_capacity():
     radius = 25.0
     problems = [_problem(200 + i, 2000, 2000, radius, crowd=(i == 1), level_mode="pm1") for i in range(2)]
     _run_batch(problems, capi.RULE_WINDOW, 100, 0.8, True, False, False, cap=2000, qcap=2000)
-    assert capi.lib().orbs_lds_bytes(2000, 2000) < 160 * 1024 < capi.lib().orbs_lds_bytes(8192, 8192)
+    # beyond ~2850 train features the descriptors stay in global memory: a 4000-feature frame (the initialisation extractor of an
+    # nFeatures = 2000 setup) is searched exactly as well, under every kind of rule
+    big = [_problem(300 + i, 4000, 3000, 20.0, crowd=(i == 1), level_mode="pm1") for i in range(2)]
+    _run_batch(big, capi.RULE_WINDOW, 100, 0.8, True, False, False, cap=4000, qcap=3000)
+    _run_batch(big, capi.RULE_INIT, 50, 0.9, True, False, False, cap=4000, qcap=3000)
+    assert max(capi.lib().orbs_lds_bytes(2000, 2000), capi.lib().orbs_lds_bytes(4000, 3000)) < 160 * 1024 < capi.lib().orbs_lds_bytes(8192, 8192)
     torch = pytest.importorskip("torch")
     z = torch.zeros(64, dtype=torch.int32, device="cuda")
     with pytest.raises(capi.OrbxError) as e:

@@ -1,28 +1,38 @@
 #!/bin/bash
 # Everything profiles/ is built from, in one go on the GPU box.  usage: tools/collect_round_artifacts.sh <name>   (-> gpurun_out/<name>, gpurun_out/<name>_pmc)
-# Order: counter passes first (profiles/traffic.json of THIS build is what bench.py reads for roofline.traffic), then the bench lines.
+# Order: counter passes first (profiles/traffic.json of THIS build — it carries the library's source hash — is what bench.py replays for the
+# VALU-issue roofline and roofline.hbm.traffic), then the bench lines.
 R=${GRAFT_REPO_ROOT:-/root/repo}; D=$R/gpurun_out/$1; mkdir -p $D; cd /tmp; export TMPDIR=/tmp
 B=1024      # bench.py's default frames per step = frames per launch of the serial command
+SER="--steps 10 --warmup 2 --no-cpu-baseline --lanes 1 --region-timing --min-seconds 0"
 # serial command (one stream, one launch per kernel over all B frames): kernel-trace stats and the two HBM counter passes
-ORBX_OVERLAP=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --lanes 1 --region-timing > $D/stats.log 2>&1
-ORBX_OVERLAP=0 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D -o fetch -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --lanes 1 --region-timing > $D/fetch.log 2>&1
-ORBX_OVERLAP=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D -o write -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --lanes 1 --region-timing > $D/write.log 2>&1
+ORBX_OVERLAP=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats -- python $R/bench.py $SER > $D/stats.log 2>&1
+ORBX_OVERLAP=0 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D -o fetch -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --lanes 1 --region-timing --min-seconds 0 > $D/fetch.log 2>&1
+ORBX_OVERLAP=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D -o write -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --lanes 1 --region-timing --min-seconds 0 > $D/write.log 2>&1
 $R/tools/run_pmc.sh $1_pmc
 python $R/tools/pmc_traffic.py $D/fetch_counter_collection.csv $D/write_counter_collection.csv $R/profiles/traffic.json $B $R/gpurun_out/$1_pmc 256 > $D/traffic.log 2>&1
 cp $R/profiles/traffic.json $D/traffic.json
+python $R/tools/pmc_table.py $R/gpurun_out/$1_pmc/a_counter_collection.csv $R/gpurun_out/$1_pmc/b_counter_collection.csv > $D/pmc_sq_counters.txt 2>&1
+python $R/tools/pmc_table.py $D/fetch_counter_collection.csv $D/write_counter_collection.csv > $D/pmc_fetch_write.txt 2>&1
 # the default command (4 lanes) under the kernel trace, then the bench lines proper
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_overlap -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $D/stats_overlap.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_overlap -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --min-seconds 0 > $D/stats_overlap.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_match -- python $R/bench.py --config match100k --steps 5 --warmup 2 --no-cpu-baseline --min-seconds 0 > $D/stats_match.log 2>&1
 cd $R
 timeout 400 python bench.py > $D/bench.json 2> $D/bench.err
 timeout 300 python bench.py --lanes 1 --no-cpu-baseline > $D/bench_one_lane.json 2>/dev/null
 timeout 300 python bench.py --region-timing --no-cpu-baseline > $D/bench_region_timing.json 2>/dev/null
-timeout 300 python bench.py --no-match --no-cpu-baseline > $D/bench_extract_only.json 2>/dev/null
-timeout 400 python bench.py --width 1920 --height 1080 --nfeatures 2000 --batch 128 --ring 256 > $D/bench_hd.json 2>/dev/null
+timeout 300 python bench.py --config vga_extract --no-cpu-baseline > $D/bench_extract_only.json 2>/dev/null
+timeout 400 python bench.py --config hd1080 > $D/bench_hd.json 2>/dev/null
 timeout 300 python bench.py --family 0 --no-cpu-baseline > $D/bench_noise.json 2>/dev/null
-timeout 200 python tools/bench_match.py > $D/match100k.txt 2>/dev/null
+timeout 300 python bench.py --config match100k > $D/bench_match100k.json 2>/dev/null
+ORBX_MATCH_MFMA=0 timeout 300 python bench.py --config match100k --no-cpu-baseline > $D/bench_match100k_popcount.json 2>/dev/null
+timeout 300 python bench.py --gpus 2 --backend gloo --share-device --no-cpu-baseline --batch 512 > $D/bench_two_ranks_one_gpu_gloo.json 2>/dev/null
 (timeout 100 python tools/bench_single_frame.py; timeout 100 python tools/bench_single_frame.py 1920 1080 2000) > $D/single_frame.txt 2>/dev/null
+timeout 100 tools/microbench/valu_rate2 > $D/valu_issue_rates2.txt 2>&1
+timeout 100 tools/microbench/mfma_valu_mix > $D/mfma_valu_mix.txt 2>&1
+timeout 100 tools/microbench/mfma_layout > $D/mfma_layout.txt 2>&1
 timeout 200 python tools/bench_kf_search.py 2>/dev/null | tail -1 > $D/kf_search.json
 timeout 300 python tools/bench_frontend.py --window 15 2>/dev/null | tail -1 > $D/frontend_w15.json
 timeout 300 python tools/bench_frontend.py 2>/dev/null | tail -1 > $D/frontend_w100.json
 ls $D | wc -l
-python -c "import json; d=json.load(open('$D/bench.json')); print(d['value'], d['ms_per_step'], d['roofline'], d['cpu_baseline']['value'])"
+python -c "import json; d=json.load(open('$D/bench.json')); print(d['value'], d['ms_per_step'], d['roofline'], d['cpu_baseline']['value'], d.get('cpu_baseline_allcores'))"
