@@ -42,6 +42,7 @@ struct orbx_extractor {
     int out1_cap = 0;
     // diagnostics
     int stop_after = -1;
+    bool no_xcd_affinity = false;     // ORBX_XCD_AFFINITY=0 at orbx_create (A/B measurements)
     StageTimer timer;
     SideStream side;
     Batch last;
@@ -144,6 +145,7 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
     h->p = *p;
     // The blur runs on a side stream next to the latency-bound selection kernels (see launch_extract);
     // ORBX_OVERLAP=0 keeps everything on one stream (cleaner per-kernel timings when profiling).
+    { const char* xa = getenv("ORBX_XCD_AFFINITY"); h->no_xcd_affinity = xa && xa[0] == '0'; }
     const char* ovl = getenv("ORBX_OVERLAP");
     if (ovl && ovl[0] == '0') { *out = h; return ORBX_OK; }
     if (hipStreamCreateWithFlags(&h->side.aux, hipStreamNonBlocking) != hipSuccess ||
@@ -205,6 +207,7 @@ int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int nfra
         memset(&b, 0, sizeof(b));
         fill_batch(h, b);
         b.nframes = std::min(h->p.max_batch, nframes - f0);
+        b.xcd_affinity = (b.nframes >= XCD_AFFINITY_MIN_FRAMES && !h->no_xcd_affinity) ? 1 : 0;
         b.img = d_imgs + (ptrdiff_t)f0 * frame_stride;
         b.img_row_stride = row_stride;
         b.img_frame_stride = frame_stride;

@@ -244,8 +244,13 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
                     const int by1 = std::min(by0 + RZ_ROWS - 1, dh - 1);
                     nr_max = std::max(nr_max, ty[by1].sy1 - ty[by0].sy0 + 1);
                 }
-                L.rz_pitch = 4 * nd_max;
+                L.rz_pitch = 4 * nd_max + 8;      // + 8: the windowed form reads three dwords from the aligned start of a lane's source window
                 L.rz_rows = nr_max;
+                // widest source window of four adjacent output pixels (a lane of k_resize): up to 8 bytes it is cut out of three
+                // aligned LDS dwords with v_alignbyte and addressed by per-lane v_perm selectors
+                int span = 1;
+                for (int x0 = 0; x0 < dw; x0 += 4) span = std::max(span, tx[std::min(x0 + 3, dw - 1)].sx1 - tx[x0].sx + 1);
+                L.rz_window = span <= 8 ? 1 : 0;
                 if (L.rz_pitch * L.rz_rows > 64 * 1024) { err = "resize tile does not fit the LDS"; return ORBX_ERR_CAPACITY; }
             }
         }

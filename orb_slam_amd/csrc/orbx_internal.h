@@ -39,6 +39,7 @@ struct LevelGeom {
     int slot_base;         // prefix of ndesired over levels (output slot of the level's first keypoint when every level is full)
     int quad_base;         // prefix of ceil(ndesired / 4) over levels: k_describe forms its waves (4 keypoints each) per level
     int tabx_off, taby_off;// offsets into the ResizeX / ResizeY tables (level >= 1)
+    int rz_window;         // k_resize: 1 = the four output pixels of a lane read at most 8 adjacent source bytes per row (windowed form)
     int rz_pitch, rz_rows; // k_resize: LDS source tile of one 256x16 output tile (bytes per row, rows), maxima over the level's tiles
     int btile_base, btiles_x, btiles_y;// blur wave tasks: 248-px strips x 32-row bands of the whole plane
     int blur_wvec;         // columns x < blur_wvec round ties-to-even (SSE2 emulation), others half-up
@@ -103,6 +104,7 @@ struct BandGeom {
 // Regions and ownership come from host tables (pyr_tab): per level k = 0 .. depth (k = 0: the source level) and tile index,
 // the first / last column (row) of the tile's region; a tile OWNS (= writes to HBM) the columns from its region start up to the
 // next tile's region start, which partitions every level.  Region starts are multiples of 4 (dword stores never straddle owners).
+constexpr int XCD_AFFINITY_MIN_FRAMES = 64;      // launch groups of at least this many frames keep a frame's workgroups on one XCD (orbx_kernels.hip: frame_item)
 constexpr int PYR_MAX_GROUPS = 4, PYR_MAX_DEPTH = 4;
 struct PyrGroup {
     int l0, depth;               // source level, number of levels produced
@@ -170,6 +172,7 @@ struct Batch {
     int32_t* out_status;      // optional [frame]
     int cap;
     int nframes;
+    int xcd_affinity;         // 1: launches renumber their blocks so that a frame's work items share one XCD (its L2)
 };
 
 // Host-side geometry builder result.

@@ -47,6 +47,29 @@ __device__ __forceinline__ int find_level(const int (&bases)[MAX_LEVELS], int id
     return level;
 }
 
+// Frame -> XCD affinity.  A launch deals its workgroups round-robin to the 8 XCDs (block b runs on XCD b % 8: observed dispatch
+// rule, used for speed only), each with its own 4 MiB L2.  In frame-major block order the workgroups of ONE frame would be spread
+// over all eight L2s, and every L2 would fetch its own copy of the 128-byte sectors that neighbouring cells, strips or keypoint
+// windows share.  With `xcd_affinity` a launch's blocks are renumbered so that all work items of frame f run on XCD f % 8:
+// block b -> (frame, item) = ((b >> 3) / per_frame * 8 + (b & 7), (b >> 3) % per_frame); the grid is rounded up to whole groups of
+// 8 frames and blocks of frames >= nframes exit.  Used from XCD_AFFINITY_MIN_FRAMES frames per launch (small launches want every
+// CU, not locality).
+__device__ __forceinline__ bool frame_item(const Batch& b, int block, int per_frame, int& frame, int& item) {
+    if (b.xcd_affinity) {
+        const int slot = block >> 3;
+        const int fr = slot / per_frame;
+        frame = fr * 8 + (block & 7);
+        item = slot - fr * per_frame;
+    } else {
+        frame = block / per_frame;
+        item = block - frame * per_frame;
+    }
+    return frame < b.nframes;
+}
+static inline int frame_item_blocks(const Batch& b, int per_frame) {
+    return (b.xcd_affinity ? (b.nframes + 7) / 8 * 8 : b.nframes) * per_frame;
+}
+
 constexpr unsigned long long UMAX_NIBBLES = 0x3689ABCDDEEEFFFFull;   // umax[v] for v = 0..15 (15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3)
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -63,6 +86,45 @@ __device__ __forceinline__ void split_px(int p, int cw, float inv_cw, int& y, in
     x = p - (int)__umul24((unsigned)y, (unsigned)cw);
 }
 
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2v as_us2v(uint32_t v) { return __builtin_bit_cast(us2v, v); }
+
+
+__device__ __forceinline__ int fast_pair_test(const uint8_t* c, int S, int v, int t) {
+    // ring offsets k=0..15 (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+    const int x0 = c[3 * S], x1 = c[3 * S + 1], x2 = c[2 * S + 2], x3 = c[S + 3], x4 = c[3], x5 = c[-S + 3], x6 = c[-2 * S + 2], x7 = c[-3 * S + 1];
+    const int x8 = c[-3 * S], x9 = c[-3 * S - 1], x10 = c[-2 * S - 2], x11 = c[-S - 3], x12 = c[-3], x13 = c[S - 3], x14 = c[2 * S - 2], x15 = c[3 * S - 1];
+    // a dark 9-arc contains one pixel of every opposite pair, so max_k min(pair) < v - t is necessary (bright: mirrored)
+    const int a = imax3(imax3(imin(x0, x8), imin(x1, x9), imin(x2, x10)), imax3(imin(x3, x11), imin(x4, x12), imin(x5, x13)), imax(imin(x6, x14), imin(x7, x15)));
+    const int bq = imin3(imin3(imax(x0, x8), imax(x1, x9), imax(x2, x10)), imin3(imax(x3, x11), imax(x4, x12), imax(x5, x13)), imin(imax(x6, x14), imax(x7, x15)));
+    return (int)(v - a > t) | (int)(bq - v > t);
+}
+
+__device__ __forceinline__ int fast_score_raw(const uint8_t* c, int S, int v, int tmin) {
+    int x[16];
+    x[0] = c[3 * S]; x[1] = c[3 * S + 1]; x[2] = c[2 * S + 2]; x[3] = c[S + 3]; x[4] = c[3]; x[5] = c[-S + 3]; x[6] = c[-2 * S + 2]; x[7] = c[-3 * S + 1];
+    x[8] = c[-3 * S]; x[9] = c[-3 * S - 1]; x[10] = c[-2 * S - 2]; x[11] = c[-S - 3]; x[12] = c[-3]; x[13] = c[S - 3]; x[14] = c[2 * S - 2]; x[15] = c[3 * S - 1];
+    int hi3[16], lo3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        hi3[k] = imax3(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+        lo3[k] = imin3(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+    }
+    int hi9[16], lo9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        hi9[k] = imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+        lo9[k] = imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+    }
+    // 16 -> 1 with three-input ops (8 instead of 16 two-input ones)
+    const int min_hi9 = imin3(imin3(imin3(hi9[0], hi9[1], hi9[2]), imin3(hi9[3], hi9[4], hi9[5]), imin3(hi9[6], hi9[7], hi9[8])),
+                              imin3(imin3(hi9[9], hi9[10], hi9[11]), imin3(hi9[12], hi9[13], hi9[14]), hi9[15]), 255);
+    const int max_lo9 = imax3(imax3(imax3(lo9[0], lo9[1], lo9[2]), imax3(lo9[3], lo9[4], lo9[5]), imax3(lo9[6], lo9[7], lo9[8])),
+                              imax3(imax3(lo9[9], lo9[10], lo9[11]), imax3(lo9[12], lo9[13], lo9[14]), lo9[15]), 0);
+    const int s = imax(v - min_hi9, max_lo9 - v) - 1;   // == OpenCV cornerScore for every corner
+    return s >= tmin ? s : 0;
+}
+
 // ------------------------------------------------------------------------------------ pyramid
 // cv::resize INTER_LINEAR 8U, level-1 -> level.  A workgroup produces a 256x4 output tile: the source
 // rectangle it needs (<= 7 rows x ~310 px) is staged in LDS with coalesced dword loads, each lane then
@@ -71,16 +133,19 @@ __device__ __forceinline__ void split_px(int p, int cw, float inv_cw, int& y, in
 // LDS source tile: L.rz_rows x L.rz_pitch bytes, the exact maximum over the level's tiles (7 KB at scale 1.2; a fixed
 // worst-case array for scale 2.5 was 31 KB and capped the kernel at 5 workgroups per CU)
 
-template <bool ALIGNED>
+template <bool ALIGNED, bool WINDOW>
 __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
     const DevGeom& g = b.g;
     const LevelGeom& L = g.lv[level];
     const int RZ_SRC_W = L.rz_pitch;
     const LevelGeom& P = g.lv[level - 1];
-    const int frame = blockIdx.z;
+    const int tiles_x = (L.w + 255) / 256, tiles_y = (L.h + RZ_ROWS - 1) / RZ_ROWS;
+    int frame, tile;
+    if (!frame_item(b, blockIdx.x, tiles_x * tiles_y, frame, tile)) return;
+    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
-    const int bx0 = blockIdx.x * 256, by0 = blockIdx.y * RZ_ROWS;
+    const int bx0 = tile_x * 256, by0 = tile_y * RZ_ROWS;
     const int bx1 = min(bx0 + 255, L.w - 1), by1 = min(by0 + RZ_ROWS - 1, L.h - 1);
     long long sstride;
     const uint8_t* src = plain_plane(b, P, level - 1, frame, sstride);
@@ -128,6 +193,57 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
     __syncthreads();
     if (dx0 >= L.w) return;
     uint8_t* dplane = b.pyr + (long long)frame * g.frame_plane_bytes + L.plane_off;
+    if (WINDOW) {
+        // Windowed form (scale factors up to ~1.7): the lane's 8 source bytes of a row lie within 8 bytes from its first tap.  Three
+        // aligned LDS dwords + two v_alignbyte bring that window into a register pair; a per-lane v_perm selector (row-invariant)
+        // builds (s[sx] | s[sx1] << 16) of each output pixel and v_dot2_u32_u16 with (a0 | a1 << 16) is the horizontal pass
+        // (D = S[sx]*a0 + S[sx+1]*a1).  A wave works on CONSECUTIVE output rows, so the lower source row of one output row is
+        // usually the upper one of the next and its horizontal results are reused (1.2 instead of 2 source rows per output row).
+        const int w0 = rx[0].sx - c0;                              // the lane's first tap inside the staged row
+        const int wa = w0 & ~3, sh = w0 & 3;
+        uint32_t sel[4], apair[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            sel[k] = (uint32_t)(rx[k].sx - c0 - w0) | 0x0C000C00u | ((uint32_t)(rx[k].sx1 - c0 - w0) << 16);     // bytes: s[sx], 0, s[sx1], 0
+            apair[k] = (uint32_t)(uint16_t)rx[k].a0 | ((uint32_t)(uint16_t)rx[k].a1 << 16);
+        }
+        auto hrow = [&](int sy, uint32_t (&d)[4]) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(s_src + (sy - r0) * RZ_SRC_W + wa);
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)sh), hi = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)sh);
+#pragma unroll
+            for (int k = 0; k < 4; k++) d[k] = __builtin_amdgcn_udot2(as_us2v(__builtin_amdgcn_perm(hi, lo, sel[k])), as_us2v(apair[k]), 0u, false);
+        };
+        constexpr int RPW = RZ_ROWS / 4;                           // consecutive output rows per wave
+        int have = -1;
+        uint32_t dprev[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+            const int dy = by0 + wave * RPW + j;
+            if (dy >= L.h) break;
+            const ResizeY ry = ty[dy];
+            uint32_t da[4], db[4];
+            if (ry.sy0 == have) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) da[k] = dprev[k];
+            } else hrow(ry.sy0, da);
+            if (ry.sy1 == ry.sy0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) db[k] = da[k];
+            } else hrow(ry.sy1, db);
+            have = ry.sy1;
+            uint32_t packed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                dprev[k] = db[k];
+                const int px = (int)(((uint32_t)(ry.b0 * (int)(da[k] >> 4)) >> 16) + ((uint32_t)(ry.b1 * (int)(db[k] >> 4)) >> 16) + 2) >> 2;
+                packed |= (uint32_t)(px & 255) << (8 * k);
+            }
+            // columns past L.w (dx0+k clamped above) land in the row padding: stride is a multiple of 64
+            *reinterpret_cast<uint32_t*>(dplane + (long long)dy * L.stride + dx0) = packed;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < RZ_ROWS / 4; j++) {
         const int dy = by0 + wave + 4 * j;
@@ -144,45 +260,6 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
         // columns past L.w (dx0+k clamped above) land in the row padding: stride is a multiple of 64
         *reinterpret_cast<uint32_t*>(dplane + (long long)dy * L.stride + dx0) = packed;
     }
-}
-
-typedef unsigned short us2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ us2v as_us2v(uint32_t v) { return __builtin_bit_cast(us2v, v); }
-
-
-__device__ __forceinline__ int fast_pair_test(const uint8_t* c, int S, int v, int t) {
-    // ring offsets k=0..15 (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-    const int x0 = c[3 * S], x1 = c[3 * S + 1], x2 = c[2 * S + 2], x3 = c[S + 3], x4 = c[3], x5 = c[-S + 3], x6 = c[-2 * S + 2], x7 = c[-3 * S + 1];
-    const int x8 = c[-3 * S], x9 = c[-3 * S - 1], x10 = c[-2 * S - 2], x11 = c[-S - 3], x12 = c[-3], x13 = c[S - 3], x14 = c[2 * S - 2], x15 = c[3 * S - 1];
-    // a dark 9-arc contains one pixel of every opposite pair, so max_k min(pair) < v - t is necessary (bright: mirrored)
-    const int a = imax3(imax3(imin(x0, x8), imin(x1, x9), imin(x2, x10)), imax3(imin(x3, x11), imin(x4, x12), imin(x5, x13)), imax(imin(x6, x14), imin(x7, x15)));
-    const int bq = imin3(imin3(imax(x0, x8), imax(x1, x9), imax(x2, x10)), imin3(imax(x3, x11), imax(x4, x12), imax(x5, x13)), imin(imax(x6, x14), imax(x7, x15)));
-    return (int)(v - a > t) | (int)(bq - v > t);
-}
-
-__device__ __forceinline__ int fast_score_raw(const uint8_t* c, int S, int v, int tmin) {
-    int x[16];
-    x[0] = c[3 * S]; x[1] = c[3 * S + 1]; x[2] = c[2 * S + 2]; x[3] = c[S + 3]; x[4] = c[3]; x[5] = c[-S + 3]; x[6] = c[-2 * S + 2]; x[7] = c[-3 * S + 1];
-    x[8] = c[-3 * S]; x[9] = c[-3 * S - 1]; x[10] = c[-2 * S - 2]; x[11] = c[-S - 3]; x[12] = c[-3]; x[13] = c[S - 3]; x[14] = c[2 * S - 2]; x[15] = c[3 * S - 1];
-    int hi3[16], lo3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        hi3[k] = imax3(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
-        lo3[k] = imin3(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
-    }
-    int hi9[16], lo9[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        hi9[k] = imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
-        lo9[k] = imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
-    }
-    // 16 -> 1 with three-input ops (8 instead of 16 two-input ones)
-    const int min_hi9 = imin3(imin3(imin3(hi9[0], hi9[1], hi9[2]), imin3(hi9[3], hi9[4], hi9[5]), imin3(hi9[6], hi9[7], hi9[8])),
-                              imin3(imin3(hi9[9], hi9[10], hi9[11]), imin3(hi9[12], hi9[13], hi9[14]), hi9[15]), 255);
-    const int max_lo9 = imax3(imax3(imax3(lo9[0], lo9[1], lo9[2]), imax3(lo9[3], lo9[4], lo9[5]), imax3(lo9[6], lo9[7], lo9[8])),
-                              imax3(imax3(lo9[9], lo9[10], lo9[11]), imax3(lo9[12], lo9[13], lo9[14]), lo9[15]), 0);
-    const int s = imax(v - min_hi9, max_lo9 - v) - 1;   // == OpenCV cornerScore for every corner
-    return s >= tmin ? s : 0;
 }
 
 // Fused pyramid: one launch produces the levels l0+1 .. l0+depth of a PyrGroup (round 2: 2 launches for 8 levels instead of 7
@@ -316,8 +393,8 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
     constexpr int Q0CAP = fast_q0cap(PPT), Q1CAP = FAST_Q1CAP, Q2CAP = FAST_Q2CAP, Q3CAP = FAST_Q3CAP;
     constexpr int WQ_BYTES = fast_wave_queue_bytes(PPT);
     const DevGeom& g = b.g;
-    const int frame = task / g.nbands_total;
-    const int item = task - frame * g.nbands_total;
+    int frame, item;
+    if (!frame_item(b, task, g.nbands_total, frame, item)) return;
     const BandGeom bg = b.bands[item];
     const int level = bg.level;
     const LevelGeom& L = g.lv[level];
@@ -909,10 +986,11 @@ __device__ __forceinline__ uint32_t load_px4_reflect(const uint8_t* row, int x, 
 template <bool ALIGNED>
 __global__ __launch_bounds__(BLUR_WAVES * 64) void k_blur(Batch b) {
     const DevGeom& g = b.g;
-    const int task_all = blockIdx.x * BLUR_WAVES + wave_id();
-    const int frame = task_all / g.nbtiles_total;
-    if (frame >= b.nframes) return;
-    const int t = task_all - frame * g.nbtiles_total;
+    const int wgs_per_frame = (g.nbtiles_total + BLUR_WAVES - 1) / BLUR_WAVES;
+    int frame, wgi;
+    if (!frame_item(b, blockIdx.x, wgs_per_frame, frame, wgi)) return;
+    const int t = wgi * BLUR_WAVES + wave_id();
+    if (t >= g.nbtiles_total) return;
     const int level = find_level(g.btile_bases, t);
     const LevelGeom& L = g.lv[level];
     const int tl = t - L.btile_base;
@@ -1011,7 +1089,8 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
     __shared__ uint32_t s_mask[256];                                   // circle byte masks of the 31 x 8 patch dwords (slots 248.. = 0)
     __shared__ __attribute__((aligned(16))) uint8_t s_win[DESC_WAVES * DESC_KPW * DESC_WIN_BYTES];   // per keypoint: 37 rows x 40 bytes of the blurred level
     const DevGeom& g = b.g;
-    const int frame = blockIdx.y;
+    int frame, wgi;
+    if (!frame_item(b, blockIdx.x, (g.nquads + DESC_WAVES - 1) / DESC_WAVES, frame, wgi)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int grp = lane >> 4, li = lane & 15;
     const int32_t* counts = b.level_count + frame * MAX_LEVELS;
@@ -1031,7 +1110,7 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
         s_mask[t] = mask;
     }
     __syncthreads();
-    const int quad = blockIdx.x * DESC_WAVES + wave_id();
+    const int quad = wgi * DESC_WAVES + wave_id();
     if (quad == 0 && lane == 0) {
         int total = 0;
         for (int l = 0; l < g.nlevels; l++) total += counts[l];
@@ -1226,11 +1305,16 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         } else {
             for (int l = 1; l < g.nlevels; l++) {
                 const LevelGeom& L = g.lv[l];
-                dim3 grid((L.w + 255) / 256, (L.h + RZ_ROWS - 1) / RZ_ROWS, F);
+                dim3 grid(frame_item_blocks(b, ((L.w + 255) / 256) * ((L.h + RZ_ROWS - 1) / RZ_ROWS)));
                 const bool al = l > 1 || al0;
                 const size_t lds = (size_t)L.rz_pitch * L.rz_rows;
-                if (al) hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), lds, stream, b, l);
-                else hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), lds, stream, b, l);
+                if (L.rz_window) {
+                    if (al) hipLaunchKernelGGL((k_resize<true, true>), grid, dim3(256), lds, stream, b, l);
+                    else hipLaunchKernelGGL((k_resize<false, true>), grid, dim3(256), lds, stream, b, l);
+                } else {
+                    if (al) hipLaunchKernelGGL((k_resize<true, false>), grid, dim3(256), lds, stream, b, l);
+                    else hipLaunchKernelGGL((k_resize<false, false>), grid, dim3(256), lds, stream, b, l);
+                }
                 ORBX_LAUNCH_CHECK();
             }
         }
@@ -1239,7 +1323,7 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     auto launch_blur = [&](hipStream_t st) -> int {
         StageScope sc(timer, st, ST_BLUR);
         const bool aligned = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
-        const int nblk = (F * g.nbtiles_total + BLUR_WAVES - 1) / BLUR_WAVES;
+        const int nblk = frame_item_blocks(b, (g.nbtiles_total + BLUR_WAVES - 1) / BLUR_WAVES);
         if (aligned) hipLaunchKernelGGL(k_blur<true>, dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);
         else hipLaunchKernelGGL(k_blur<false>, dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);
         ORBX_LAUNCH_CHECK();
@@ -1252,7 +1336,7 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         const size_t lds = (size_t)g.fast_lds_bytes;
         auto launch = [&](auto kern, int threads) -> bool {
             if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-            hipLaunchKernelGGL(kern, dim3(F * g.nbands_total), dim3(threads), lds, stream, b);
+            hipLaunchKernelGGL(kern, dim3(frame_item_blocks(b, g.nbands_total)), dim3(threads), lds, stream, b);
             return true;
         };
         constexpr FastShape A = FAST_SMALL, B = FAST_LARGE;
@@ -1300,7 +1384,7 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     if (stop_after == ST_BLUR) return ORBX_OK;
     {
         StageScope sc(timer, stream, ST_DESCRIBE);
-        hipLaunchKernelGGL(k_describe, dim3((g.nquads + DESC_WAVES - 1) / DESC_WAVES, F), dim3(DESC_WAVES * 64), 0, stream, b);
+        hipLaunchKernelGGL(k_describe, dim3(frame_item_blocks(b, (g.nquads + DESC_WAVES - 1) / DESC_WAVES)), dim3(DESC_WAVES * 64), 0, stream, b);
         ORBX_LAUNCH_CHECK();
     }
     return ORBX_OK;

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes as the TCC
-block cannot hold both).  Per-launch HBM-side bytes per kernel = (FETCH_SIZE + WRITE_SIZE) * 1024 (the counters are
-in KiB).  gfx950 note (MI355X_MICROARCH.md §HBM): FETCH_SIZE under-counts 16 B/lane streaming reads by 2x; our
-kernels read 4 B/lane (dword) or 1 B/lane, for which the guide gives no correction, so the raw value is reported
-and `read_correction` records that no factor was applied."""
+block cannot hold both).  Per-launch HBM-side bytes per kernel = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (the counters are
+in KiB).  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half the bytes of a streaming read.  Calibrated
+here for the access widths of these kernels (tools/microbench/fetch_calib, profiles/r02_fetch_calibration.txt): coalesced
+1, 4 and 16 B-per-lane reads of 1 GiB all report exactly 0.500; WRITE_SIZE is exact (1.000); 32-byte runs 640 B apart (a
+keypoint patch row) report the 64-byte lines they touch (2.0 x the unique bytes).  So reads are doubled for every kernel;
+for the gather-like loads of k_describe that is an upper bound.  Raw counters are kept in `detail`."""
 import csv, json, os, re, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from orb_slam_amd import capi
@@ -24,8 +26,8 @@ for k, stage in STAGE.items():
     n_per_step = 7 if k == "k_resize" else 1          # the pyramid stage is 7 launches per step
     fb = sum(f[k]) / len(f[k]) * 1024 * n_per_step
     wb = sum(w[k]) / len(w[k]) * 1024 * n_per_step if k in w else 0.0
-    per_launch[stage] = int(fb + wb)
-    detail[stage] = {"fetch_bytes": int(fb), "write_bytes": int(wb), "dispatches_sampled": len(f[k])}
+    per_launch[stage] = int(2 * fb + wb)
+    detail[stage] = {"fetch_bytes_raw": int(fb), "fetch_bytes_corrected": int(2 * fb), "write_bytes": int(wb), "dispatches_sampled": len(f[k])}
 # optional: VALU / LDS activity from the SQ counter passes of tools/run_pmc.sh (argv[5] = directory with a_*/b_* CSVs)
 valu = {}
 if len(sys.argv) > 5:
@@ -53,6 +55,6 @@ if len(sys.argv) > 5:
         per_frame = {STAGE[k]: round(sum(v) / frames, 1) for k, v in insts.items() if k in STAGE}
 json.dump({"workload": "vga_640x480_nf1000", "src_hash": capi.build_id(), "batch": batch, "sq_activity": valu, "valu_wave_insts_per_frame": per_frame,
            "per_launch_bytes": per_launch, "detail": detail,
-           "read_correction": "none applied (4 B/lane and 1 B/lane accesses; the guide's x2 applies to 16 B/lane reads)",
+           "read_correction": "FETCH_SIZE x 2 (gfx950: streaming reads of 1, 4 and 16 B per lane all report exactly half, tools/microbench/fetch_calib); WRITE_SIZE as is",
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py"}, open(out, "w"), indent=1)
 print(json.dumps(per_launch))
