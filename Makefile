@@ -9,7 +9,7 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -ffp-contract=off -mll
 ORBX_SRCS  := $(wildcard orb_slam_amd/csrc/*.hip)
 ORBX_HDRS  := $(wildcard orb_slam_amd/csrc/*.h orb_slam_amd/csrc/*.inc include/*.h)
 
-all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so oracle_ref orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/cpp/example_lanes tools/microbench/valu_rate tools/microbench/valu_rate2
+all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so oracle_ref orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/cpp/example_lanes orb_slam_amd/cpp/bench_single_frame tools/microbench/valu_rate tools/microbench/valu_rate2 tools/microbench/mfma_layout tools/microbench/mfma_valu_mix tools/microbench/fetch_calib
 
 # the hash of the kernel sources travels inside the library (orbx_build_id): counters replayed by bench.py must come from THIS build
 SRC_HASH   := $(shell cat $(sort $(ORBX_SRCS) $(ORBX_HDRS)) | sha256sum | cut -c1-16)
@@ -39,14 +39,24 @@ orb_slam_amd/cpp/example_pipeline: orb_slam_amd/cpp/example_pipeline.cpp include
 orb_slam_amd/cpp/example_lanes: orb_slam_amd/cpp/example_lanes.cpp orb_slam_amd/cpp/LanePipeline.h include/orbx.h orb_slam_amd/liborbx.so
 	$(CXX) -O2 -std=c++14 -Iinclude -Iorb_slam_amd/cpp $< -o $@ -Lorb_slam_amd -lorbx -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
 
+# the drop-in call's latency from plain C++
+orb_slam_amd/cpp/bench_single_frame: orb_slam_amd/cpp/bench_single_frame.cpp include/orbx.h orb_slam_amd/liborbx.so
+	$(CXX) -O2 -std=c++14 -Iinclude $< -o $@ -Lorb_slam_amd -lorbx -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
+
 # measurement aid: issue rate of the VALU opcodes the kernels are made of (profiles/r01_valu_issue_rates.txt)
 tools/microbench/valu_rate: tools/microbench/valu_rate.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value $< -o $@
 tools/microbench/valu_rate2: tools/microbench/valu_rate2.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value $< -o $@
+tools/microbench/mfma_layout: tools/microbench/mfma_layout.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result $< -o $@
+tools/microbench/mfma_valu_mix: tools/microbench/mfma_valu_mix.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result $< -o $@
+tools/microbench/fetch_calib: tools/microbench/fetch_calib.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result $< -o $@
 
 clean:
-	rm -f tools/microbench/valu_rate tools/microbench/valu_rate2 orb_slam_amd/cpp/example_lanes orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
+	rm -f tools/microbench/valu_rate tools/microbench/valu_rate2 tools/microbench/mfma_layout tools/microbench/mfma_valu_mix tools/microbench/fetch_calib orb_slam_amd/cpp/bench_single_frame orb_slam_amd/cpp/example_lanes orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
 	rm -rf oracle/_ref
 
 .PHONY: all clean oracle_ref

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) void k_pyramid(Batch b, int group) {
     const int frame = blockIdx.z, ix = blockIdx.x, iy = blockIdx.y;
     const int tid = threadIdx.x;
     const int l0 = pg.l0, depth = pg.depth;
+    if (group == 0 && ix == 0 && iy == 0 && tid == 0) b.status[frame] = ORBX_OK;     // (the selection stage may set an error later)
     const int* xt = b.pyr_tab + pg.xtab;
     const int* yt = b.pyr_tab + pg.ytab;
     auto xr = [&](int k, int i, int e) { return xt[(k * (pg.ntx + 1) + i) * 2 + e]; };
@@ -678,62 +679,76 @@ __global__ __launch_bounds__(NT) void k_fast_cells(Batch b) {
 // runs the reference's (inherently sequential) redistribution loop on the LDS copy, the lanes write the result back.
 constexpr int QUOTA_MAX_CELLS = 1024;   // checked on the host
 
-__global__ __launch_bounds__(64) void k_quota(Batch b) {
-    __shared__ int s_nkeys[QUOTA_MAX_CELLS], s_nret[QUOTA_MAX_CELLS], s_off[QUOTA_MAX_CELLS];
-    __shared__ uint8_t s_thr[QUOTA_MAX_CELLS], s_done[QUOTA_MAX_CELLS], s_skip[QUOTA_MAX_CELLS];
-    __shared__ int s_total;
+struct QuotaLds {
+    int nkeys[QUOTA_MAX_CELLS], nret[QUOTA_MAX_CELLS], off[QUOTA_MAX_CELLS];
+    uint8_t thr[QUOTA_MAX_CELLS], done[QUOTA_MAX_CELLS], skip[QUOTA_MAX_CELLS];
+    int total;
+};
+
+// one wave (lanes 0..63 of the calling workgroup's first wave); `sync` = the barrier between the phases (a wave-level fence when the
+// wave is alone, __syncthreads when other waves of the workgroup wait for the result)
+template <typename Sync>
+__device__ __forceinline__ void quota_body(const Batch& b, int frame, int level, int lane, bool active, QuotaLds& q, Sync sync) {
     const DevGeom& g = b.g;
-    const int frame = blockIdx.x / g.nlevels, level = blockIdx.x - frame * g.nlevels;
-    const int lane = threadIdx.x;
     const LevelGeom& L = g.lv[level];
     const CellGeom* cg = b.cells + L.cell_base;
     const CellState* cs = b.cstate + (long long)frame * g.nbands_total;   // per band; a cell sums its bands
     CellSel* sel = b.csel + (long long)frame * g.ncells_total + L.cell_base;
     const int nCells = L.ncells, nfc = L.nfeat_cell;
-    for (int c = lane; c < nCells; c += 64) {
-        const CellGeom cgc = cg[c];
-        int n_hi = 0, n_lo = 0;
-        for (int k = 0; k < cgc.nbands; k++) { const CellState t = cs[cgc.band0 + k]; n_hi += t.n_hi; n_lo += t.n_lo; }
-        const bool fallback = n_hi <= 3;                      // :609  size()<=3 -> FAST(...,7,...)
-        s_skip[c] = (uint8_t)cgc.skipped;
-        s_thr[c] = (uint8_t)(cgc.skipped || !fallback ? g.fast_th : 7);
-        s_nkeys[c] = cgc.skipped ? 0 : (fallback ? n_lo : n_hi);
-    }
-    __syncthreads();
-    if (lane == 0) {
+    if (active)
+        for (int c = lane; c < nCells; c += 64) {
+            const CellGeom cgc = cg[c];
+            int n_hi = 0, n_lo = 0;
+            for (int k = 0; k < cgc.nbands; k++) { const CellState t = cs[cgc.band0 + k]; n_hi += t.n_hi; n_lo += t.n_lo; }
+            const bool fallback = n_hi <= 3;                      // :609  size()<=3 -> FAST(...,7,...)
+            q.skip[c] = (uint8_t)cgc.skipped;
+            q.thr[c] = (uint8_t)(cgc.skipped || !fallback ? g.fast_th : 7);
+            q.nkeys[c] = cgc.skipped ? 0 : (fallback ? n_lo : n_hi);
+        }
+    sync();
+    if (active && lane == 0) {
         int nToDistribute = 0, nNoMore = 0;
         for (int c = 0; c < nCells; c++) {
-            if (s_skip[c]) { s_nret[c] = 0; s_done[c] = 0; continue; }   // reference `continue`: never reaches the bookkeeping
-            const int nk = s_nkeys[c];
-            if (nk > nfc) { s_nret[c] = nfc; s_done[c] = 0; }
-            else { s_nret[c] = nk; nToDistribute += nfc - nk; s_done[c] = 1; nNoMore++; }
+            if (q.skip[c]) { q.nret[c] = 0; q.done[c] = 0; continue; }   // reference `continue`: never reaches the bookkeeping
+            const int nk = q.nkeys[c];
+            if (nk > nfc) { q.nret[c] = nfc; q.done[c] = 0; }
+            else { q.nret[c] = nk; nToDistribute += nfc - nk; q.done[c] = 1; nNoMore++; }
         }
         while (nToDistribute > 0 && nNoMore < nCells) {
             const int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nCells - nNoMore));
             nToDistribute = 0;
             for (int c = 0; c < nCells; c++) {
-                if (!s_done[c]) {
-                    const int nk = s_nkeys[c];
-                    if (nk > nNew) { s_nret[c] = nNew; }
-                    else { s_nret[c] = nk; nToDistribute += nNew - nk; s_done[c] = 1; nNoMore++; }
+                if (!q.done[c]) {
+                    const int nk = q.nkeys[c];
+                    if (nk > nNew) { q.nret[c] = nNew; }
+                    else { q.nret[c] = nk; nToDistribute += nNew - nk; q.done[c] = 1; nNoMore++; }
                 }
             }
         }
         int off = 0;
-        for (int c = 0; c < nCells; c++) { s_off[c] = off; off += s_nret[c]; }
+        for (int c = 0; c < nCells; c++) { q.off[c] = off; off += q.nret[c]; }
         if (off > L.sel_cap) { b.status[frame] = ORBX_ERR_CAPACITY; off = -1; }
-        s_total = off;
+        q.total = off;
         b.level_total[frame * MAX_LEVELS + level] = off < 0 ? 0 : off;
     }
-    __syncthreads();
-    const bool bad = s_total < 0;
-    for (int c = lane; c < nCells; c += 64) {
-        CellSel r;
-        r.thr = s_thr[c]; r.nkeys = s_nkeys[c];
-        r.nretain = bad ? 0 : s_nret[c];
-        r.out_off = bad ? 0 : s_off[c];
-        sel[c] = r;
+    sync();
+    if (active) {
+        const bool bad = q.total < 0;
+        for (int c = lane; c < nCells; c += 64) {
+            CellSel r;
+            r.thr = q.thr[c]; r.nkeys = q.nkeys[c];
+            r.nretain = bad ? 0 : q.nret[c];
+            r.out_off = bad ? 0 : q.off[c];
+            sel[c] = r;
+        }
     }
+}
+
+__global__ __launch_bounds__(64) void k_quota(Batch b) {
+    __shared__ QuotaLds q;
+    const DevGeom& g = b.g;
+    const int frame = blockIdx.x / g.nlevels, level = blockIdx.x - frame * g.nlevels;
+    quota_body(b, frame, level, (int)threadIdx.x, true, q, [] { __syncthreads(); });
 }
 
 // ------------------------------------------------------------------------------------ retainBest per cell
@@ -847,16 +862,13 @@ __device__ float harris_response(const uint8_t* img, long long step, int x, int 
 // Launched twice: lists of up to SEL_SMALL entries with a small LDS footprint (many waves per CU — the common case),
 // longer ones with the full staging area; each launch skips the cells of the other class.
 constexpr int SEL_SMALL = 384;
-__global__ __launch_bounds__(64) void k_cell_select(Batch b, int lds_entries, int min_entries) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// one wave; returns false when the cell's list belongs to the other length class (it did nothing)
+__device__ __forceinline__ bool cell_select_body(const Batch& b, int frame, int cell, int level, uint8_t* smem, int lds_entries, int min_entries, int lane) {
     const DevGeom& g = b.g;
-    const int frame = blockIdx.x / g.ncells_total, cell = blockIdx.x - frame * g.ncells_total;
-    const int level = find_level(g.cell_bases, cell);
     const LevelGeom& L = g.lv[level];
     const CellGeom cgeo = b.cells[cell];
     const CellSel s = b.csel[(long long)frame * g.ncells_total + cell];
-    if (s.nretain <= 0) return;
-    const int lane = threadIdx.x;
+    if (s.nretain <= 0) return true;
     // the cell's list = its bands' sub-lists in band (= raster) order
     const CellState* bst = b.cstate + (long long)frame * g.nbands_total + cgeo.band0;
     const BandGeom* bgs = b.bands + cgeo.band0;
@@ -864,7 +876,7 @@ __global__ __launch_bounds__(64) void k_cell_select(Batch b, int lds_entries, in
     Cand* c = lbase + cgeo.cand_off;
     int n_all = 0;
     for (int k = 0; k < cgeo.nbands; k++) n_all += bst[k].n_all;
-    if (n_all < min_entries || (n_all > lds_entries && lds_entries < g.sel_lds_entries)) return;   // the other launch's class
+    if (n_all < min_entries || (n_all > lds_entries && lds_entries < g.sel_lds_entries)) return false;   // the other class
     Cand* out = b.sel + (long long)frame * g.frame_sel + L.sel_base + s.out_off;
     const float thr = (float)s.thr;
     long long stride;
@@ -885,7 +897,7 @@ __global__ __launch_bounds__(64) void k_cell_select(Batch b, int lds_entries, in
             const int keep = min(m, s.nretain);
             for (int i = 0; i < keep; i++) out[i] = c[i];
         }
-        return;
+        return true;
     }
     Cand* lst = reinterpret_cast<Cand*>(smem);
     uint16_t* lpos = reinterpret_cast<uint16_t*>(smem + (size_t)lds_entries * sizeof(Cand));
@@ -914,15 +926,20 @@ __global__ __launch_bounds__(64) void k_cell_select(Batch b, int lds_entries, in
     if (m > s.nretain) wave_nth_element(lst, 0, s.nretain, m, lpos, rpos, lane);
     const int keep = min(m, s.nretain);
     for (int i = lane; i < keep; i += 64) out[i] = lst[i];
+    return true;
 }
 
-// reference :697-701 (per-level cap), same scheme
-__global__ __launch_bounds__(64) void k_level_select(Batch b) {
+__global__ __launch_bounds__(64) void k_cell_select(Batch b, int lds_entries, int min_entries) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const DevGeom& g = b.g;
-    const int frame = blockIdx.x / g.nlevels, level = blockIdx.x - frame * g.nlevels;
+    const int frame = blockIdx.x / g.ncells_total, cell = blockIdx.x - frame * g.ncells_total;
+    (void)cell_select_body(b, frame, cell, find_level(g.cell_bases, cell), smem, lds_entries, min_entries, (int)threadIdx.x);
+}
+
+// reference :697-701 (per-level cap), same scheme; one wave
+__device__ __forceinline__ void level_select_body(const Batch& b, int frame, int level, uint8_t* smem, int lane) {
+    const DevGeom& g = b.g;
     const LevelGeom& L = g.lv[level];
-    const int lane = threadIdx.x;
     const int total = b.level_total[frame * MAX_LEVELS + level];
     int n = total;
     if (total > L.ndesired) {
@@ -943,6 +960,13 @@ __global__ __launch_bounds__(64) void k_level_select(Batch b) {
         }
     }
     if (lane == 0) b.level_count[frame * MAX_LEVELS + level] = n;
+}
+
+__global__ __launch_bounds__(64) void k_level_select(Batch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const DevGeom& g = b.g;
+    const int frame = blockIdx.x / g.nlevels, level = blockIdx.x - frame * g.nlevels;
+    level_select_body(b, frame, level, smem, (int)threadIdx.x);
 }
 
 // diagnostics: wave_nth_element on a caller-supplied response list (pos carries the original index)
@@ -1286,14 +1310,16 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     const DevGeom& g = hg.g;
     const int F = b.nframes;
     if (F <= 0) return ORBX_OK;
-    if (hipMemsetAsync(b.status, 0, sizeof(int32_t) * F, stream) != hipSuccess) return ORBX_ERR_DEVICE;
+    const bool fused_pyramid = g.npyr_groups > 0 && F < PYR_FUSED_MAX_FRAMES;
+    // per-frame status starts at ORBX_OK: a fill launch for full batches, folded into the first k_pyramid launch otherwise
+    if (!fused_pyramid && hipMemsetAsync(b.status, 0, sizeof(int32_t) * F, stream) != hipSuccess) return ORBX_ERR_DEVICE;
     {
         StageScope sc(timer, stream, ST_PYRAMID);
         const bool al0 = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
         // Fused launches when the batch is too small to fill the chip (the drop-in call: one frame): there the chain of dependent
         // launches is the cost (189 vs 236 us per VGA frame); a full batch prefers the leaner per-level kernels (0.72 vs 0.81 ms per 1024
         // frames: the cones recompute their overlap and synchronise per level).
-        if (g.npyr_groups > 0 && F < PYR_FUSED_MAX_FRAMES) {
+        if (fused_pyramid) {
             for (int gi = 0; gi < g.npyr_groups; gi++) {
                 const PyrGroup& pg = g.pyr[gi];
                 const bool al = pg.l0 > 0 || al0;
@@ -1363,7 +1389,9 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         StageScope sc(timer, stream, ST_CELL_SELECT);
         const size_t lds = (size_t)g.sel_lds_cell;
         if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cell_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ORBX_ERR_DEVICE;
-        const int small = std::min(SEL_SMALL, g.sel_lds_entries);
+        // two launches by list length (short lists with a small LDS footprint: many waves per CU); a launch group too small to fill
+        // the chip takes ONE launch with the full staging area instead (a dependent launch costs more than the occupancy gains)
+        const int small = F < PYR_FUSED_MAX_FRAMES ? g.sel_lds_entries : std::min(SEL_SMALL, g.sel_lds_entries);
         hipLaunchKernelGGL(k_cell_select, dim3(F * g.ncells_total), dim3(64), (size_t)small * (sizeof(Cand) + 4) + 16, stream, b, small, 0);
         ORBX_LAUNCH_CHECK();
         if (small < g.sel_lds_entries) hipLaunchKernelGGL(k_cell_select, dim3(F * g.ncells_total), dim3(64), lds, stream, b, g.sel_lds_entries, small + 1);
