@@ -356,3 +356,30 @@ def test_large_batch_takes_the_per_level_pyramid(gpu_extractor_factory, unaligne
             assert n[f] == len(ok), (max_batch, f)
             _assert_kps_equal(kps[f, :n[f]].copy().view(capi.KP_DTYPE).reshape(-1), ok)
             np.testing.assert_array_equal(desc[f, :n[f]], od)
+
+
+def test_xcd_affinity_block_renumbering(gpu_extractor_factory):
+    """launch groups of >= 64 frames renumber their blocks (a frame's workgroups share one XCD): 70 frames — not a multiple of
+    8, so the last group of eight is incomplete — against the oracle, plus a second call reusing the handle with 64 frames"""
+    torch = pytest.importorskip("torch")
+    B, w, h, nf = 70, 322, 246, 300
+    frames = np.concatenate([synth.frames(w, h, synth.BLOCKS, 900, 50), synth.frames(w, h, synth.NOISE, 950, 12), synth.frames(w, h, synth.LOWTEX, 980, 8)])
+    o = orc.OracleExtractor(nfeatures=nf)
+    want = [o(frames[f]) for f in range(B)]
+    ex = gpu_extractor_factory(nfeatures=nf, max_batch=B)
+    cap = ex.max_keypoints
+    d_img = torch.from_numpy(frames).cuda()
+    for nb in (B, 64):
+        d_kps = torch.zeros((nb, cap, 7), dtype=torch.float32, device="cuda")
+        d_desc = torch.zeros((nb, cap, 32), dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        ex.extract_batch_device(d_img.data_ptr(), nb, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        n = d_n.cpu().numpy()
+        kps = d_kps.cpu().numpy().view(np.uint8).reshape(nb, cap, 28)
+        desc = d_desc.cpu().numpy()
+        for f in range(nb):
+            ok, od = want[f]
+            assert n[f] == len(ok), (nb, f)
+            _assert_kps_equal(kps[f, :n[f]].copy().view(capi.KP_DTYPE).reshape(-1), ok)
+            np.testing.assert_array_equal(desc[f, :n[f]], od)

@@ -27,7 +27,7 @@ timeout 300 python bench.py --family 0 --no-cpu-baseline > $D/bench_noise.json 2
 timeout 300 python bench.py --config match100k > $D/bench_match100k.json 2>/dev/null
 ORBX_MATCH_MFMA=0 timeout 300 python bench.py --config match100k --no-cpu-baseline > $D/bench_match100k_popcount.json 2>/dev/null
 timeout 300 python bench.py --gpus 2 --backend gloo --share-device --no-cpu-baseline --batch 512 > $D/bench_two_ranks_one_gpu_gloo.json 2>/dev/null
-(timeout 100 python tools/bench_single_frame.py; timeout 100 python tools/bench_single_frame.py 1920 1080 2000) > $D/single_frame.txt 2>/dev/null
+(timeout 100 python tools/bench_single_frame.py; timeout 100 python tools/bench_single_frame.py 1920 1080 2000; timeout 100 orb_slam_amd/cpp/bench_single_frame; timeout 100 orb_slam_amd/cpp/bench_single_frame 1920 1080 2000) > $D/single_frame.txt 2>/dev/null
 timeout 100 tools/microbench/valu_rate2 > $D/valu_issue_rates2.txt 2>&1
 timeout 100 tools/microbench/mfma_valu_mix > $D/mfma_valu_mix.txt 2>&1
 timeout 100 tools/microbench/mfma_layout > $D/mfma_layout.txt 2>&1
