@@ -10,6 +10,7 @@ namespace orbx {
 int launch_eval_math(int kind, const float* in0, const float* in1, float* out0, float* out1, int n);
 void stage_timer_collect(StageTimer& t);
 int launch_debug_nth(const float* d_resp, int n, int nth, int* d_out);
+int launch_ingest(uint8_t* d_dst, const uint8_t* mapped_src, size_t bytes, hipStream_t stream);
 }
 using namespace orbx;
 
@@ -35,8 +36,11 @@ struct orbx_extractor {
     size_t img1_bytes = 0;
     int img1_stride = 0;
     uint8_t* d_out1 = nullptr;   // one block: [n, status, pad to 64 B][kps: cap x 28 B, padded to 64][desc: cap x 32 B]
-    uint8_t* h_out1 = nullptr;   // pinned mirror of d_out1 (one D2H copy per frame)
-    uint8_t* h_img1 = nullptr;   // pinned staging of the input frame
+    uint8_t* h_out1 = nullptr;   // the same block in pinned host memory, mapped into the device: k_describe writes the results there
+    uint8_t* m_out1 = nullptr;   //   (its device address); d_out1 + one D2H copy only with ORBX_ZERO_COPY=0
+    uint8_t* h_img1 = nullptr;   // pinned staging of the input frame, mapped into the device (m_img1): fetched by k_ingest
+    uint8_t* m_img1 = nullptr;
+    bool zero_copy = true;       // ORBX_ZERO_COPY=0 at orbx_create: DMA copies both ways instead (A/B measurements)
     hipStream_t s1 = nullptr;    // stream of the single-frame path
     size_t out1_bytes = 0, kps1_off = 0, desc1_off = 0;
     int out1_cap = 0;
@@ -146,6 +150,7 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
     // The blur runs on a side stream next to the latency-bound selection kernels (see launch_extract);
     // ORBX_OVERLAP=0 keeps everything on one stream (cleaner per-kernel timings when profiling).
     { const char* xa = getenv("ORBX_XCD_AFFINITY"); h->no_xcd_affinity = xa && xa[0] == '0'; }
+    { const char* zc = getenv("ORBX_ZERO_COPY"); h->zero_copy = !(zc && zc[0] == '0'); }
     const char* ovl = getenv("ORBX_OVERLAP");
     if (ovl && ovl[0] == '0') { *out = h; return ORBX_OK; }
     if (hipStreamCreateWithFlags(&h->side.aux, hipStreamNonBlocking) != hipSuccess ||
@@ -241,7 +246,8 @@ int orbx_extract(orbx_extractor* h, const uint8_t* img, int w, int hgt, ptrdiff_
         if (h->h_img1) (void)hipHostFree(h->h_img1);
         h->h_img1 = nullptr;
         HIPCHK(h, hipMalloc(&h->d_img1, bytes));
-        HIPCHK(h, hipHostMalloc(&h->h_img1, bytes, hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc(&h->h_img1, bytes, hipHostMallocMapped));
+        HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->m_img1), h->h_img1, 0));
         h->img1_bytes = bytes;
     }
     if (h->out1_cap < need) {
@@ -252,24 +258,30 @@ int orbx_extract(orbx_extractor* h, const uint8_t* img, int w, int hgt, ptrdiff_
         h->desc1_off = h->kps1_off + ((size_t)need * sizeof(orbx_keypoint) + 63) / 64 * 64;
         h->out1_bytes = h->desc1_off + (size_t)need * 32;
         HIPCHK(h, hipMalloc(&h->d_out1, h->out1_bytes));
-        HIPCHK(h, hipHostMalloc(&h->h_out1, h->out1_bytes, hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc(&h->h_out1, h->out1_bytes, hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->m_out1), h->h_out1, 0));
         h->out1_cap = need;
     }
     if (!h->s1) HIPCHK(h, hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
-    // pinned staging both ways: one H2D copy in, one D2H copy out (n, status, keypoints and descriptors in one block)
-    if (bytes <= (size_t)512 << 10) {   // small frames: stage through pinned memory (one DMA); large ones: let the runtime pipeline the copy
+    // In: small frames are staged in pinned memory and fetched from there by a kernel (k_ingest: no copy engine, no queue switch before
+    // the first pyramid launch); large ones go through the runtime's pipelined copy.  Out: k_describe, the only writer of the results,
+    // stores n / status / keypoints / descriptors straight into the pinned, device-mapped block (posted PCIe writes, visible to the
+    // host once the stream has drained) - the D2H copy and the kernel -> copy dependency in front of it (~15 us) are gone.
+    if (bytes <= (size_t)512 << 10) {
         for (int y = 0; y < hgt; y++) memcpy(h->h_img1 + (size_t)y * dstride, img + (ptrdiff_t)y * stride, (size_t)w);
-        HIPCHK(h, hipMemcpyAsync(h->d_img1, h->h_img1, bytes, hipMemcpyHostToDevice, h->s1));
+        if (h->zero_copy) { if ((rc = launch_ingest(h->d_img1, h->m_img1, bytes, h->s1)) != ORBX_OK) { h->err = "kernel launch failed (no gfx950 code object for this device?)"; return rc; } }
+        else HIPCHK(h, hipMemcpyAsync(h->d_img1, h->h_img1, bytes, hipMemcpyHostToDevice, h->s1));
     } else {
         HIPCHK(h, hipMemcpy2DAsync(h->d_img1, dstride, img, stride, w, hgt, hipMemcpyHostToDevice, h->s1));
     }
-    int32_t* d_n = reinterpret_cast<int32_t*>(h->d_out1);
-    // (Replaying the launch group from a HIP graph was measured and does not help: 188 vs 181 us — the latency is the
-    //  chain of 16 dependent small kernels, not the launch calls.)
-    rc = orbx_extract_batch_device(h, h->d_img1, 1, w, hgt, dstride, (ptrdiff_t)bytes, reinterpret_cast<orbx_keypoint*>(h->d_out1 + h->kps1_off),
-                                   h->d_out1 + h->desc1_off, d_n, need, d_n + 1, h->s1);
+    uint8_t* out = h->zero_copy ? h->m_out1 : h->d_out1;
+    int32_t* d_n = reinterpret_cast<int32_t*>(out);
+    // (Replaying the launch group from a HIP graph was measured and does not help: 188 vs 181 us - the latency is the
+    //  chain of dependent small kernels, not the launch calls.)
+    rc = orbx_extract_batch_device(h, h->d_img1, 1, w, hgt, dstride, (ptrdiff_t)bytes, reinterpret_cast<orbx_keypoint*>(out + h->kps1_off),
+                                   out + h->desc1_off, d_n, need, d_n + 1, h->s1);
     if (rc != ORBX_OK) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->h_out1, h->d_out1, h->out1_bytes, hipMemcpyDeviceToHost, h->s1));
+    if (!h->zero_copy) HIPCHK(h, hipMemcpyAsync(h->h_out1, h->d_out1, h->out1_bytes, hipMemcpyDeviceToHost, h->s1));
     HIPCHK(h, hipStreamSynchronize(h->s1));
     const int32_t* res = reinterpret_cast<const int32_t*>(h->h_out1);
     if (h->stop_after >= 0) { *n_out = 0; return ORBX_OK; }

@@ -87,7 +87,7 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
     // --- per-level geometry
     const float imageRatio = (float)w / h;   // level 0 cols/rows (:526)
     int plane_off = 0, cell_base = 0, cand_base = 0, sel_base = 0, slot_base = 0, quad_base = 0;
-    int btile_base = 0;
+    int btile_base = 0, btile_base_s = 0;
     for (int l = 0; l < nl; l++) {
         LevelGeom& L = g.lv[l];
         const float s = out.inv_scale[l];
@@ -198,6 +198,9 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
         L.btiles_y = (L.h + BLUR_ROWS - 1) / BLUR_ROWS;
         L.btile_base = btile_base;
         btile_base += L.btiles_x * L.btiles_y;
+        L.btiles_y_s = (L.h + BLUR_ROWS_SMALL - 1) / BLUR_ROWS_SMALL;
+        L.btile_base_s = btile_base_s;
+        btile_base_s += L.btiles_x * L.btiles_y_s;
 
         // cv::resize tables level l-1 -> l
         if (l > 0) {
@@ -267,7 +270,8 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
             PyrGroup pg;
             memset(&pg, 0, sizeof(pg));
             pg.l0 = l0;
-            pg.depth = std::min(l0 == 0 ? 3 : PYR_MAX_DEPTH, nl - 1 - l0);
+            constexpr int depth_cfg[2] = {ORBX_PYR_DEPTH};   // first group, further groups
+            pg.depth = std::min(std::min(l0 == 0 ? depth_cfg[0] : depth_cfg[1], PYR_MAX_DEPTH), nl - 1 - l0);
             const LevelGeom& LD = g.lv[l0 + pg.depth];
             pg.ntx = (LD.w + tile[0] - 1) / tile[0];
             pg.nty = (LD.h + tile[1] - 1) / tile[1];
@@ -354,10 +358,12 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
         g.cell_bases[l] = live ? g.lv[l].cell_base : INT_MAX;
         g.quad_bases[l] = live ? g.lv[l].quad_base : INT_MAX;
         g.btile_bases[l] = live ? g.lv[l].btile_base : INT_MAX;
+        g.btile_bases_s[l] = live ? g.lv[l].btile_base_s : INT_MAX;
     }
     g.ncells_total = cell_base;
     g.nbands_total = (int)out.bands.size();
     g.nbtiles_total = btile_base;
+    g.nbtiles_total_s = btile_base_s;
     g.nslots = slot_base;
     g.nquads = quad_base;
     g.frame_plane_bytes = align_up(plane_off, 256);

@@ -42,6 +42,7 @@ struct LevelGeom {
     int rz_window;         // k_resize: 1 = the four output pixels of a lane read at most 8 adjacent source bytes per row (windowed form)
     int rz_pitch, rz_rows; // k_resize: LDS source tile of one 256x16 output tile (bytes per row, rows), maxima over the level's tiles
     int btile_base, btiles_x, btiles_y;// blur wave tasks: 248-px strips x 32-row bands of the whole plane
+    int btile_base_s, btiles_y_s;      // the same with BLUR_ROWS_SMALL-row bands (launch groups too small to fill the chip: shorter waves)
     int blur_wvec;         // columns x < blur_wvec round ties-to-even (SSE2 emulation), others half-up
     int blur_sel_last, blur_sel_halo;   // v_perm selectors building the reflect-101 bytes of the last / right-halo dword of a row
     float scale;           // mvScaleFactor[level]
@@ -73,6 +74,7 @@ constexpr int DESC_WAVES = ORBX_DESC_WAVES;   // k_describe: keypoints (waves) p
 #define ORBX_RZ_ROWS 48
 #endif
 constexpr int BLUR_ROWS = ORBX_BLUR_ROWS;   // k_blur: output rows per wave strip
+constexpr int BLUR_ROWS_SMALL = 8;          // ... when the launch group cannot fill the chip anyway (a wave's strip is a serial chain of rows)
 constexpr int RZ_ROWS = ORBX_RZ_ROWS;       // k_resize: output rows per workgroup (a tall tile amortises the table -> source -> LDS latency chain)
 // The two launch shapes of k_fast_cells: threads per work item, dwords (4 pixels) per lane and round, band size in pixels, widest
 // cell.  Per WAVE the kernel keeps a queue of flagged dwords (one round plus one slice of 64), of expanded pixel offsets (a slice of
@@ -105,7 +107,10 @@ struct BandGeom {
 // the first / last column (row) of the tile's region; a tile OWNS (= writes to HBM) the columns from its region start up to the
 // next tile's region start, which partitions every level.  Region starts are multiples of 4 (dword stores never straddle owners).
 constexpr int XCD_AFFINITY_MIN_FRAMES = 64;      // launch groups of at least this many frames keep a frame's workgroups on one XCD (orbx_kernels.hip: frame_item)
-constexpr int PYR_MAX_GROUPS = 4, PYR_MAX_DEPTH = 4;
+#ifndef ORBX_PYR_DEPTH
+#define ORBX_PYR_DEPTH 4, 4
+#endif
+constexpr int PYR_MAX_GROUPS = 4, PYR_MAX_DEPTH = 8;
 struct PyrGroup {
     int l0, depth;               // source level, number of levels produced
     int ntx, nty;                // tiles of the deepest level
@@ -115,7 +120,7 @@ struct PyrGroup {
     int lds_bytes;
 };
 #ifndef ORBX_PYR_TILE
-#define ORBX_PYR_TILE 64, 32
+#define ORBX_PYR_TILE 16, 16
 #endif
 
 struct CellState { int32_t n_all, n_hi, n_lo; };     // survivors total, with score>=fastTh, with score>=7
@@ -125,7 +130,7 @@ struct DevGeom {
     int nlevels;
     int ncells_total;
     int nbands_total;        // k_fast_cells work items per frame (>= ncells_total)
-    int nbtiles_total;
+    int nbtiles_total, nbtiles_total_s;
     int nslots;              // sum of ndesired (max keypoints per frame)
     int nquads;              // sum of ceil(ndesired / 4): k_describe waves per frame
     int score_type, fast_th, tmin;
@@ -141,7 +146,7 @@ struct DevGeom {
     int umax[HALF_PATCH + 1];
     // per-level bases as compact arrays: one scalar load each, so a wave finds its level in a single round trip
     // (walking lv[l].xxx_base level by level was a chain of up to nlevels dependent scalar loads, ~1.5 us per wave)
-    int cell_bases[MAX_LEVELS], quad_bases[MAX_LEVELS], btile_bases[MAX_LEVELS];
+    int cell_bases[MAX_LEVELS], quad_bases[MAX_LEVELS], btile_bases[MAX_LEVELS], btile_bases_s[MAX_LEVELS];
     LevelGeom lv[MAX_LEVELS];
 };
 

@@ -319,7 +319,6 @@ __global__ __launch_bounds__(256) void k_pyramid(Batch b, int group) {
         }
     }
     __syncthreads();
-    const int gx = tid & 31, gy = tid >> 5;
     for (int k = 1; k <= depth; k++) {
         const int level = l0 + k;
         const LevelGeom& L = g.lv[level];
@@ -334,14 +333,17 @@ __global__ __launch_bounds__(256) void k_pyramid(Batch b, int group) {
         const int dpitch = k < depth ? pg.pitch[k] : 0;
         uint8_t* dplane = b.pyr + (long long)frame * g.frame_plane_bytes + L.plane_off;
         const int ngroups = ((xe - xs) >> 2) + 1;
-        for (int G0 = 0; G0 < ngroups; G0 += 32) {
+        // threads: dword columns x row phases, the split chosen per level (the regions narrow towards the deepest level)
+        const int lc = ngroups > 16 ? 5 : ngroups > 8 ? 4 : 3;
+        const int gx = tid & ((1 << lc) - 1), gy = tid >> lc, ystep = 256 >> lc;
+        for (int G0 = 0; G0 < ngroups; G0 += 1 << lc) {
             const int G = G0 + gx;
             if (G >= ngroups) continue;
             const int X = xs + 4 * G;
             ResizeX rx[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) rx[j] = tx[min(X + j, L.w - 1)];
-            for (int y = ys + gy; y <= ye; y += 8) {
+            for (int y = ys + gy; y <= ye; y += ystep) {
                 const ResizeY ry = ty[y];
                 const uint8_t* q0 = sbuf + (ry.sy0 - sys) * spitch - sxs;
                 const uint8_t* q1 = sbuf + (ry.sy1 - sys) * spitch - sxs;
@@ -389,13 +391,11 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {   // number of 
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 template <bool ALIGNED, int NT, int PPT>
-__device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t* smem) {
+__device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int item, uint8_t* smem) {
     constexpr int NW = NT / 64;
     constexpr int Q0CAP = fast_q0cap(PPT), Q1CAP = FAST_Q1CAP, Q2CAP = FAST_Q2CAP, Q3CAP = FAST_Q3CAP;
     constexpr int WQ_BYTES = fast_wave_queue_bytes(PPT);
     const DevGeom& g = b.g;
-    int frame, item;
-    if (!frame_item(b, task, g.nbands_total, frame, item)) return;
     const BandGeom bg = b.bands[item];
     const int level = bg.level;
     const LevelGeom& L = g.lv[level];
@@ -671,84 +671,89 @@ __device__ __forceinline__ void fast_cell_task(const Batch& b, int task, uint8_t
 template <bool ALIGNED, int NT, int PPT>
 __global__ __launch_bounds__(NT) void k_fast_cells(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    fast_cell_task<ALIGNED, NT, PPT>(b, blockIdx.x, smem);
+    int frame, item;
+    if (!frame_item(b, blockIdx.x, b.g.nbands_total, frame, item)) return;
+    fast_band_task<ALIGNED, NT, PPT>(b, frame, item, smem);
 }
 
 // ------------------------------------------------------------------------------------ quotas
-// reference :609-670.  One wave per (frame, level): the lanes gather the cells' counts in parallel into LDS, lane 0
-// runs the reference's (inherently sequential) redistribution loop on the LDS copy, the lanes write the result back.
+// reference :609-670.  One wave per (frame, level).  The redistribution loop of the reference looks sequential, but within one of
+// its passes the new per-cell allowance is fixed before the pass starts and every cell decides on its own; only the two totals
+// (features left to distribute, cells that cannot take more) couple the cells, and they are sums.  So a pass is one sweep of the
+// lanes over their cells plus two wave reductions, and the output offsets are a wave prefix sum in cell order.  Lane i owns the
+// cells i, i + 64, ...; nothing a lane writes is read by another lane, so the LDS arrays need no barriers.  (A single lane walking
+// the cells one by one took 10 us per level: nothing for a full batch, 7 % of the one-frame call.)
 constexpr int QUOTA_MAX_CELLS = 1024;   // checked on the host
 
 struct QuotaLds {
-    int nkeys[QUOTA_MAX_CELLS], nret[QUOTA_MAX_CELLS], off[QUOTA_MAX_CELLS];
-    uint8_t thr[QUOTA_MAX_CELLS], done[QUOTA_MAX_CELLS], skip[QUOTA_MAX_CELLS];
-    int total;
+    int nkeys[QUOTA_MAX_CELLS], nret[QUOTA_MAX_CELLS];
+    uint8_t thr[QUOTA_MAX_CELLS], done[QUOTA_MAX_CELLS];
 };
-
-// one wave (lanes 0..63 of the calling workgroup's first wave); `sync` = the barrier between the phases (a wave-level fence when the
-// wave is alone, __syncthreads when other waves of the workgroup wait for the result)
-template <typename Sync>
-__device__ __forceinline__ void quota_body(const Batch& b, int frame, int level, int lane, bool active, QuotaLds& q, Sync sync) {
-    const DevGeom& g = b.g;
-    const LevelGeom& L = g.lv[level];
-    const CellGeom* cg = b.cells + L.cell_base;
-    const CellState* cs = b.cstate + (long long)frame * g.nbands_total;   // per band; a cell sums its bands
-    CellSel* sel = b.csel + (long long)frame * g.ncells_total + L.cell_base;
-    const int nCells = L.ncells, nfc = L.nfeat_cell;
-    if (active)
-        for (int c = lane; c < nCells; c += 64) {
-            const CellGeom cgc = cg[c];
-            int n_hi = 0, n_lo = 0;
-            for (int k = 0; k < cgc.nbands; k++) { const CellState t = cs[cgc.band0 + k]; n_hi += t.n_hi; n_lo += t.n_lo; }
-            const bool fallback = n_hi <= 3;                      // :609  size()<=3 -> FAST(...,7,...)
-            q.skip[c] = (uint8_t)cgc.skipped;
-            q.thr[c] = (uint8_t)(cgc.skipped || !fallback ? g.fast_th : 7);
-            q.nkeys[c] = cgc.skipped ? 0 : (fallback ? n_lo : n_hi);
-        }
-    sync();
-    if (active && lane == 0) {
-        int nToDistribute = 0, nNoMore = 0;
-        for (int c = 0; c < nCells; c++) {
-            if (q.skip[c]) { q.nret[c] = 0; q.done[c] = 0; continue; }   // reference `continue`: never reaches the bookkeeping
-            const int nk = q.nkeys[c];
-            if (nk > nfc) { q.nret[c] = nfc; q.done[c] = 0; }
-            else { q.nret[c] = nk; nToDistribute += nfc - nk; q.done[c] = 1; nNoMore++; }
-        }
-        while (nToDistribute > 0 && nNoMore < nCells) {
-            const int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nCells - nNoMore));
-            nToDistribute = 0;
-            for (int c = 0; c < nCells; c++) {
-                if (!q.done[c]) {
-                    const int nk = q.nkeys[c];
-                    if (nk > nNew) { q.nret[c] = nNew; }
-                    else { q.nret[c] = nk; nToDistribute += nNew - nk; q.done[c] = 1; nNoMore++; }
-                }
-            }
-        }
-        int off = 0;
-        for (int c = 0; c < nCells; c++) { q.off[c] = off; off += q.nret[c]; }
-        if (off > L.sel_cap) { b.status[frame] = ORBX_ERR_CAPACITY; off = -1; }
-        q.total = off;
-        b.level_total[frame * MAX_LEVELS + level] = off < 0 ? 0 : off;
-    }
-    sync();
-    if (active) {
-        const bool bad = q.total < 0;
-        for (int c = lane; c < nCells; c += 64) {
-            CellSel r;
-            r.thr = q.thr[c]; r.nkeys = q.nkeys[c];
-            r.nretain = bad ? 0 : q.nret[c];
-            r.out_off = bad ? 0 : q.off[c];
-            sel[c] = r;
-        }
-    }
-}
 
 __global__ __launch_bounds__(64) void k_quota(Batch b) {
     __shared__ QuotaLds q;
     const DevGeom& g = b.g;
     const int frame = blockIdx.x / g.nlevels, level = blockIdx.x - frame * g.nlevels;
-    quota_body(b, frame, level, (int)threadIdx.x, true, q, [] { __syncthreads(); });
+    const int lane = (int)threadIdx.x;
+    const LevelGeom& L = g.lv[level];
+    const CellGeom* cg = b.cells + L.cell_base;
+    const CellState* cs = b.cstate + (long long)frame * g.nbands_total;   // per band; a cell sums its bands
+    CellSel* sel = b.csel + (long long)frame * g.ncells_total + L.cell_base;
+    const int nCells = L.ncells, nfc = L.nfeat_cell;
+    // first pass of the reference (:622-641), fused with the gather of the cells' counts
+    int dist = 0, nomore = 0;
+    for (int c = lane; c < nCells; c += 64) {
+        const CellGeom cgc = cg[c];
+        int n_hi = 0, n_lo = 0;
+        for (int k = 0; k < cgc.nbands; k++) { const CellState t = cs[cgc.band0 + k]; n_hi += t.n_hi; n_lo += t.n_lo; }
+        const bool fallback = n_hi <= 3;                      // :609  size()<=3 -> FAST(...,7,...)
+        const int nk = cgc.skipped ? 0 : (fallback ? n_lo : n_hi);
+        q.thr[c] = (uint8_t)(cgc.skipped || !fallback ? g.fast_th : 7);
+        q.nkeys[c] = nk;
+        // a skipped cell takes the reference's `continue`: it never reaches the bookkeeping of this pass (and is then treated as an
+        // open cell with no keypoints by the passes below, exactly like there)
+        if (cgc.skipped) { q.nret[c] = 0; q.done[c] = 0; }
+        else if (nk > nfc) { q.nret[c] = nfc; q.done[c] = 0; }
+        else { q.nret[c] = nk; dist += nfc - nk; q.done[c] = 1; nomore++; }
+    }
+    int nToDistribute = wave_sum(dist), nNoMore = wave_sum(nomore);
+    while (nToDistribute > 0 && nNoMore < nCells) {           // :645-668
+        const int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nCells - nNoMore));
+        dist = 0; nomore = 0;
+        for (int c = lane; c < nCells; c += 64) {
+            if (q.done[c]) continue;
+            const int nk = q.nkeys[c];
+            if (nk > nNew) q.nret[c] = nNew;
+            else { q.nret[c] = nk; dist += nNew - nk; q.done[c] = 1; nomore++; }
+        }
+        nToDistribute = wave_sum(dist);
+        nNoMore += wave_sum(nomore);
+    }
+    // output offsets in cell order; the level's total decides whether the lists fit
+    int total = 0;
+    for (int c0 = 0; c0 < nCells; c0 += 64) total += (c0 + lane < nCells) ? q.nret[c0 + lane] : 0;
+    total = wave_sum(total);
+    const bool bad = total > L.sel_cap;
+    int base = 0;
+    for (int c0 = 0; c0 < nCells; c0 += 64) {
+        const int c = c0 + lane;
+        const int v = c < nCells ? q.nret[c] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (c < nCells) {
+            CellSel r;
+            r.thr = q.thr[c]; r.nkeys = q.nkeys[c];
+            r.nretain = bad ? 0 : v;
+            r.out_off = bad ? 0 : base + incl - v;
+            sel[c] = r;
+        }
+        base += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) {
+        if (bad) b.status[frame] = ORBX_ERR_CAPACITY;
+        b.level_total[frame * MAX_LEVELS + level] = bad ? 0 : total;
+    }
 }
 
 // ------------------------------------------------------------------------------------ retainBest per cell
@@ -1007,21 +1012,17 @@ __device__ __forceinline__ uint32_t load_px4_reflect(const uint8_t* row, int x, 
     return v;
 }
 
-template <bool ALIGNED>
-__global__ __launch_bounds__(BLUR_WAVES * 64) void k_blur(Batch b) {
+template <bool ALIGNED, int ROWS>
+__device__ __forceinline__ void blur_strip(const Batch& b, int frame, int t) {   // t = strip index within the frame (wave-uniform)
     const DevGeom& g = b.g;
-    const int wgs_per_frame = (g.nbtiles_total + BLUR_WAVES - 1) / BLUR_WAVES;
-    int frame, wgi;
-    if (!frame_item(b, blockIdx.x, wgs_per_frame, frame, wgi)) return;
-    const int t = wgi * BLUR_WAVES + wave_id();
-    if (t >= g.nbtiles_total) return;
-    const int level = find_level(g.btile_bases, t);
+    constexpr bool SHORT = ROWS != BLUR_ROWS;       // the tiling with short strips (launch_extract picks it for small launch groups)
+    const int level = find_level(SHORT ? g.btile_bases_s : g.btile_bases, t);
     const LevelGeom& L = g.lv[level];
-    const int tl = t - L.btile_base;
+    const int tl = t - (SHORT ? L.btile_base_s : L.btile_base);
     const int band = tl / L.btiles_x, strip = tl - band * L.btiles_x;
     const int lane = threadIdx.x & 63;
     const int x = (strip * BLUR_STRIP_DW + lane - 1) * 4;      // first pixel of this lane's dword (may be < 0)
-    const int y0 = band * BLUR_ROWS;
+    const int y0 = band * ROWS;
     const int w = L.w, h = L.h;
     long long stride;
     const uint8_t* src = plain_plane(b, L, level, frame, stride);
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(BLUR_WAVES * 64) void k_blur(Batch b) {
     uint32_t pp[6][4];            // pp[r % 6] = (row r-1 | row r << 16) of the lane's 4 pixels
     uint32_t prev[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < BLUR_ROWS + 6; r++) {
+    for (int r = 0; r < ROWS + 6; r++) {
         const int yy = reflect101(y0 + r - 3, h);
         const uint8_t* row = src + (long long)yy * stride;
         uint32_t C = 0;
@@ -1088,6 +1089,35 @@ __global__ __launch_bounds__(BLUR_WAVES * 64) void k_blur(Batch b) {
 #pragma unroll
         for (int i = 0; i < 4; i++) prev[i] = cur[i];
     }
+}
+
+template <bool ALIGNED, int ROWS>
+__global__ __launch_bounds__(BLUR_WAVES * 64) void k_blur(Batch b) {
+    const DevGeom& g = b.g;
+    const int ntiles = ROWS != BLUR_ROWS ? g.nbtiles_total_s : g.nbtiles_total;
+    int frame, wgi;
+    if (!frame_item(b, blockIdx.x, (ntiles + BLUR_WAVES - 1) / BLUR_WAVES, frame, wgi)) return;
+    const int t = wgi * BLUR_WAVES + wave_id();
+    if (t < ntiles) blur_strip<ALIGNED, ROWS>(b, frame, t);
+}
+
+// FAST and the blur both depend on the pyramid only.  A launch group that cannot fill the chip (the one-frame drop-in call) runs
+// them side by side in ONE launch: the first blocks of a frame blur short strips (4 waves = 4 strips), the rest are cell bands.
+// (Two streams would do the same for a full batch - launch_extract forks there - but a fork / join across hardware queues costs
+// ~8 us each way, as much as either kernel takes on one frame.)
+template <bool ALIGNED>
+__global__ __launch_bounds__(FAST_SMALL.threads) void k_fast_blur(Batch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr FastShape A = FAST_SMALL;
+    constexpr int NW = A.threads / 64;
+    const DevGeom& g = b.g;
+    const int nblur = (g.nbtiles_total_s + NW - 1) / NW;
+    const int per_frame = nblur + g.nbands_total;
+    const int frame = blockIdx.x / per_frame, item = blockIdx.x - frame * per_frame;
+    if (item < nblur) {
+        const int t = item * NW + wave_id();
+        if (t < g.nbtiles_total_s) blur_strip<ALIGNED, BLUR_ROWS_SMALL>(b, frame, t);
+    } else fast_band_task<ALIGNED, A.threads, A.ppt>(b, frame, item - nblur, smem);
 }
 
 // ------------------------------------------------------------------------------------ orientation + rBRIEF + output
@@ -1349,13 +1379,22 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     auto launch_blur = [&](hipStream_t st) -> int {
         StageScope sc(timer, st, ST_BLUR);
         const bool aligned = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
-        const int nblk = frame_item_blocks(b, (g.nbtiles_total + BLUR_WAVES - 1) / BLUR_WAVES);
-        if (aligned) hipLaunchKernelGGL(k_blur<true>, dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);
-        else hipLaunchKernelGGL(k_blur<false>, dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);
+        if (F < PYR_FUSED_MAX_FRAMES) {   // short strips: 4x the waves, a quarter of the serial row chain each
+            const int nblk = frame_item_blocks(b, (g.nbtiles_total_s + BLUR_WAVES - 1) / BLUR_WAVES);
+            if (aligned) hipLaunchKernelGGL((k_blur<true, BLUR_ROWS_SMALL>), dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);
+            else hipLaunchKernelGGL((k_blur<false, BLUR_ROWS_SMALL>), dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);
+        } else {
+            const int nblk = frame_item_blocks(b, (g.nbtiles_total + BLUR_WAVES - 1) / BLUR_WAVES);
+            if (aligned) hipLaunchKernelGGL((k_blur<true, BLUR_ROWS>), dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);
+            else hipLaunchKernelGGL((k_blur<false, BLUR_ROWS>), dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);
+        }
         ORBX_LAUNCH_CHECK();
         return ORBX_OK;
     };
-    const bool overlap = side && side->aux && stop_after < 0;
+    // (a launch group that cannot fill the chip keeps the blur in line: its short strips take ~6 us, the fork and the join across
+    //  two hardware queues cost 8 us each)
+    const bool overlap = side && side->aux && stop_after < 0 && F >= PYR_FUSED_MAX_FRAMES;
+    const bool fuse_blur = F < PYR_FUSED_MAX_FRAMES && g.fast_small && !b.xcd_affinity;    // k_fast_blur
     {
         StageScope sc(timer, stream, ST_FAST_CELLS);
         const bool aligned = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
@@ -1367,7 +1406,15 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         };
         constexpr FastShape A = FAST_SMALL, B = FAST_LARGE;
         bool ok;
-        if (g.fast_small) ok = aligned ? launch(k_fast_cells<true, A.threads, A.ppt>, A.threads) : launch(k_fast_cells<false, A.threads, A.ppt>, A.threads);
+        if (fuse_blur) {
+            const int per_frame = (g.nbtiles_total_s + A.threads / 64 - 1) / (A.threads / 64) + g.nbands_total;
+            auto launch2 = [&](auto kern) -> bool {
+                if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+                hipLaunchKernelGGL(kern, dim3(F * per_frame), dim3(A.threads), lds, stream, b);
+                return true;
+            };
+            ok = aligned ? launch2(k_fast_blur<true>) : launch2(k_fast_blur<false>);
+        } else if (g.fast_small) ok = aligned ? launch(k_fast_cells<true, A.threads, A.ppt>, A.threads) : launch(k_fast_cells<false, A.threads, A.ppt>, A.threads);
         else ok = aligned ? launch(k_fast_cells<true, B.threads, B.ppt>, B.threads) : launch(k_fast_cells<false, B.threads, B.ppt>, B.threads);
         if (!ok) return ORBX_ERR_DEVICE;
         ORBX_LAUNCH_CHECK();
@@ -1408,13 +1455,27 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     if (stop_after == ST_LEVEL_SELECT) return ORBX_OK;
     if (overlap) {
         if (hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) return ORBX_ERR_DEVICE;
-    } else if (launch_blur(stream) != ORBX_OK) return ORBX_ERR_DEVICE;
+    } else if (!fuse_blur && launch_blur(stream) != ORBX_OK) return ORBX_ERR_DEVICE;
     if (stop_after == ST_BLUR) return ORBX_OK;
     {
         StageScope sc(timer, stream, ST_DESCRIBE);
         hipLaunchKernelGGL(k_describe, dim3(frame_item_blocks(b, (g.nquads + DESC_WAVES - 1) / DESC_WAVES)), dim3(DESC_WAVES * 64), 0, stream, b);
         ORBX_LAUNCH_CHECK();
     }
+    return ORBX_OK;
+}
+
+// The one-frame drop-in call (orbx_extract): the frame is fetched from the pinned, device-mapped staging buffer by a kernel instead
+// of a DMA copy (a copy -> kernel dependency costs ~9 us on top of the copy's 15 us for a VGA frame; 300 waves with one 16-byte
+// load each in flight pull the 300 KB over PCIe in less, and the next kernel follows without a queue switch).
+__global__ __launch_bounds__(256) void k_ingest(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+int launch_ingest(uint8_t* d_dst, const uint8_t* mapped_src, size_t bytes, hipStream_t stream) {
+    const int n16 = (int)(bytes / 16);
+    hipLaunchKernelGGL(k_ingest, dim3((n16 + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const uint4*>(mapped_src), reinterpret_cast<uint4*>(d_dst), n16);
+    ORBX_LAUNCH_CHECK();
     return ORBX_OK;
 }
 
