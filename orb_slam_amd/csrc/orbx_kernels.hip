@@ -156,13 +156,32 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
     ResizeX rx[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) rx[k] = tx[min(dx0 + k, L.w - 1)];
+    // the row-table entries of this wave's output rows, one per lane, fetched before the staging: read inside the row loop they
+    // were a global-load round trip per output row (a uniform address, but not provably read-only, so no scalar load), and that
+    // chain of dependent loads - not the VALU work - set the kernel's pace
+    constexpr int RPW = RZ_ROWS / 4;                               // consecutive output rows per wave (windowed form)
+    const uint2 ryl = *reinterpret_cast<const uint2*>(ty + min(by0 + wave * RPW + min(lane, RPW - 1), L.h - 1));
     // source rectangle of this tile (tables are monotone)
     const int r0 = ty[by0].sy0, r1 = ty[by1].sy1;
     const int c0 = tx[bx0].sx & ~3, c1 = tx[bx1].sx1;
     const int nd = ((c1 - c0) >> 2) + 1, nr = r1 - r0 + 1;
-    {
-        // flattened (row, dword) items, 8 independent loads in flight per lane (a row-per-iteration loop serialises
-        // ~6 dependent global-load round trips per workgroup and made this kernel latency-bound)
+    if (ALIGNED) {
+        // LDS-DMA staging (as in k_fast_cells): one global_load_lds_dword per (row, 64-dword piece), lane i's dword lands at
+        // M0 + 4 i.  Row bases are scalars, so the staging costs a wave ~2 instructions per row instead of ~20 VALU instructions
+        // per dword (flattened index -> row / column, bounds, address, ds_write): that loop was 45 % of this kernel's instructions.
+        typedef const void __attribute__((address_space(1))) * gptr_t;
+        typedef void __attribute__((address_space(3))) * lptr_t;
+        const uint8_t* base = src + (long long)r0 * sstride + c0;
+        for (int p0 = 0; p0 < nd; p0 += 64) {
+            const bool on = p0 + lane < nd;
+            for (int r = wave; r < nr; r += 4) {
+                const uint8_t* grow = base + (long long)r * sstride + 4 * p0;     // wave-uniform
+                if (on) __builtin_amdgcn_global_load_lds((gptr_t)(grow + 4 * lane), (lptr_t)(s_src + r * RZ_SRC_W + 4 * p0), 4, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA writes have landed; the barrier below covers the other waves
+    } else {
+        // unaligned frames (level 0 -> 1 only): flattened (row, dword) items, 8 independent loads in flight per lane
         const int total = nr * nd;
         const float inv_nd = 1.0f / (float)nd;
         const uint8_t* base = src + (long long)r0 * sstride + c0;
@@ -207,37 +226,42 @@ __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
             sel[k] = (uint32_t)(rx[k].sx - c0 - w0) | 0x0C000C00u | ((uint32_t)(rx[k].sx1 - c0 - w0) << 16);     // bytes: s[sx], 0, s[sx1], 0
             apair[k] = (uint32_t)(uint16_t)rx[k].a0 | ((uint32_t)(uint16_t)rx[k].a1 << 16);
         }
+        // hrow leaves the horizontal results already shifted (D >> 4, the form the vertical pass consumes: once per source row, not
+        // once per use).  Vertical pass: (b * (D >> 4)) >> 16 is v_mul_hi_u32 with the weight pre-shifted to the high half (a scalar
+        // per row) - one instruction instead of multiply + shift; the result is < 256 by construction (weights sum to 2048), so the
+        // four pixels are packed with shift-or, no masks.
         auto hrow = [&](int sy, uint32_t (&d)[4]) {
             const uint32_t* p = reinterpret_cast<const uint32_t*>(s_src + (sy - r0) * RZ_SRC_W + wa);
             const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
             const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)sh), hi = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)sh);
 #pragma unroll
-            for (int k = 0; k < 4; k++) d[k] = __builtin_amdgcn_udot2(as_us2v(__builtin_amdgcn_perm(hi, lo, sel[k])), as_us2v(apair[k]), 0u, false);
+            for (int k = 0; k < 4; k++) d[k] = __builtin_amdgcn_udot2(as_us2v(__builtin_amdgcn_perm(hi, lo, sel[k])), as_us2v(apair[k]), 0u, false) >> 4;
         };
-        constexpr int RPW = RZ_ROWS / 4;                           // consecutive output rows per wave
         int have = -1;
         uint32_t dprev[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
             const int dy = by0 + wave * RPW + j;
             if (dy >= L.h) break;
-            const ResizeY ry = ty[dy];
+            const uint32_t ry_rows = (uint32_t)__builtin_amdgcn_readlane((int)ryl.x, j), ry_w = (uint32_t)__builtin_amdgcn_readlane((int)ryl.y, j);
+            const int sy0 = (int16_t)(ry_rows & 0xffffu), sy1 = (int16_t)(ry_rows >> 16);
+            const uint32_t b0s = ry_w << 16, b1s = ry_w & 0xffff0000u;      // the weights (0 .. 2048) in the high halves
             uint32_t da[4], db[4];
-            if (ry.sy0 == have) {
+            if (sy0 == have) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) da[k] = dprev[k];
-            } else hrow(ry.sy0, da);
-            if (ry.sy1 == ry.sy0) {
+            } else hrow(sy0, da);
+            if (sy1 == sy0) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) db[k] = da[k];
-            } else hrow(ry.sy1, db);
-            have = ry.sy1;
+            } else hrow(sy1, db);
+            have = sy1;
             uint32_t packed = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 dprev[k] = db[k];
-                const int px = (int)(((uint32_t)(ry.b0 * (int)(da[k] >> 4)) >> 16) + ((uint32_t)(ry.b1 * (int)(db[k] >> 4)) >> 16) + 2) >> 2;
-                packed |= (uint32_t)(px & 255) << (8 * k);
+                const uint32_t px = (__umulhi(da[k], b0s) + __umulhi(db[k], b1s) + 2u) >> 2;
+                packed |= px << (8 * k);
             }
             // columns past L.w (dx0+k clamped above) land in the row padding: stride is a multiple of 64
             *reinterpret_cast<uint32_t*>(dplane + (long long)dy * L.stride + dx0) = packed;
