@@ -1190,7 +1190,37 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
     if (!frame_item(b, blockIdx.x, (g.nquads + DESC_WAVES - 1) / DESC_WAVES, frame, wgi)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int grp = lane >> 4, li = lane & 15;
+    // The wave's chain of dependent memory round trips sets this kernel's pace as much as its arithmetic, so everything is requested
+    // as early as its address is known: the per-level counts (one load, lane l holds level l) and the frame status first, then the
+    // wave's keypoints, and only then the LDS tables are built (their barrier rides on those loads); the 37 x 37 windows of the
+    // blurred level follow by LDS-DMA as soon as the keypoints are there, in flight during IC_Angle and the angle arithmetic.
     const int32_t* counts = b.level_count + frame * MAX_LEVELS;
+    const int cl = lane < g.nlevels ? counts[lane] : 0;
+    const int st0 = b.status[frame];
+    const int quad = wgi * DESC_WAVES + wave_id();
+    const bool live = quad < g.nquads;
+    const int level = __builtin_amdgcn_readfirstlane(find_level(g.quad_bases, live ? quad : 0));
+    // the level's geometry as scalars (wave-uniform by construction; pinned so that nothing is re-read through per-lane addresses)
+    const LevelGeom& LG = g.lv[level];
+    struct { int w, h, stride, plane_off, sel_base, quad_base; float scale, kp_size; } L = {
+        __builtin_amdgcn_readfirstlane(LG.w), __builtin_amdgcn_readfirstlane(LG.h), __builtin_amdgcn_readfirstlane(LG.stride),
+        __builtin_amdgcn_readfirstlane(LG.plane_off), __builtin_amdgcn_readfirstlane(LG.sel_base), __builtin_amdgcn_readfirstlane(LG.quad_base),
+        __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, LG.scale))),
+        __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, LG.kp_size)))};
+    int out_base = 0, total = 0, cnt = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int c = __builtin_amdgcn_readlane(cl, l);
+        if (l < level) out_base += c;
+        if (l == level) cnt = c;
+        total += c;
+    }
+    const int k0 = (quad - L.quad_base) * DESC_KPW;
+    const bool work = live && k0 < cnt && total <= b.cap && __builtin_amdgcn_readfirstlane(st0) == ORBX_OK;
+    const bool valid = work && k0 + grp < cnt;
+    const int k = valid ? k0 + grp : (work ? k0 : 0);       // idle groups shadow the wave's first keypoint (results dropped)
+    Cand kp;
+    kp.pos = 0; kp.resp = 0.f;
+    if (work) kp = b.sel[(long long)frame * g.frame_sel + L.sel_base + k];
     for (int t = tid; t < 256; t += DESC_WAVES * 64) {
         const uint32_t pk = c_pattern[t];
         reinterpret_cast<float4*>(s_pat)[t] = make_float4((float)(int)(int8_t)pk, (float)(int)(int8_t)(pk >> 8), (float)(int)(int8_t)(pk >> 16), (float)(int)(int8_t)(pk >> 24));
@@ -1200,45 +1230,57 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
         const int um = r < 31 ? (int)((UMAX_NIBBLES >> (4 * (av & 15))) & 15ull) : -1;
         uint32_t mask = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int u = 4 * c + k - HALF_PATCH;
-            if ((u < 0 ? -u : u) <= um) mask |= 0xFFu << (8 * k);
+        for (int kk = 0; kk < 4; kk++) {
+            const int u = 4 * c + kk - HALF_PATCH;
+            if ((u < 0 ? -u : u) <= um) mask |= 0xFFu << (8 * kk);
         }
         s_mask[t] = mask;
     }
     __syncthreads();
-    const int quad = wgi * DESC_WAVES + wave_id();
     if (quad == 0 && lane == 0) {
-        int total = 0;
-        for (int l = 0; l < g.nlevels; l++) total += counts[l];
-        int st = b.status[frame];
-        if (total > b.cap) { st = ORBX_ERR_CAPACITY; total = 0; }
-        b.out_n[frame] = st == ORBX_OK ? total : 0;
+        int st = st0, tot = total;
+        if (tot > b.cap) { st = ORBX_ERR_CAPACITY; tot = 0; }
+        b.out_n[frame] = st == ORBX_OK ? tot : 0;
         if (b.out_status) b.out_status[frame] = st;
     }
-    if (quad >= g.nquads) return;
-    const int level = __builtin_amdgcn_readfirstlane(find_level(g.quad_bases, quad));
-    // the level's geometry as scalars (wave-uniform by construction; pinned so that nothing is re-read through per-lane addresses)
-    const LevelGeom& LG = g.lv[level];
-    struct { int w, h, stride, plane_off, sel_base, quad_base; float scale, kp_size; } L = {
-        __builtin_amdgcn_readfirstlane(LG.w), __builtin_amdgcn_readfirstlane(LG.h), __builtin_amdgcn_readfirstlane(LG.stride),
-        __builtin_amdgcn_readfirstlane(LG.plane_off), __builtin_amdgcn_readfirstlane(LG.sel_base), __builtin_amdgcn_readfirstlane(LG.quad_base),
-        __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, LG.scale))),
-        __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, LG.kp_size)))};
-    const int cnt = __builtin_amdgcn_readfirstlane(counts[level]);
-    const int k0 = (quad - L.quad_base) * DESC_KPW;
-    if (k0 >= cnt) return;
-    int out_base = 0, total = 0;
-    for (int l = 0; l < g.nlevels; l++) { if (l < level) out_base += counts[l]; total += counts[l]; }
-    if (total > b.cap || b.status[frame] != ORBX_OK) return;
-    const bool valid = k0 + grp < cnt;
-    const int k = valid ? k0 + grp : k0;                    // idle groups shadow the wave's first keypoint (results dropped)
-    const Cand kp = b.sel[(long long)frame * g.frame_sel + L.sel_base + k];
+    if (!work) return;
     const int x = kp.pos & 0xFFFF, y = kp.pos >> 16;
     const uint8_t* plain;
     unsigned pstride;                                        // rows < 2^24 bytes, planes < 2^31 bytes (host-checked)
     if (level == 0) { pstride = (unsigned)b.img_row_stride; plain = b.img + (long long)frame * b.img_frame_stride; }
     else { pstride = (unsigned)L.stride; plain = b.pyr + (long long)frame * g.frame_plane_bytes + L.plane_off; }
+    const uint8_t* blur = b.blur + (long long)frame * g.frame_plane_bytes + L.plane_off;
+    // rounded pattern offsets never exceed 18 px (|(-13,-13)| = 18.4): keypoints at least 19 px from every edge — all but the
+    // outermost ring of candidates — take the branch-free path with the window in LDS
+    const bool interior = x >= 19 && y >= 19 && x < L.w - 19 && y < L.h - 19;
+    {
+        // window of keypoint q: rows y-18 .. y+18, 40 bytes from the aligned start at or left of x-18, row after row (pitch 40 = 10
+        // dwords), i.e. 370 consecutive LDS dwords: 6 global_load_lds_dword of the whole wave per keypoint (lane i of instruction n
+        // fetches dword e = 64 n + i: row e / 10, column e % 10; the lane offsets are the same for the four keypoints).  A row's last
+        // dword may reach past the level's last pixel: it stays inside the blurred plane (rows are padded to 64, a next row exists)
+        // and those bytes are never tapped.
+        typedef const void __attribute__((address_space(1))) * gptr_t;
+        typedef void __attribute__((address_space(3))) * lptr_t;
+        unsigned eoff[6];
+#pragma unroll
+        for (int n = 0; n < 6; n++) {
+            const unsigned e = 64u * n + (unsigned)lane, er = (e * 205u) >> 11;           // e / 10 for e < 1029
+            eoff[n] = __umul24(er, (unsigned)L.stride) + 4u * (e - 10u * er);
+        }
+        uint8_t* win0 = s_win + wave_id() * DESC_KPW * DESC_WIN_BYTES;
+#pragma unroll
+        for (int q = 0; q < DESC_KPW; q++) {
+            const unsigned posq = (unsigned)__builtin_amdgcn_readlane((int)kp.pos, 16 * q);
+            const bool inq = __builtin_amdgcn_readlane((int)interior, 16 * q) != 0;
+            if (!inq || (q > 0 && k0 + q >= cnt)) continue;                              // wave-uniform
+            const int xq = posq & 0xFFFF, yq = posq >> 16;
+            const uint8_t* srcq = blur + __umul24((unsigned)(yq - 18), (unsigned)L.stride) + (unsigned)((xq - 18) & ~3);
+#pragma unroll
+            for (int n = 0; n < 6; n++)
+                if (n < 5 || lane < DESC_WIN_ROWS * 10 - 320)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(srcq + eoff[n]), (lptr_t)(win0 + q * DESC_WIN_BYTES + 256 * n), 4, 0, 0);
+        }
+    }
 
     // IC_Angle on the unblurred level (:705-706 run before the blur)
     int m10, m01;
@@ -1272,32 +1314,13 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float sn, cs;
     sincosf_orb(angle * factorPI, &sn, &cs);
-    const uint8_t* blur = b.blur + (long long)frame * g.frame_plane_bytes + L.plane_off;
-    // rounded pattern offsets never exceed 18 px (|(-13,-13)| = 18.4): keypoints at least 19 px from every edge — all but the
-    // outermost ring of candidates — take the branch-free path
-    const bool interior = x >= 19 && y >= 19 && x < L.w - 19 && y < L.h - 19;
     const float4* pat = reinterpret_cast<const float4*>(s_pat) + li;
     uint32_t mybits = 0;                                        // bit j: test li + 16 j
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the wave's window DMA has landed (issued before IC_Angle)
+    wave_lds_fence();                                           // the windows are private to this wave: no workgroup barrier
     if (interior) {
-        // window rows y-18 .. y+18, bytes from the aligned start at or left of x-18; the last dword of a row may be clamped to
-        // the level's last dword (its out-of-row bytes lie beyond x+18 and are never tapped)
-        uint8_t* win = s_win + (wave_id() * DESC_KPW + grp) * DESC_WIN_BYTES;
+        const uint8_t* win = s_win + (wave_id() * DESC_KPW + grp) * DESC_WIN_BYTES;
         const int xa = (x - 18) & ~3;
-        const int dmax = ((L.w - 1) & ~3) - xa;                 // last readable dword, as a byte offset from xa
-        const uint8_t* src = blur + __umul24((unsigned)(y - 18), (unsigned)L.stride) + (unsigned)xa;
-        int row = li >= 10 ? 1 : 0, col = li >= 10 ? li - 10 : li;          // dword e = li + 16 i of the 37 x 10 window: e / 10, e % 10
-        uint32_t wv[24];
-#pragma unroll
-        for (int i = 0; i < 24; i++) {
-            const int rr = imin(row, DESC_WIN_ROWS - 1);
-            wv[i] = *reinterpret_cast<const uint32_t*>(src + __umul24((unsigned)rr, (unsigned)L.stride) + (unsigned)imin(4 * col, dmax));
-            col += 6; row += 1;
-            if (col >= 10) { col -= 10; row += 1; }
-        }
-#pragma unroll
-        for (int i = 0; i < 24; i++)
-            if (li + 16 * i < DESC_WIN_ROWS * 10) reinterpret_cast<uint32_t*>(win)[li + 16 * i] = wv[i];
-        wave_lds_fence();                                       // the window is private to this wave: no workgroup barrier
         const uint8_t* ctr = win + 18 * DESC_WIN_PITCH + (x - xa);
 #pragma unroll
         for (int j = 0; j < 16; j++) {
