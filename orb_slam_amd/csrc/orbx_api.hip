@@ -30,7 +30,7 @@ struct orbx_extractor {
     Cand *d_cand = nullptr, *d_sel = nullptr;
     CellState* d_cstate = nullptr;
     CellSel* d_csel = nullptr;
-    int32_t *d_level_total = nullptr, *d_level_count = nullptr, *d_status = nullptr;
+    int32_t *d_level_total = nullptr, *d_level_count = nullptr, *d_status = nullptr, *d_long_cells = nullptr;
     // single-frame staging for orbx_extract
     uint8_t* d_img1 = nullptr;
     size_t img1_bytes = 0;
@@ -72,7 +72,7 @@ static void free_geometry(orbx_extractor* h) {
     dev_free(h->d_cells); dev_free(h->d_bands); dev_free(h->d_tabx); dev_free(h->d_taby); dev_free(h->d_pyr_tab);
     dev_free(h->d_pyr); dev_free(h->d_blur);
     dev_free(h->d_cand); dev_free(h->d_sel); dev_free(h->d_cstate); dev_free(h->d_csel);
-    dev_free(h->d_level_total); dev_free(h->d_level_count); dev_free(h->d_status);
+    dev_free(h->d_level_total); dev_free(h->d_level_count); dev_free(h->d_status); dev_free(h->d_long_cells);
     h->gw = h->gh = 0;
     h->have_last = false;
 }
@@ -111,6 +111,8 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
     HIPCHK(h, hipMemset(h->d_level_total, 0, B * MAX_LEVELS * sizeof(int32_t)));
     HIPCHK(h, hipMemset(h->d_level_count, 0, B * MAX_LEVELS * sizeof(int32_t)));
     HIPCHK(h, hipMalloc(&h->d_status, B * sizeof(int32_t)));
+    HIPCHK(h, hipMalloc(&h->d_long_cells, (1 + B * g.ncells_total) * sizeof(int32_t)));
+    HIPCHK(h, hipMemset(h->d_long_cells, 0, sizeof(int32_t)));
     HIPCHK(h, hipDeviceSynchronize());
     h->gw = w;
     h->gh = hgt;
@@ -121,7 +123,7 @@ static void fill_batch(orbx_extractor* h, Batch& b) {
     b.g = h->hg.g; b.cells = h->d_cells; b.bands = h->d_bands; b.tabx = h->d_tabx; b.taby = h->d_taby; b.pyr_tab = h->d_pyr_tab;
     b.pyr = h->d_pyr; b.blur = h->d_blur;
     b.cand = h->d_cand; b.sel = h->d_sel; b.cstate = h->d_cstate; b.csel = h->d_csel;
-    b.level_total = h->d_level_total; b.level_count = h->d_level_count; b.status = h->d_status;
+    b.level_total = h->d_level_total; b.level_count = h->d_level_count; b.status = h->d_status; b.long_cells = h->d_long_cells;
 }
 
 extern "C" {

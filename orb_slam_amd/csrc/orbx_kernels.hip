@@ -777,6 +777,7 @@ __global__ __launch_bounds__(64) void k_quota(Batch b) {
     if (lane == 0) {
         if (bad) b.status[frame] = ORBX_ERR_CAPACITY;
         b.level_total[frame * MAX_LEVELS + level] = bad ? 0 : total;
+        if (blockIdx.x == 0) b.long_cells[0] = 0;              // k_cell_select's list of long cells starts empty
     }
 }
 
@@ -888,9 +889,12 @@ __device__ float harris_response(const uint8_t* img, long long step, int x, int 
 
 // One wave per (frame, cell): ordered __ballot filter of the cell's list at its threshold into LDS, Harris responses
 // in parallel when selected, wave_nth_element, first nToRetain entries out.
-// Launched twice: lists of up to SEL_SMALL entries with a small LDS footprint (many waves per CU — the common case),
-// longer ones with the full staging area; each launch skips the cells of the other class.
+// k_cell_select: four cells per workgroup (one-wave workgroups made the launch dispatch-bound: 151 k workgroups per 1024 VGA frames,
+// ~95 us even when every wave exits at once), each wave with a staging area of SEL_SMALL entries (the common case; small LDS
+// footprint, many waves per CU).  A cell whose list is longer is appended to Batch::long_cells and taken by k_cell_select_long,
+// a small fixed grid of one-wave workgroups with the full staging area that walks that (usually empty) list.
 constexpr int SEL_SMALL = 384;
+__host__ __device__ constexpr int sel_wave_bytes(int entries) { return (entries * ((int)sizeof(Cand) + 4) + 16 + 15) & ~15; }
 // one wave; returns false when the cell's list belongs to the other length class (it did nothing)
 __device__ __forceinline__ bool cell_select_body(const Batch& b, int frame, int cell, int level, uint8_t* smem, int lds_entries, int min_entries, int lane) {
     const DevGeom& g = b.g;
@@ -958,11 +962,27 @@ __device__ __forceinline__ bool cell_select_body(const Batch& b, int frame, int 
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_cell_select(Batch b, int lds_entries, int min_entries) {
+__global__ __launch_bounds__(256) void k_cell_select(Batch b, int lds_entries) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const DevGeom& g = b.g;
-    const int frame = blockIdx.x / g.ncells_total, cell = blockIdx.x - frame * g.ncells_total;
-    (void)cell_select_body(b, frame, cell, find_level(g.cell_bases, cell), smem, lds_entries, min_entries, (int)threadIdx.x);
+    const int wave = wave_id(), lane = (int)threadIdx.x & 63;
+    const int id = (int)blockIdx.x * 4 + wave;
+    if (id >= b.nframes * g.ncells_total) return;
+    const int frame = id / g.ncells_total, cell = id - frame * g.ncells_total;
+    if (!cell_select_body(b, frame, cell, find_level(g.cell_bases, cell), smem + wave * sel_wave_bytes(lds_entries), lds_entries, 0, lane) && lane == 0)
+        b.long_cells[1 + atomicAdd(&b.long_cells[0], 1)] = id;
+}
+
+__global__ __launch_bounds__(64) void k_cell_select_long(Batch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const DevGeom& g = b.g;
+    const int n = b.long_cells[0];
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int id = b.long_cells[1 + i];
+        const int frame = id / g.ncells_total, cell = id - frame * g.ncells_total;
+        (void)cell_select_body(b, frame, cell, find_level(g.cell_bases, cell), smem, g.sel_lds_entries, 0, (int)threadIdx.x);
+        wave_lds_fence();
+    }
 }
 
 // reference :697-701 (per-level cap), same scheme; one wave
@@ -1500,15 +1520,19 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     if (stop_after == ST_QUOTA) return ORBX_OK;
     {
         StageScope sc(timer, stream, ST_CELL_SELECT);
-        const size_t lds = (size_t)g.sel_lds_cell;
-        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cell_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ORBX_ERR_DEVICE;
-        // two launches by list length (short lists with a small LDS footprint: many waves per CU); a launch group too small to fill
-        // the chip takes ONE launch with the full staging area instead (a dependent launch costs more than the occupancy gains)
+        // a launch group too small to fill the chip takes ONE launch with the full staging area per wave (a dependent launch costs
+        // more than the occupancy gains); otherwise short lists first, then the (usually empty) list of long cells
         const int small = F < PYR_FUSED_MAX_FRAMES ? g.sel_lds_entries : std::min(SEL_SMALL, g.sel_lds_entries);
-        hipLaunchKernelGGL(k_cell_select, dim3(F * g.ncells_total), dim3(64), (size_t)small * (sizeof(Cand) + 4) + 16, stream, b, small, 0);
+        const size_t lds = (size_t)4 * sel_wave_bytes(small);
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cell_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ORBX_ERR_DEVICE;
+        hipLaunchKernelGGL(k_cell_select, dim3((F * g.ncells_total + 3) / 4), dim3(256), lds, stream, b, small);
         ORBX_LAUNCH_CHECK();
-        if (small < g.sel_lds_entries) hipLaunchKernelGGL(k_cell_select, dim3(F * g.ncells_total), dim3(64), lds, stream, b, g.sel_lds_entries, small + 1);
-        ORBX_LAUNCH_CHECK();
+        if (small < g.sel_lds_entries) {
+            const size_t ldsl = (size_t)sel_wave_bytes(g.sel_lds_entries);
+            if (ldsl > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cell_select_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsl) != hipSuccess) return ORBX_ERR_DEVICE;
+            hipLaunchKernelGGL(k_cell_select_long, dim3(std::min(F * g.ncells_total, 1024)), dim3(64), ldsl, stream, b);
+            ORBX_LAUNCH_CHECK();
+        }
     }
     if (stop_after == ST_CELL_SELECT) return ORBX_OK;
     {
