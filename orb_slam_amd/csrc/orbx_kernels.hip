@@ -1376,22 +1376,25 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
             mybits |= (uint32_t)(val[0] < val[1]) << j;
         }
     }
-    unsigned long long words[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) words[j] = __ballot((mybits >> j) & 1u);
+    // Lane li of a group holds the outcomes of the tests li, li + 16, ..., li + 240 in bits 0..15; descriptor halfword j is bit j of
+    // the 16 lanes: a 16 x 16 bit-matrix transpose inside the group, four butterfly stages (partner lane ^ s by ds_swizzle, the LDS
+    // crossbar; keep half of the own bits, take the other half from the partner shifted by s).  (16 ballots and a 16-way select of
+    // SGPR pairs took ~130 instructions; this takes ~30.)
+    uint32_t half = mybits;
+    auto stage = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        constexpr uint32_t M0 = s == 8 ? 0x00FFu : s == 4 ? 0x0F0Fu : s == 2 ? 0x3333u : 0x5555u;     // bit positions with (pos & s) == 0
+        const bool hi = (li & s) != 0;
+        const uint32_t y = (uint32_t)__builtin_amdgcn_ds_swizzle((int)half, (s << 10) | 0x1F);        // lane ^ s
+        const uint32_t ysh = hi ? (y >> s) : (y << s);
+        const uint32_t mk = hi ? (~M0 & 0xFFFFu) : M0;
+        half = (half & mk) | (ysh & ~mk & 0xFFFFu);
+    };
+    stage(std::integral_constant<int, 8>{}); stage(std::integral_constant<int, 4>{});
+    stage(std::integral_constant<int, 2>{}); stage(std::integral_constant<int, 1>{});
     if (!valid) return;
     const int out_idx = out_base + k;
-    {
-        // test t = li + 16 j is bit li of descriptor halfword j: halfword j of group grp = bits 16 grp .. of ballot j; lane li stores halfword li
-        uint32_t half = 0;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint32_t w32 = grp >= 2 ? (uint32_t)(words[j] >> 32) : (uint32_t)words[j];
-            if (li == j) half = w32;
-        }
-        half = (half >> (16 * (grp & 1))) & 0xFFFFu;
-        reinterpret_cast<uint16_t*>(b.out_desc + ((long long)frame * b.cap + out_idx) * 32)[li] = (uint16_t)half;
-    }
+    reinterpret_cast<uint16_t*>(b.out_desc + ((long long)frame * b.cap + out_idx) * 32)[li] = (uint16_t)half;   // lane li stores halfword li
     if (li == 0) {
         orbx_keypoint o;
         o.x = (float)x; o.y = (float)y;
