@@ -119,7 +119,10 @@ int orbs_list_search_batch_device(const orbs_params* prm, const orbx_keypoint* d
  * mvLevelSigma2 (nlevels <= ORBS_MAX_LEVELS).  d_kps1 / d_qdesc / d_qvalid are pKF1's undistorted keypoints, descriptors and
  * "has no MapPoint yet" flags in feature order (query q uses slot d_qindex[q]); d_claimed marks pKF2's features that already
  * hold a MapPoint.  Outputs as in orbs_list_search_batch_device: d_q2t[q] = vMatches12[idx1] for query position q; d_best = the
- * BestDist of the query's candidate list (INT_MAX when empty), d_second = the distance of the match taken (INT_MAX none). */
+ * BestDist of the query's candidate list (INT_MAX when empty), d_second = the distance of the match taken (INT_MAX none).
+ * Precondition: within one vocabulary node the train list ascends in feature index (true for the fv_feat of
+ * orbv_transform_batch_device): distance ties are broken by list position here, by (distance, idx2) in the reference's sorted
+ * vDistIndex — the two agree exactly when the list is in index order. */
 int orbs_triangulation_search_batch_device(const orbs_params* prm, const float* d_F12, const float* level_sigma2, int nlevels,
                                            const orbx_keypoint* d_kps2, const uint8_t* d_desc2, const int32_t* d_list, const int32_t* d_nlist,
                                            const int32_t* d_nt, int cap, const uint8_t* d_claimed, const int32_t* d_qrange, const int32_t* d_qindex,
