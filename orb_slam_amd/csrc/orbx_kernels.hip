@@ -3,12 +3,13 @@
 // launch cost is amortised over the batch and the 256 CUs always see >> 256 workgroups.
 //
 // Stage            reference (under /root/reference/src/ORBextractor.cc)        kernel
-//   pyramid        ComputePyramid :781-822 (cv::resize INTER_LINEAR)             k_resize (per level, 7 launches)
-//   FAST + NMS     cv::FAST(cell, th, true) :607/:613 + raster-ordered cell lists  k_fast_cells (one workgroup per grid cell)
-//   quotas         :622-670                                                      k_quota      (one wave per level; lane 0 runs the sequential rule)
-//   retainBest     :683-685 (per cell), :697-701 (per level)                     k_cell_select / k_level_select (wave-parallel, permutation-exact introselect)
-//   blur           GaussianBlur 7x7 s=2 :760                                     k_blur
-//   orientation    IC_Angle :124-151, descriptor :155-194, scaling :769-775      k_describe   (one wave per keypoint)
+//   pyramid        ComputePyramid :781-822 (cv::resize INTER_LINEAR)             k_resize (per level, 7 launches) | k_pyramid (cones of levels, 2 launches; < 32 frames)
+//   FAST + NMS     cv::FAST(cell, th, true) :607/:613 + raster-ordered cell lists  k_fast_cells (one workgroup per grid-cell row band)
+//   quotas         :622-670                                                      k_quota      (one wave per level; a pass of the rule = one sweep of the lanes + two reductions)
+//   retainBest     :683-685 (per cell), :697-701 (per level)                     k_cell_select (+ _long) / k_level_select (wave-parallel, permutation-exact introselect)
+//   blur           GaussianBlur 7x7 s=2 :760                                     k_blur       (inside k_fast_blur for < 32 frames)
+//   orientation    IC_Angle :124-151, descriptor :155-194, scaling :769-775      k_describe   (one wave per four keypoints)
+// The one-frame drop-in call also has k_ingest (the staged frame fetched from pinned host memory by a kernel).
 //
 // No 16-px border planes exist on the device: the only out-of-image reads of the reference (blur
 // taps <= 3 px, rotated BRIEF taps <= 2 px outside the ROI) are served by reflect-101 index math,
@@ -1533,7 +1534,8 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         if (small < g.sel_lds_entries) {
             const size_t ldsl = (size_t)sel_wave_bytes(g.sel_lds_entries);
             if (ldsl > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cell_select_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsl) != hipSuccess) return ORBX_ERR_DEVICE;
-            hipLaunchKernelGGL(k_cell_select_long, dim3(std::min(F * g.ncells_total, 1024)), dim3(64), ldsl, stream, b);
+            // enough one-wave workgroups to fill the chip when the list is long (noise-like frames: most cells), cheap when it is empty
+            hipLaunchKernelGGL(k_cell_select_long, dim3(std::min(F * g.ncells_total, 8192)), dim3(64), ldsl, stream, b);
             ORBX_LAUNCH_CHECK();
         }
     }

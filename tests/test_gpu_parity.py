@@ -383,3 +383,21 @@ def test_xcd_affinity_block_renumbering(gpu_extractor_factory):
             assert n[f] == len(ok), (nb, f)
             _assert_kps_equal(kps[f, :n[f]].copy().view(capi.KP_DTYPE).reshape(-1), ok)
             np.testing.assert_array_equal(desc[f, :n[f]], od)
+
+
+def test_single_frame_copy_engine_path(monkeypatch):
+    """orbx_extract normally fetches the staged frame with a kernel and lets k_describe write the results straight into pinned host
+    memory; ORBX_ZERO_COPY=0 (read at orbx_create) takes DMA copies both ways instead.  Both forms, same handle reused over sizes,
+    against the oracle."""
+    for zc in ("0", "1"):
+        monkeypatch.setenv("ORBX_ZERO_COPY", zc)
+        ex = capi.ORBextractor(nfeatures=500)
+        try:
+            for (w, h, fam, idx) in ((640, 480, synth.BLOCKS, 3), (322, 246, synth.NOISE, 4), (752, 480, synth.LOWTEX, 5), (640, 480, synth.BLOCKS, 6)):
+                img = synth.frame(w, h, fam, idx)
+                ok, od = orc.OracleExtractor(nfeatures=500)(img)
+                gk, gd = ex(img)
+                _assert_kps_equal(gk, ok)
+                np.testing.assert_array_equal(gd, od)
+        finally:
+            ex.close()
