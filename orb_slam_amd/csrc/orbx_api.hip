@@ -111,8 +111,7 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
     HIPCHK(h, hipMemset(h->d_level_total, 0, B * MAX_LEVELS * sizeof(int32_t)));
     HIPCHK(h, hipMemset(h->d_level_count, 0, B * MAX_LEVELS * sizeof(int32_t)));
     HIPCHK(h, hipMalloc(&h->d_status, B * sizeof(int32_t)));
-    HIPCHK(h, hipMalloc(&h->d_long_cells, (1 + B * g.ncells_total) * sizeof(int32_t)));
-    HIPCHK(h, hipMemset(h->d_long_cells, 0, sizeof(int32_t)));
+    HIPCHK(h, hipMalloc(&h->d_long_cells, (B * g.ncells_total + 64) * sizeof(int32_t)));
     HIPCHK(h, hipDeviceSynchronize());
     h->gw = w;
     h->gh = hgt;

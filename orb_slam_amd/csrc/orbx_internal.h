@@ -171,7 +171,7 @@ struct Batch {
     int32_t* level_total;     // [frame][MAX_LEVELS]  keypoints gathered from the cells
     int32_t* level_count;     // [frame][MAX_LEVELS]  after the per-level cap
     int32_t* status;          // [frame]
-    int32_t* long_cells;      // [1 + frames * ncells_total]: a count, then frame * ncells_total + cell of the cells whose lists exceed the short staging area (k_cell_select)
+    int32_t* long_cells;      // [frame][ncells_total]  1: the cell's list exceeds k_cell_select's short staging area (k_cell_select_long takes it)
     orbx_keypoint* out_kps;   // [frame][cap]
     uint8_t* out_desc;        // [frame][cap][32]
     int32_t* out_n;           // [frame]

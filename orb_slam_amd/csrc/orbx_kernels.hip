@@ -778,7 +778,6 @@ __global__ __launch_bounds__(64) void k_quota(Batch b) {
     if (lane == 0) {
         if (bad) b.status[frame] = ORBX_ERR_CAPACITY;
         b.level_total[frame * MAX_LEVELS + level] = bad ? 0 : total;
-        if (blockIdx.x == 0) b.long_cells[0] = 0;              // k_cell_select's list of long cells starts empty
     }
 }
 
@@ -892,8 +891,8 @@ __device__ float harris_response(const uint8_t* img, long long step, int x, int 
 // in parallel when selected, wave_nth_element, first nToRetain entries out.
 // k_cell_select: four cells per workgroup (one-wave workgroups made the launch dispatch-bound: 151 k workgroups per 1024 VGA frames,
 // ~95 us even when every wave exits at once), each wave with a staging area of SEL_SMALL entries (the common case; small LDS
-// footprint, many waves per CU).  A cell whose list is longer is appended to Batch::long_cells and taken by k_cell_select_long,
-// a small fixed grid of one-wave workgroups with the full staging area that walks that (usually empty) list.
+// footprint, many waves per CU).  A cell whose list is longer is flagged in Batch::long_cells and taken by k_cell_select_long
+// (one-wave workgroups with the full staging area, each looking after 8 consecutive cells).
 constexpr int SEL_SMALL = 384;
 __host__ __device__ constexpr int sel_wave_bytes(int entries) { return (entries * ((int)sizeof(Cand) + 4) + 16 + 15) & ~15; }
 // one wave; returns false when the cell's list belongs to the other length class (it did nothing)
@@ -970,18 +969,28 @@ __global__ __launch_bounds__(256) void k_cell_select(Batch b, int lds_entries) {
     const int id = (int)blockIdx.x * 4 + wave;
     if (id >= b.nframes * g.ncells_total) return;
     const int frame = id / g.ncells_total, cell = id - frame * g.ncells_total;
-    if (!cell_select_body(b, frame, cell, find_level(g.cell_bases, cell), smem + wave * sel_wave_bytes(lds_entries), lds_entries, 0, lane) && lane == 0)
-        b.long_cells[1 + atomicAdd(&b.long_cells[0], 1)] = id;
-}
+    const bool done = cell_select_body(b, frame, cell, find_level(g.cell_bases, cell), smem + wave * sel_wave_bytes(lds_entries), lds_entries, 0, lane);
+    if (lane == 0) b.long_cells[id] = done ? 0 : 1;          // a flag per cell: no list, no atomics (one counter for ~150 k long cells of a
+}                                                            // noise-like batch serialised for 1.3 ms, 64 sharded ones still for 0.5)
 
+// the cells k_cell_select left over (lists beyond its staging area): a wave looks at the flags of SEL_LONG_CHUNK consecutive cells
+// and takes the flagged ones with the full staging area.  Normally none is flagged and the launch is ~10 k workgroups that exit.
+#ifndef ORBX_SEL_LONG_CHUNK
+#define ORBX_SEL_LONG_CHUNK 8
+#endif
+constexpr int SEL_LONG_CHUNK = ORBX_SEL_LONG_CHUNK;
 __global__ __launch_bounds__(64) void k_cell_select_long(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const DevGeom& g = b.g;
-    const int n = b.long_cells[0];
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const int id = b.long_cells[1 + i];
+    const int lane = (int)threadIdx.x, total = b.nframes * g.ncells_total;
+    const int id0 = (int)blockIdx.x * SEL_LONG_CHUNK;
+    const bool mine = lane < SEL_LONG_CHUNK && id0 + lane < total && b.long_cells[id0 + lane] != 0;
+    unsigned long long m = __ballot(mine);
+    while (m) {
+        const int id = id0 + __ffsll((long long)m) - 1;
+        m &= m - 1;
         const int frame = id / g.ncells_total, cell = id - frame * g.ncells_total;
-        (void)cell_select_body(b, frame, cell, find_level(g.cell_bases, cell), smem, g.sel_lds_entries, 0, (int)threadIdx.x);
+        (void)cell_select_body(b, frame, cell, find_level(g.cell_bases, cell), smem, g.sel_lds_entries, 0, lane);
         wave_lds_fence();
     }
 }
@@ -1534,8 +1543,7 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         if (small < g.sel_lds_entries) {
             const size_t ldsl = (size_t)sel_wave_bytes(g.sel_lds_entries);
             if (ldsl > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cell_select_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsl) != hipSuccess) return ORBX_ERR_DEVICE;
-            // enough one-wave workgroups to fill the chip when the list is long (noise-like frames: most cells), cheap when it is empty
-            hipLaunchKernelGGL(k_cell_select_long, dim3(std::min(F * g.ncells_total, 8192)), dim3(64), ldsl, stream, b);
+            hipLaunchKernelGGL(k_cell_select_long, dim3((F * g.ncells_total + SEL_LONG_CHUNK - 1) / SEL_LONG_CHUNK), dim3(64), ldsl, stream, b);
             ORBX_LAUNCH_CHECK();
         }
     }
