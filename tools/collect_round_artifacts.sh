@@ -1,9 +1,11 @@
 #!/bin/bash
-# Everything profiles/ is built from, in one go on the GPU box.  usage: tools/collect_round_artifacts.sh <name>   (-> gpurun_out/<name>, gpurun_out/<name>_pmc)
+# Everything profiles/ is built from, in one go on the GPU box.  usage: tools/collect_round_artifacts.sh <name> [lines]   (-> gpurun_out/<name>, gpurun_out/<name>_pmc)
+# `lines` skips the counter passes (profiles/traffic.json and valu_mix.json must already carry this build's hash) and only re-runs the bench lines.
 # Order: counter passes first (profiles/traffic.json of THIS build — it carries the library's source hash — is what bench.py replays for the
 # VALU-issue roofline and roofline.hbm.traffic), then the bench lines.
 R=${GRAFT_REPO_ROOT:-/root/repo}; D=$R/gpurun_out/$1; mkdir -p $D; cd /tmp; export TMPDIR=/tmp
 B=1024      # bench.py's default frames per step = frames per launch of the serial command
+if [ "$2" != "lines" ]; then
 SER="--steps 10 --warmup 2 --no-cpu-baseline --lanes 1 --region-timing --min-seconds 0"
 # serial command (one stream, one launch per kernel over all B frames): kernel-trace stats and the two HBM counter passes
 ORBX_OVERLAP=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats -- python $R/bench.py $SER > $D/stats.log 2>&1
@@ -12,8 +14,10 @@ ORBX_OVERLAP=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-fo
 $R/tools/run_pmc.sh $1_pmc
 python $R/tools/pmc_traffic.py $D/fetch_counter_collection.csv $D/write_counter_collection.csv $R/profiles/traffic.json $B $R/gpurun_out/$1_pmc 256 > $D/traffic.log 2>&1
 cp $R/profiles/traffic.json $D/traffic.json
+(cd $R && python tools/valu_mix.py > $D/valu_mix.log 2>&1; cp profiles/valu_mix.json $D/valu_mix.json)
 python $R/tools/pmc_table.py $R/gpurun_out/$1_pmc/a_counter_collection.csv $R/gpurun_out/$1_pmc/b_counter_collection.csv > $D/pmc_sq_counters.txt 2>&1
 python $R/tools/pmc_table.py $D/fetch_counter_collection.csv $D/write_counter_collection.csv > $D/pmc_fetch_write.txt 2>&1
+fi
 # the default command (4 lanes) under the kernel trace, then the bench lines proper
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_overlap -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --min-seconds 0 > $D/stats_overlap.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_match -- python $R/bench.py --config match100k --steps 5 --warmup 2 --no-cpu-baseline --min-seconds 0 > $D/stats_match.log 2>&1
