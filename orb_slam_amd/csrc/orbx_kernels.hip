@@ -1178,10 +1178,10 @@ __global__ __launch_bounds__(BLUR_WAVES * 64) void k_blur(Batch b) {
 // them side by side in ONE launch: the first blocks of a frame blur short strips (4 waves = 4 strips), the rest are cell bands.
 // (Two streams would do the same for a full batch - launch_extract forks there - but a fork / join across hardware queues costs
 // ~8 us each way, as much as either kernel takes on one frame.)
-template <bool ALIGNED>
-__global__ __launch_bounds__(FAST_SMALL.threads) void k_fast_blur(Batch b) {
+template <bool ALIGNED, bool SMALL>
+__global__ __launch_bounds__(SMALL ? FAST_SMALL.threads : FAST_LARGE.threads) void k_fast_blur(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr FastShape A = FAST_SMALL;
+    constexpr FastShape A = SMALL ? FAST_SMALL : FAST_LARGE;
     constexpr int NW = A.threads / 64;
     const DevGeom& g = b.g;
     const int nblur = (g.nbtiles_total_s + NW - 1) / NW;
@@ -1493,7 +1493,7 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     // (a launch group that cannot fill the chip keeps the blur in line: its short strips take ~6 us, the fork and the join across
     //  two hardware queues cost 8 us each)
     const bool overlap = side && side->aux && stop_after < 0 && F >= PYR_FUSED_MAX_FRAMES;
-    const bool fuse_blur = F < PYR_FUSED_MAX_FRAMES && g.fast_small && !b.xcd_affinity;    // k_fast_blur
+    const bool fuse_blur = F < PYR_FUSED_MAX_FRAMES && !b.xcd_affinity;    // k_fast_blur
     {
         StageScope sc(timer, stream, ST_FAST_CELLS);
         const bool aligned = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
@@ -1506,13 +1506,15 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         constexpr FastShape A = FAST_SMALL, B = FAST_LARGE;
         bool ok;
         if (fuse_blur) {
-            const int per_frame = (g.nbtiles_total_s + A.threads / 64 - 1) / (A.threads / 64) + g.nbands_total;
+            const int threads = g.fast_small ? A.threads : B.threads;
+            const int per_frame = (g.nbtiles_total_s + threads / 64 - 1) / (threads / 64) + g.nbands_total;
             auto launch2 = [&](auto kern) -> bool {
                 if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-                hipLaunchKernelGGL(kern, dim3(F * per_frame), dim3(A.threads), lds, stream, b);
+                hipLaunchKernelGGL(kern, dim3(F * per_frame), dim3(threads), lds, stream, b);
                 return true;
             };
-            ok = aligned ? launch2(k_fast_blur<true>) : launch2(k_fast_blur<false>);
+            if (g.fast_small) ok = aligned ? launch2(k_fast_blur<true, true>) : launch2(k_fast_blur<false, true>);
+            else ok = aligned ? launch2(k_fast_blur<true, false>) : launch2(k_fast_blur<false, false>);
         } else if (g.fast_small) ok = aligned ? launch(k_fast_cells<true, A.threads, A.ppt>, A.threads) : launch(k_fast_cells<false, A.threads, A.ppt>, A.threads);
         else ok = aligned ? launch(k_fast_cells<true, B.threads, B.ppt>, B.threads) : launch(k_fast_cells<false, B.threads, B.ppt>, B.threads);
         if (!ok) return ORBX_ERR_DEVICE;
