@@ -940,15 +940,23 @@ __device__ __forceinline__ bool cell_select_body(const Batch& b, int frame, int 
     for (int k = 0; k < cgeo.nbands; k++) {
         const Cand* bc = lbase + bgs[k].cand_off;
         const int nb = bst[k].n_all;
-        for (int base = 0; base < nb; base += 64) {
-            const int i = base + lane;
-            Cand e;
-            e.pos = 0; e.resp = -1.f;
-            if (i < nb) e = bc[i];
-            const bool pass = i < nb && e.resp >= thr;
-            const unsigned long long mk = __ballot(pass);
-            if (pass) lst[m + __popcll(mk & lt)] = e;
-            m += __popcll(mk);
+        for (int base = 0; base < nb; base += 256) {           // four loads in flight per lane, then the ordered filter chunk by chunk
+            Cand e4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = base + 64 * k + lane;
+                e4[k].pos = 0; e4[k].resp = -1.f;
+                if (i < nb) e4[k] = bc[i];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (base + 64 * k >= nb) break;
+                const int i = base + 64 * k + lane;
+                const bool pass = i < nb && e4[k].resp >= thr;
+                const unsigned long long mk = __ballot(pass);
+                if (pass) lst[m + __popcll(mk & lt)] = e4[k];
+                m += __popcll(mk);
+            }
         }
     }
     wave_lds_fence();
@@ -1011,7 +1019,14 @@ __device__ __forceinline__ void level_select_body(const Batch& b, int frame, int
                 Cand* lst = reinterpret_cast<Cand*>(smem);
                 uint16_t* lpos = reinterpret_cast<uint16_t*>(smem + (size_t)g.sel_lds_entries * sizeof(Cand));
                 uint16_t* rpos = lpos + g.sel_lds_entries;
-                for (int i = lane; i < total; i += 64) lst[i] = v[i];
+                // four loads in flight per lane (one per iteration made the gather a chain of round trips: 7 for a VGA level 0)
+                for (int i0 = 0; i0 < total; i0 += 256) {
+                    Cand e[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const int i = i0 + 64 * k + lane; if (i < total) e[k] = v[i]; }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const int i = i0 + 64 * k + lane; if (i < total) lst[i] = e[k]; }
+                }
                 wave_lds_fence();
                 wave_nth_element(lst, 0, n, total, lpos, rpos, lane);
                 for (int i = lane; i < n; i += 64) v[i] = lst[i];
