@@ -331,6 +331,7 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
                     "pricing": "SQ_INSTS_VALU of the kernel (profiles/traffic.json) priced with its static opcode mix (profiles/valu_mix.json): 2 cycles per "
                                "wave64 instruction for mov/add/sub/and/or/xor/bitop3/right shifts/f32 add-mul-fma, 4 for every other measured opcode "
                                "(profiles/r01_valu_issue_rates.txt, r02_valu_issue_rates2.txt)",
+                    "traffic": hbm.get("traffic"),      # HBM-side bytes per launch of this kernel (PMC), as in roofline.hbm
                     "hbm": hbm}
     out = {
         "metric": "frames/s ORB %s @%dx%d, %d kp" % ("extract+match" if do_match else "extract", w, h, nfeat),
@@ -452,7 +453,8 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
                 "avg_launch_ms": round(kernel_ms, 4), "pairs_per_launch": float(nq) * n,
                 "timing": "HIP events on the launch stream around the %d calls of the timed region (split + merge kernel per call)" % nsteps,
                 "hbm": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 6),
-                        "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 6), "algorithmic_bytes_per_launch": a_match, "traffic": None}}
+                        "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 6), "algorithmic_bytes_per_launch": a_match, "traffic": None},
+                "traffic": None}
     out = {
         "metric": "pairs/s Hamming top-2, %d x %d 256-bit descriptors" % (n, n),
         "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "repeats": repeats, "timed_steps": nsteps,
