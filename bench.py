@@ -133,18 +133,18 @@ def cpu_baseline_allcores(w, h, nfeat, do_match, seconds):
             "sample": "%d worker processes x %.0f s, one oracle extractor each, %d frames in all" % (workers, seconds, sum(n for n, _ in res))}
 
 
-def load_replayed_counters(build_id):
+def load_replayed_counters(build_id, traffic_file="traffic.json"):
     """profiles/traffic.json (rocprofv3 --pmc passes over the serial command) and profiles/valu_mix.json (static opcode mix) carry
     the hash of the kernel sources they were measured on; they are used only when it equals the loaded library's."""
     out = {"traffic": None, "mix": None, "note": None}
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))
         if tj.get("src_hash") == build_id:
             out["traffic"] = tj
         else:
-            out["note"] = "profiles/traffic.json was measured on other kernel sources (hash %s, library %s): not replayed" % (tj.get("src_hash"), build_id)
+            out["note"] = "profiles/%s was measured on other kernel sources (hash %s, library %s): not replayed" % (traffic_file, tj.get("src_hash"), build_id)
     except Exception as e:
-        out["note"] = "profiles/traffic.json unreadable: %s" % e
+        out["note"] = "profiles/%s unreadable: %s" % (traffic_file, e)
     try:
         mj = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
         if mj.get("src_hash") == build_id:
@@ -298,10 +298,13 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
     value = total_frames / tmax
 
     # counters replayed from profiles/ (PMC passes cannot run inside this process): only when measured on THIS build
-    rep = load_replayed_counters(capi.build_id())
+    # the two workloads with committed counter passes: VGA / 1000 (profiles/traffic.json) and 1080p / 2000 (profiles/traffic_hd1080.json)
+    wl_tag = {(640, 480, 1000, 1): "vga_640x480_nf1000", (1920, 1080, 2000, 1): "hd_1920x1080_nf2000"}.get((w, h, nfeat, a.family))
+    traffic_file = "traffic_hd1080.json" if wl_tag == "hd_1920x1080_nf2000" else "traffic.json"
+    rep = load_replayed_counters(capi.build_id(), traffic_file)
     traffic, valu_insts, valu_launch = None, None, None
     tj = rep["traffic"]
-    same_workload = tj is not None and tj.get("workload") == "vga_640x480_nf1000" and (w, h, nfeat, a.family) == (640, 480, 1000, 1)
+    same_workload = tj is not None and wl_tag is not None and tj.get("workload") == wl_tag
     if same_workload:
         if tj.get("batch") == B:
             traffic = tj.get("per_launch_bytes", {}).get(dom)
@@ -313,12 +316,14 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
            "frac_of_achievable": round(dom_gbs / HBM_ACHIEVABLE_GBS, 5), "achievable_peak": HBM_ACHIEVABLE_GBS, "traffic": traffic,
            "algorithmic_bytes_per_launch": dom_bytes,
            "traffic_note": "HBM-side (FETCH_SIZE + WRITE_SIZE) * 1024 per launch of this kernel, rocprofv3 --pmc passes over the serial command "
-                           "(profiles/traffic.json; replayed only when its source hash equals the library's)" if traffic else rep["note"]}
+                           "(profiles/%s; replayed only when its source hash equals the library's)" % traffic_file if traffic else rep["note"]}
     timing = ("serial pass after the timed region: 10 steps, one launch per kernel over all %d frames, nothing else on the chip "
               "(HIP events on the launch stream)" % B) if concurrent else "timed region (one stream)"
     roofline = dict(hbm)
     roofline.update({"kernel": dom, "avg_launch_ms": round(stage_ms[dom], 4), "frames_per_launch": B, "timing": timing})
     mix = rep["mix"]
+    if mix and wl_tag == "hd_1920x1080_nf2000" and "fast_cells_large" in mix:
+        mix = dict(mix, fast_cells=mix["fast_cells_large"])       # 1080p grids take the 512-thread work-item shape of k_fast_cells
     if valu_launch and mix and dom in mix:
         # The resource that binds this integer path is VALU issue, not HBM (SURVEY.md §8d predicted it, the counters confirm it): the
         # dominant kernel's wave-level VALU instructions per launch / its duration, against 1024 SIMDs x 2.4 GHz / (cycles per instruction).

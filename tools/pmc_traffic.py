@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes as the TCC
 block cannot hold both).  Per-launch HBM-side bytes per kernel = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (the counters are
-in KiB).  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half the bytes of a streaming read.  Calibrated
+in KiB).  usage: pmc_traffic.py fetch.csv write.csv out.json batch [sq_dir [sq_batch [workload]]]  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half the bytes of a streaming read.  Calibrated
 here for the access widths of these kernels (tools/microbench/fetch_calib, profiles/r02_fetch_calibration.txt): coalesced
 1, 4 and 16 B-per-lane reads of 1 GiB all report exactly 0.500; WRITE_SIZE is exact (1.000); 32-byte runs 640 B apart (a
 keypoint patch row) report the 64-byte lines they touch (2.0 x the unique bytes).  So reads are doubled for every kernel;
@@ -53,7 +53,7 @@ if len(sys.argv) > 5:
     frames = len(insts.get("k_fast_cells", [])) * sq_batch
     if frames:
         per_frame = {STAGE[k]: round(sum(v) / frames, 1) for k, v in insts.items() if k in STAGE}
-json.dump({"workload": "vga_640x480_nf1000", "src_hash": capi.build_id(), "batch": batch, "sq_activity": valu, "valu_wave_insts_per_frame": per_frame,
+json.dump({"workload": sys.argv[7] if len(sys.argv) > 7 else "vga_640x480_nf1000", "src_hash": capi.build_id(), "batch": batch, "sq_activity": valu, "valu_wave_insts_per_frame": per_frame,
            "per_launch_bytes": per_launch, "detail": detail,
            "read_correction": "FETCH_SIZE x 2 (gfx950: streaming reads of 1, 4 and 16 B per lane all report exactly half, tools/microbench/fetch_calib); WRITE_SIZE as is",
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py"}, open(out, "w"), indent=1)
