@@ -84,7 +84,9 @@ typedef struct orbs_params {
 /* LDS bytes one problem needs (the train frame is staged in LDS); ORBX_ERR_CAPACITY from the search when this exceeds
  * what a gfx950 workgroup can have (160 KiB).  cap = 1000 / qcap = 1000 needs ~60 KiB.  Up to ~2850 train features the
  * descriptors are staged too; larger frames keep them in global memory (25 instead of 57 bytes of LDS per feature), which
- * carries a problem to ~6500 train features — e.g. the 4000-feature initialisation extractor of an nFeatures = 2000 setup. */
+ * carries a problem to ~6500 train features — e.g. the 4000-feature initialisation extractor of an nFeatures = 2000 setup.
+ * (The grid searches of frames up to ~2400 features add a level-bucketed index, 16 KiB more than this function reports; larger
+ * frames are searched without it.  Same results either way.) */
 size_t orbs_lds_bytes(int cap, int qcap);
 
 /* Outputs per problem: d_q2t[qcap] the train feature each query is finally matched to (-1 none), d_t2q[cap] the query each

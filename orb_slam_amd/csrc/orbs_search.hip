@@ -30,12 +30,23 @@ namespace orbs {
 constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 constexpr int HISTO_LENGTH = 30;             // src/ORBmatcher.cc:42
 
-struct Layout { uint32_t off16, tx, ty, tang, tmeta, tdesc, state, claim, t2q, q2t, binv, hist, epi, total; };
+struct Layout { uint32_t off16, tx, ty, tang, tmeta, tdesc, state, claim, t2q, q2t, binv, hist, epi, rank16, r2s, total; };
+
+// Level-bucketed index of the grid searches (round 2).  A query asks for the features of a window AND of a level range
+// (Frame::GetFeaturesInArea's minLevel / maxLevel): with the plain 64 x 48 CSR a same-level query at r = 100 walks ~140 entries
+// to find the ~18 of its level, and every one costs three scattered LDS reads before the octave test rejects it.  The staged frame
+// is therefore ordered by (level bucket, coarse column, coarse row) - coarse cell = 2 x 2 grid cells - with one offset per
+// bucket, so a query walks, per level of its range and per coarse column of its window, one contiguous run.  Which entries it
+// VISITS changes; what it accepts does not: the exact window / level test still runs on every visited entry, and a candidate's
+// key carries its position in the reference's CSR order (rank16), not its LDS slot, so ties break as before.
+constexpr int BK_LEVELS = 8;                           // levels >= 7 share the last bucket (the exact octave test sorts them out)
+constexpr int BK_COLS = ORBF_GRID_COLS / 2, BK_ROWS = ORBF_GRID_ROWS / 2, BK_CELLS = BK_COLS * BK_ROWS;
+constexpr int BK_N = BK_LEVELS * BK_CELLS;             // buckets; the offset table has BK_N + 2 entries (see stage_bucketed)
 
 // desc_in_lds: the train descriptors (32 of the ~57 bytes a staged feature costs) are staged too; frames too large for that
 // (beyond ~2850 features) leave them in global memory — the candidates of a window then gather 32 bytes each through L2 — which
 // carries the capacity to ~6500 features per problem (an initialisation extractor of 4000 features fits).
-__host__ __device__ inline Layout make_layout(int cap, int qcap, bool desc_in_lds) {
+__host__ __device__ inline Layout make_layout(int cap, int qcap, bool desc_in_lds, bool bucketed = false) {
     auto al = [](uint32_t x) { return (x + 15u) & ~15u; };
     Layout L;
     uint32_t o = 0;
@@ -44,7 +55,7 @@ __host__ __device__ inline Layout make_layout(int cap, int qcap, bool desc_in_ld
     L.ty = o; o += al((uint32_t)cap * 4);
     L.tang = o; o += al((uint32_t)cap * 4);
     L.tmeta = o; o += al((uint32_t)cap * 4);
-    L.off16 = o; o += al((ORBF_GRID_CELLS + 1) * 2);
+    L.off16 = o; o += al((uint32_t)((bucketed ? BK_N + 2 : ORBF_GRID_CELLS + 1) * 2));   // (BK_N + 2 > ORBF_GRID_CELLS + 1: the fine offsets are staged here first)
     L.state = o; o += al((uint32_t)cap * 2);
     L.claim = o; o += al((uint32_t)cap * 4);
     L.t2q = o; o += al((uint32_t)cap * 2);
@@ -52,6 +63,8 @@ __host__ __device__ inline Layout make_layout(int cap, int qcap, bool desc_in_ld
     L.binv = o; o += al((uint32_t)(cap > qcap ? cap : qcap));
     L.hist = o; o += 32 * 4;
     L.epi = o; o += ORBS_MAX_LEVELS * 4;
+    L.rank16 = o; o += bucketed ? al((uint32_t)cap * 2) : 0u;
+    L.r2s = o; o += bucketed ? al((uint32_t)cap * 2) : 0u;
     L.total = o;
     return L;
 }
@@ -76,6 +89,7 @@ struct Args {
     int32_t* nmatches;
     int cap, qcap;
     int desc_in_lds;
+    int bucketed;              // grid mode with the level-bucketed index (make_layout(.., true))
     // list mode (orbs_list_search_batch_device): cell_feat is the candidate list, nlist its length, qrange the per-query runs
     const int32_t* nlist;
     const int32_t* qrange;
@@ -139,6 +153,7 @@ struct Staged {
     const float* epi_thr;
     const uint8_t* gdesc;      // the problem's train descriptors in global memory (read by feature index when !desc_lds)
     bool desc_lds;
+    const uint16_t* rank16;    // bucketed index: the slot's position in the reference's CSR order (the low half of its key)
 };
 __device__ __forceinline__ void staged_desc(const Staged& S, int j, uint32_t meta, uint4& t0, uint4& t1) {
     if (S.desc_lds) { t0 = S.tdesc[2 * j]; t1 = S.tdesc[2 * j + 1]; }
@@ -175,6 +190,7 @@ __device__ __forceinline__ uint32_t hamming_key(const uint4& t0, const uint4& t1
 // KEY_NONE when it is in the window but claimed; `inwin` says whether it was in the window at all.
 // ORBS_RULE_TRIANGULATION: admissible = unclaimed && distance <= th; bit 15 of the key says whether the candidate also lies on
 // the query's epipolar line (list positions stay below 2^15: the staged frame has to fit the LDS).
+template <bool BK>
 __device__ __forceinline__ uint32_t candidate_key(const Staged& S, int rule, int j, float x, float y, float r, int minLevel, int maxLevel,
                                                   const uint4& q0, const uint4& q1, const EpiLine& E, bool& inwin) {
     const uint32_t meta = S.tmeta[j];
@@ -196,18 +212,57 @@ __device__ __forceinline__ uint32_t candidate_key(const Staged& S, int rule, int
     staged_desc(S, j, meta, t0, t1);
     const uint32_t dist = hamming_key(t0, t1, q0, q1);
     if (rule == ORBS_RULE_INIT && st <= dist) return KEY_NONE;                      // `if(vMatchedDistance[i2]<=dist) continue;`
-    return (dist << 16) | (uint32_t)j;
+    return (dist << 16) | (BK ? (uint32_t)S.rank16[j] : (uint32_t)j);
+}
+
+// level buckets a query's level range can hold entries in (Frame::GetFeaturesInArea: no check when both are -1; with a check and
+// maxLevel < minLevel nothing passes)
+__device__ __forceinline__ void bk_levels(int minLevel, int maxLevel, int& lb0, int& lb1) {
+    if (minLevel == -1 && maxLevel == -1) { lb0 = 0; lb1 = BK_LEVELS - 1; return; }
+    lb0 = min(max(minLevel, 0), BK_LEVELS - 1);
+    lb1 = maxLevel < minLevel ? lb0 - 1 : min(max(maxLevel, 0), BK_LEVELS - 1);
+    if (maxLevel < 0) lb1 = lb0 - 1;
+}
+
+// packed 16-bit counters in LDS (two per dword): add v to entry idx, return its old value (entries stay below 65536)
+__device__ __forceinline__ uint32_t add16(uint16_t* base, int idx, uint32_t v) {
+    const int sh = (idx & 1) * 16;
+    const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(base) + (idx >> 1), v << sh);
+    return (old >> sh) & 0xFFFFu;
 }
 
 // The whole wave scans ONE query's window (8 grid columns at a time, 8 lanes per column) under the current claim state and
 // reduces to the two smallest keys: the in-order fallback for queries whose speculative result was overtaken by a claim.
+template <bool BK>
 __device__ __forceinline__ void scan_wave(const Staged& S, int rule, bool list_mode, int lane, int x0, int x1, int y0, int y1, float x, float y, float r,
                                           int minLevel, int maxLevel, const uint4& q0, const uint4& q1, const EpiLine& E, uint32_t& k1, uint32_t& k2) {
     uint32_t a1 = KEY_NONE, a2 = KEY_NONE;
+    if (BK) {                                          // (level bucket, coarse column) pairs, 8 at a time, 8 lanes per run
+        int lb0, lb1;
+        bk_levels(minLevel, maxLevel, lb0, lb1);
+        const int cx0 = x0 >> 1, cy0 = y0 >> 1, cy1 = y1 >> 1, ncol = (x1 >> 1) - cx0 + 1;
+        const int npair = x1 >= x0 ? (lb1 - lb0 + 1) * ncol : 0;
+        for (int p0 = 0; p0 < npair; p0 += 8) {
+            const int pi = p0 + (lane >> 3);
+            int j = 0, jend = 0;
+            if (pi < npair) {
+                const int lv = pi / ncol, base = (lb0 + lv) * BK_CELLS + (cx0 + pi - lv * ncol) * BK_ROWS;
+                j = S.off16[base + cy0] + (lane & 7);
+                jend = S.off16[base + cy1 + 1];
+            }
+            for (; j < jend; j += 8) {
+                bool inwin;
+                const uint32_t key = candidate_key<true>(S, rule, j, x, y, r, minLevel, maxLevel, q0, q1, E, inwin);
+                a2 = min(a2, max(a1, key));
+                a1 = min(a1, key);
+            }
+        }
+        x1 = x0 - 1;
+    }
     if (list_mode) {                                   // one explicit run [y0, y1): all 64 lanes stride it
         for (int j = y0 + lane; j < y1; j += 64) {
             bool inwin;
-            const uint32_t key = candidate_key(S, rule, j, x, y, r, minLevel, maxLevel, q0, q1, E, inwin);
+            const uint32_t key = candidate_key<false>(S, rule, j, x, y, r, minLevel, maxLevel, q0, q1, E, inwin);
             if (rule == ORBS_RULE_TRIANGULATION) a2 = min(a2, (key & 0x8000u) ? key : KEY_NONE);      // a2 = best candidate ON the line
             else a2 = min(a2, max(a1, key));
             a1 = min(a1, key);
@@ -223,7 +278,7 @@ __device__ __forceinline__ void scan_wave(const Staged& S, int rule, bool list_m
         }
         for (; j < jend; j += 8) {
             bool inwin;
-            const uint32_t key = candidate_key(S, rule, j, x, y, r, minLevel, maxLevel, q0, q1, E, inwin);
+            const uint32_t key = candidate_key<false>(S, rule, j, x, y, r, minLevel, maxLevel, q0, q1, E, inwin);
             a2 = min(a2, max(a1, key));          // branch-free two-smallest update (a1 <= a2)
             a1 = min(a1, key);
         }
@@ -267,9 +322,10 @@ __device__ __forceinline__ bool accept_rule(const orbs_params& prm, int bestDist
 //      With little contention a wave commits its 64 queries in two or three rounds.
 constexpr int GROUP = 256;
 
+template <bool BK>
 __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_params prm, Args a) {
     extern __shared__ __align__(16) uint8_t lds[];
-    const Layout L = make_layout(a.cap, a.qcap, a.desc_in_lds != 0);
+    const Layout L = make_layout(a.cap, a.qcap, a.desc_in_lds != 0, BK);
     uint16_t* off16 = (uint16_t*)(lds + L.off16);
     float* tx = (float*)(lds + L.tx);
     float* ty = (float*)(lds + L.ty);
@@ -284,12 +340,14 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
     uint8_t* binv = lds + L.binv;
     int* hist = (int*)(lds + L.hist);
     float* epi_thr = (float*)(lds + L.epi);
+    uint16_t* rank16 = (uint16_t*)(lds + L.rank16);      // BK only
+    uint16_t* r2s = (uint16_t*)(lds + L.r2s);            // BK only: CSR position -> LDS slot
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int nt = min(a.nt[p], a.cap), nq = min(a.nq[p], a.qcap);
     const int rule = prm.rule;
     const size_t tb = (size_t)p * a.cap, qb = (size_t)p * a.qcap;
-    const Staged S{off16, tx, ty, tmeta, tdesc, state, epi_thr, a.desc + tb * 32, desc_lds};
-    const bool list_mode = a.qrange != nullptr;
+    const Staged S{off16, tx, ty, tmeta, tdesc, state, epi_thr, a.desc + tb * 32, desc_lds, rank16};
+    const bool list_mode = !BK && a.qrange != nullptr;
     const int32_t* coff = a.cell_off + (size_t)p * (ORBF_GRID_CELLS + 1);
     const int32_t* cfeat = a.cell_feat + tb;
     const orbx_keypoint* kps = a.kps_un + tb;
@@ -297,6 +355,60 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
     // ---- stage the train frame in LDS, in grid (or list) order
     if (!list_mode) for (int i = tid; i <= ORBF_GRID_CELLS; i += GROUP) off16[i] = (uint16_t)min(coff[i], a.cap);
     const int m = list_mode ? max(min(a.nlist[p], a.cap), 0) : min(coff[ORBF_GRID_CELLS], a.cap);
+    if (BK) {
+        // counting sort of the CSR entries into (level bucket, coarse column, coarse row) order, all in LDS:
+        //  (a) every entry's bucket, from the cell the caller's CSR files it under (r2s[] holds it for now);
+        //  (b) counts: entry b + 2 of the table; an inclusive prefix sum turns entry b + 1 into bucket b's start;
+        //  (c) scatter with a fetch-add on entry b + 1, which ends as bucket b's end = bucket b + 1's start: the table is then
+        //      T[x] = start of bucket x for x = 0 .. BK_N (T[BK_N] = m), what the scans index.  Slots inside a bucket are handed out
+        //      in atomic order; nothing depends on it (keys carry the CSR position, rank16).
+        __syncthreads();
+        for (int c = tid; c < ORBF_GRID_CELLS; c += GROUP) {
+            const int cx = c / ORBF_GRID_ROWS, cy = c - cx * ORBF_GRID_ROWS;
+            const int cc = (cx >> 1) * BK_ROWS + (cy >> 1);
+            for (int j = off16[c]; j < min((int)off16[c + 1], m); ++j) {
+                const int f = min(max(cfeat[j], 0), max(nt - 1, 0));
+                r2s[j] = (uint16_t)(min(max(kps[f].octave, 0), BK_LEVELS - 1) * BK_CELLS + cc);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < (BK_N + 2 + 1) / 2; i += GROUP) reinterpret_cast<uint32_t*>(off16)[i] = 0u;
+        __syncthreads();
+        for (int j = tid; j < m; j += GROUP) (void)add16(off16, r2s[j] + 2, 1u);
+        __syncthreads();
+        {
+            constexpr int CH = (BK_N + 2 + GROUP - 1) / GROUP;
+            int sum = 0;
+            for (int k = 0; k < CH; ++k) { const int i = tid * CH + k; if (i < BK_N + 2) sum += off16[i]; }
+            int incl = sum;
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+            if (lane == 63) hist[wave] = incl;
+            __syncthreads();
+            int run = incl - sum;
+            for (int w = 0; w < wave; ++w) run += hist[w];
+            for (int k = 0; k < CH; ++k) { const int i = tid * CH + k; if (i < BK_N + 2) { run += off16[i]; off16[i] = (uint16_t)run; } }
+        }
+        __syncthreads();
+        for (int j = tid; j < m; j += GROUP) {
+            const int slot = (int)add16(off16, r2s[j] + 1, 1u);
+            const int f = min(max(cfeat[j], 0), max(nt - 1, 0));
+            const orbx_keypoint kp = kps[f];
+            tx[slot] = kp.x;
+            ty[slot] = kp.y;
+            tang[slot] = kp.angle;
+            tmeta[slot] = (uint32_t)f | ((uint32_t)kp.octave << 16);
+            rank16[slot] = (uint16_t)j;
+            r2s[j] = (uint16_t)slot;
+        }
+        __syncthreads();
+        if (desc_lds)
+            for (int j = tid; j < m; j += GROUP) {
+                const uint4* d = (const uint4*)(a.desc + (tb + (tmeta[j] & 0xFFFFu)) * 32);
+                tdesc[2 * j] = d[0];
+                tdesc[2 * j + 1] = d[1];
+            }
+        __syncthreads();                                       // hist[] (scan scratch above) is zeroed below
+    } else
     for (int j = tid; j < m; j += GROUP) {
         const int f = min(max(cfeat[j], 0), max(nt - 1, 0));          // a malformed list must not index outside the frame
         const orbx_keypoint kp = kps[f];
@@ -361,22 +473,42 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
         if (!qv) wx1 = -1;
         uint32_t e0 = KEY_NONE, e1 = KEY_NONE, e2 = KEY_NONE, e3 = KEY_NONE;
         bool any = false;
+        auto take = [&](uint32_t t) {                    // insertion into the four smallest keys
+            uint32_t lo;
+            lo = min(e0, t); t = max(e0, t); e0 = lo;
+            lo = min(e1, t); t = max(e1, t); e1 = lo;
+            lo = min(e2, t); t = max(e2, t); e2 = lo;
+            e3 = min(e3, t);
+        };
+        if (BK) {
+            int lb0, lb1;
+            bk_levels(ql0, ql1, lb0, lb1);
+            const int cy0 = wy0 >> 1, cy1 = wy1 >> 1;
+            for (int lv = lb0; lv <= lb1; ++lv)
+                for (int cc = wx0 >> 1; cc <= (wx1 >> 1) && wx1 >= wx0; ++cc) {
+                    const int base = lv * BK_CELLS + cc * BK_ROWS;
+                    const int jend = off16[base + cy1 + 1];
+                    for (int j = off16[base + cy0]; j < jend; ++j) {
+                        bool inwin;
+                        const uint32_t t = candidate_key<true>(S, rule, j, qx, qy, qr, ql0, ql1, qd0, qd1, E, inwin);
+                        any |= inwin;
+                        take(t);
+                    }
+                }
+        } else
         for (int col = wx0; col <= wx1; ++col) {
             const int jend = list_mode ? wy1 : off16[col * ORBF_GRID_ROWS + wy1 + 1];
             for (int j = list_mode ? wy0 : off16[col * ORBF_GRID_ROWS + wy0]; j < jend; ++j) {
                 bool inwin;
-                uint32_t t = candidate_key(S, rule, j, qx, qy, qr, ql0, ql1, qd0, qd1, E, inwin);
+                const uint32_t t = candidate_key<false>(S, rule, j, qx, qy, qr, ql0, ql1, qd0, qd1, E, inwin);
                 any |= inwin;
-                uint32_t lo;
-                lo = min(e0, t); t = max(e0, t); e0 = lo;
-                lo = min(e1, t); t = max(e1, t); e1 = lo;
-                lo = min(e2, t); t = max(e2, t); e2 = lo;
-                e3 = min(e3, t);
+                take(t);
             }
         }
         // train index | octave << 16 of the four entries
-        const uint32_t f0 = e0 != KEY_NONE ? tmeta[e0 & pos_mask] : 0u, f1 = e1 != KEY_NONE ? tmeta[e1 & pos_mask] : 0u;
-        const uint32_t f2 = e2 != KEY_NONE ? tmeta[e2 & pos_mask] : 0u, f3 = e3 != KEY_NONE ? tmeta[e3 & pos_mask] : 0u;
+        auto slot_of = [&](uint32_t key) -> uint32_t { return BK ? (uint32_t)r2s[key & 0xFFFFu] : (key & pos_mask); };   // the staged entry a key names
+        const uint32_t f0 = e0 != KEY_NONE ? tmeta[slot_of(e0)] : 0u, f1 = e1 != KEY_NONE ? tmeta[slot_of(e1)] : 0u;
+        const uint32_t f2 = e2 != KEY_NONE ? tmeta[slot_of(e2)] : 0u, f3 = e3 != KEY_NONE ? tmeta[slot_of(e3)] : 0u;
         const uint32_t on_line = tri ? ((e0 >> 15) & 1u) | ((e1 >> 14) & 2u) | ((e2 >> 13) & 4u) | ((e3 >> 12) & 8u) : 0u;
         const bool full = e3 != KEY_NONE;              // a fifth candidate may exist
         int my_best = -1, my_second = -1;
@@ -433,7 +565,7 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
                         if (vAccept) {
                             const int q = q0 + w * 64 + lane;
                             int bin = 255;
-                            if (rot_on) bin = rot_bin(qa, tang[kc & pos_mask]);
+                            if (rot_on) bin = rot_bin(qa, tang[slot_of(kc)]);
                             if (rule == ORBS_RULE_INIT) {
                                 const int prev = t2q[bIdx];
                                 if (prev >= 0) q2t[prev] = -1;                 // vnMatches12[vnMatches21[bestIdx2]] = -1
@@ -452,11 +584,11 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
                     if (__builtin_amdgcn_readlane((int)dry, F)) {
                         // the whole wave rescans query F under the current state
                         uint32_t k1, k2;
-                        scan_wave(S, rule, list_mode, lane, __builtin_amdgcn_readlane(wx0, F), __builtin_amdgcn_readlane(wx1, F), __builtin_amdgcn_readlane(wy0, F),
+                        scan_wave<BK>(S, rule, list_mode, lane, __builtin_amdgcn_readlane(wx0, F), __builtin_amdgcn_readlane(wx1, F), __builtin_amdgcn_readlane(wy0, F),
                                   __builtin_amdgcn_readlane(wy1, F), lane_f(qx, F), lane_f(qy, F), lane_f(qr, F), __builtin_amdgcn_readlane(ql0, F),
                                   __builtin_amdgcn_readlane(ql1, F), lane_u4(qd0, F), lane_u4(qd1, F),
                                   EpiLine{lane_f(E.a, F), lane_f(E.b, F), lane_f(E.c, F), lane_f(E.den, F), prm.th}, k1, k2);
-                        const uint32_t m1 = k1 != KEY_NONE ? tmeta[k1 & pos_mask] : 0u, m2 = k2 != KEY_NONE ? tmeta[k2 & pos_mask] : 0u;
+                        const uint32_t m1 = k1 != KEY_NONE ? tmeta[slot_of(k1)] : 0u, m2 = k2 != KEY_NONE ? tmeta[slot_of(k2)] : 0u;
                         const int bestDist = k1 != KEY_NONE ? (int)(k1 >> 16) : INT_MAX, bestDist2 = k2 != KEY_NONE ? (int)(k2 >> 16) : INT_MAX;
                         const int bestIdx = (int)((tri ? m2 : m1) & 0xFFFFu);
                         const bool accept = accept_rule(prm, bestDist, bestDist2, k1 != KEY_NONE ? (int)(m1 >> 16) : -1, k2 != KEY_NONE ? (int)(m2 >> 16) : -1);
@@ -464,7 +596,7 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
                         if (accept) {
                             const int q = q0 + w * 64 + F;
                             int bin = 255;
-                            if (rot_on) bin = rot_bin(lane_f(qa, F), tang[(tri ? k2 : k1) & pos_mask]);
+                            if (rot_on) bin = rot_bin(lane_f(qa, F), tang[slot_of(tri ? k2 : k1)]);
                             if (lane == 0) {
                                 if (rule == ORBS_RULE_INIT) {
                                     const int prev = t2q[bestIdx];
@@ -567,12 +699,19 @@ __global__ __launch_bounds__(256) void k_agreement(const int32_t* __restrict__ m
 }  // namespace orbs
 
 // the kernel may use up to the whole 160 KiB of LDS: raise the dynamic-LDS limit of the current device
-static int orbs_set_lds(size_t) {
+static int orbs_set_lds(size_t, bool bucketed = false) {
     // the attribute belongs to the CURRENT device: set it on every launch path (a cheap runtime call), not once per process
-    return hipFuncSetAttribute((const void*)orbs::k_window_search, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+    const void* k = bucketed ? (const void*)orbs::k_window_search<true> : (const void*)orbs::k_window_search<false>;
+    return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
 
 extern "C" {
+
+// ORBS_BUCKETS=0 in the environment (read once): the plain 64 x 48 CSR scan for the grid searches too (A/B measurements)
+static bool orbs_use_buckets() {
+    static const bool on = [] { const char* e = getenv("ORBS_BUCKETS"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 // the layout a problem of this size gets: descriptors staged when that fits the 160 KiB of a workgroup
 static size_t orbs_choose_layout(int cap, int qcap, int& desc_in_lds) {
@@ -612,14 +751,19 @@ int orbs_window_search_batch_device(const orbf_bounds* b, const orbs_params* prm
         return ORBX_ERR_ARG;
     if (prm->check_orientation && prm->rule != ORBS_RULE_MAPPOINTS && !d_qangle) return ORBX_ERR_ARG;
     int desc_in_lds = 1;
-    const size_t lds = orbs_choose_layout(cap, qcap, desc_in_lds);
+    size_t lds = orbs_choose_layout(cap, qcap, desc_in_lds);
     if (lds > 160 * 1024) return ORBX_ERR_CAPACITY;
-    if (orbs_set_lds(lds) != ORBX_OK) return ORBX_ERR_DEVICE;
+    // the level-bucketed index (see BK_LEVELS) wherever the frame still fits with its descriptors staged
+    const size_t lds_bk = orbs::make_layout(cap, qcap, true, true).total;
+    const bool bucketed = desc_in_lds && lds_bk <= 160 * 1024 && orbs_use_buckets();
+    if (bucketed) lds = lds_bk;
+    if (orbs_set_lds(lds, bucketed) != ORBX_OK) return ORBX_ERR_DEVICE;
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
     orbs::Args a{d_kps_un, d_desc, d_cell_off, d_cell_feat, d_nt, d_claimed, d_qxyr, d_qlev, d_qdesc, d_qangle, d_qvalid, d_nq,
-                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, desc_in_lds, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
-    hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, *b, prm2, a);
+                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, desc_in_lds, bucketed ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
+    if (bucketed) hipLaunchKernelGGL(orbs::k_window_search<true>, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, *b, prm2, a);
+    else hipLaunchKernelGGL(orbs::k_window_search<false>, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, *b, prm2, a);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
 
@@ -640,9 +784,9 @@ int orbs_list_search_batch_device(const orbs_params* prm, const orbx_keypoint* d
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
     orbs::Args a{d_kps, d_desc, nullptr, d_list, d_nt, d_claimed, nullptr, nullptr, d_qdesc, d_qangle, d_qvalid, d_nq,
-                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, desc_in_lds, d_nlist, d_qrange, d_qindex, nullptr, nullptr, {}};
+                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, desc_in_lds, 0, d_nlist, d_qrange, d_qindex, nullptr, nullptr, {}};
     orbf_bounds nob{};
-    hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, nob, prm2, a);
+    hipLaunchKernelGGL(orbs::k_window_search<false>, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, nob, prm2, a);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
 
@@ -664,10 +808,10 @@ int orbs_triangulation_search_batch_device(const orbs_params* prm, const float* 
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
     orbs::Args a{d_kps2, d_desc2, nullptr, d_list, d_nt, d_claimed, nullptr, nullptr, d_qdesc, nullptr, d_qvalid, d_nq,
-                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, desc_in_lds, d_nlist, d_qrange, d_qindex, d_kps1, d_F12, {}};
+                 d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, desc_in_lds, 0, d_nlist, d_qrange, d_qindex, d_kps1, d_F12, {}};
     for (int i = 0; i < ORBS_MAX_LEVELS; ++i) a.epi_thr[i] = orbs_epipolar_bound(level_sigma2[i < nlevels ? i : nlevels - 1]);
     orbf_bounds nob{};
-    hipLaunchKernelGGL(orbs::k_window_search, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, nob, prm2, a);
+    hipLaunchKernelGGL(orbs::k_window_search<false>, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, nob, prm2, a);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
 
