@@ -127,12 +127,12 @@ __device__ __forceinline__ int fast_score_raw(const uint8_t* c, int S, int v, in
 }
 
 // ------------------------------------------------------------------------------------ pyramid
-// cv::resize INTER_LINEAR 8U, level-1 -> level.  A workgroup produces a 256x4 output tile: the source
-// rectangle it needs (<= 7 rows x ~310 px) is staged in LDS with coalesced dword loads, each lane then
-// reads its 16 taps as LDS bytes, produces 4 horizontally adjacent output pixels and stores one dword.
+// cv::resize INTER_LINEAR 8U, level-1 -> level.  A workgroup produces a 256 x RZ_ROWS output tile: the source rectangle it
+// needs (<= ~60 rows x ~310 px at scale 1.2) is staged in LDS (LDS-DMA for aligned planes), each lane then produces 4 horizontally
+// adjacent output pixels per row of its wave's RZ_ROWS / 4 consecutive rows and stores one dword per row.
 // (Byte gathers straight from global memory made this kernel texture-addresser bound.)
-// LDS source tile: L.rz_rows x L.rz_pitch bytes, the exact maximum over the level's tiles (7 KB at scale 1.2; a fixed
-// worst-case array for scale 2.5 was 31 KB and capped the kernel at 5 workgroups per CU)
+// LDS source tile: L.rz_rows x L.rz_pitch bytes, the exact maximum over the level's tiles (a fixed worst-case array for scale
+// 2.5 capped the kernel's occupancy)
 
 template <bool ALIGNED, bool WINDOW>
 __global__ __launch_bounds__(256) void k_resize(Batch b, int level) {
@@ -1066,10 +1066,11 @@ int launch_debug_nth(const float* d_resp, int n, int nth, int* d_out) {
 // ------------------------------------------------------------------------------------ blur
 // GaussianBlur 7x7 sigma 2 (8U fixed point, taps [18,34,49,55,49,34,18]/256 twice, 16 fractional bits).
 // Register-resident separable filter, no LDS: one wave owns a 248-px wide column strip and streams down
-// BLUR_ROWS output rows.  Lane j holds one dword (4 pixels) of the current row; the neighbouring dwords
-// come from lanes j-1 / j+1 by DPP wave shifts, v_alignbyte_b32 cuts the 4-byte tap windows and two
-// v_dot4_u32_u8 give a pixel's 7-tap row sum.  The last 7 row sums live in registers (loop fully unrolled),
-// so the column pass is 7 multiply-adds per pixel; each lane stores its 4 output pixels as one dword.
+// ROWS output rows.  Lane j holds one dword (4 pixels) of the current row; the neighbouring dwords
+// come from lanes j-1 / j+1 by DPP wave shifts; the 7 taps of each of the lane's pixels are byte-weight dwords over the
+// three aligned dwords (v_dot4_u32_u8, no shifted copies).  The last row sums live in registers as row pairs (loop fully
+// unrolled), so the column pass is three v_dot2_u32_u16 + one multiply-add per pixel; each lane stores its 4 output pixels as
+// one dword.  Details at blur_strip below and in DESIGN.md 4.2.
 // Reads the UNBLURRED plane and writes a separate blurred plane, which is what the reference's in-place
 // filter computes (its border taps read the unblurred reflect-101 border; here: reflect-101 index math).
 constexpr int BLUR_STRIP_DW = 62;   // useful dwords per wave (lanes 1..62; lanes 0 and 63 are halo)
@@ -1215,11 +1216,11 @@ __global__ __launch_bounds__(SMALL ? FAST_SMALL.threads : FAST_LARGE.threads) vo
 //     lane & 7 and the rows of one parity: 16 (unaligned) dword loads, the circle as byte masks from an LDS table (constant LDS
 //     offsets), two v_dot4_u32_u8 per dword (sum of (u + 15) I and sum of I), the row weight as a multiply-add; 4-step reduction.
 //   rBRIEF (:154-194): lane i of a group evaluates tests i, i + 16, ..., i + 240.  The 37 x 37 window the rotated pattern can reach
-//     (|offset| <= 18) is first copied from the blurred level into LDS with row-contiguous dword loads (10 per row): 512 scattered
+//     (|offset| <= 18) is first copied from the blurred level into LDS (LDS-DMA, 6 wave instructions per keypoint): 512 scattered
 //     byte gathers per keypoint straight from global memory kept the kernel bound by the L1's cache-line rate (one wave-load
 //     touched 40-64 lines), the LDS serves them at bank speed.  The pattern comes from an LDS table of floats (one 16-byte read
 //     per test, no unpacking); the rotated coordinates are rounded with v_rndne and the tap offset iy * pitch + ix is formed in
-//     float (exact) and converted once.  A __ballot holds 16 bits (2 descriptor bytes) of each of the wave's four keypoints.
+//     float (exact) and converted once.  The 16 x 16 test bits of a group are transposed into descriptor halfwords by ds_swizzle.
 //   Keypoints closer than 19 px to an edge may read the level's UNBLURRED reflect-101 border: their group of lanes
 //     takes its taps from global memory with the reflection in the index math.
 // Waves are formed per level (slots padded to multiples of 4), so the level is wave-uniform and its geometry scalar.
