@@ -19,7 +19,14 @@ pass after the timed region (every kernel alone on the chip).
 N > 1: one rank per GPU, every rank works on its own stream (weak scaling, no data-path collective); RCCL only takes the MAX of
 the timing and gathers the counters.  Run as a plain command it spawns its N ranks itself; under torch.distributed.run it uses
 the ranks it is given.  The timed region is `repeats` x K steps, with `repeats` chosen so that it lasts at least
-`--min-seconds` (default 2 s; 0 = exactly K steps).  Prints ONE JSON line on rank 0.
+`--min-seconds` (default 6 s, so that a 5 s device sampler must land inside it; 0 = exactly K steps).  Prints ONE JSON line on rank 0.
+
+After the timed region (never inside it) every rank compares a sample of the LAST timed step's outputs with the CPU oracle —
+every lane border from both sides, the step border, interior frames: keypoints + descriptors byte for byte, top-2 match against
+the previous frame integer for integer — and the line carries `config.parity_checked_frames` / `config.parity_mismatches`; a
+mismatch makes the process exit 1.  The default run (`--config vga`) then also runs BASELINE.json's other GPU configurations,
+`hd1080` (configs[2]; at N > 1 this is configs[3], one 1080p stream per GPU) and `match100k` (configs[4]), for >= 1.5 s each and
+embeds them under `also` (headline keys unchanged; `--no-also` skips them).
 """
 import argparse
 import json
@@ -190,6 +197,9 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
     del frames
     pipe = LanePipeline(w, h, B, lanes=a.lanes, nfeatures=nfeat, device=local_rank, do_match=do_match)   # orb_slam_amd/pipeline.py
     G, b, cap = pipe.G, pipe.b, pipe.cap
+    if a.warmup < 1:
+        raise SystemExit("--warmup must be >= 1 (first-call costs would land in the timed region)")
+    pipe.tune(d_img.data_ptr())          # explicit, blocking stream-placement probe (ORBX_LANE_PLACEMENT=k skips it); outside every timed loop
 
     def step(i, timed):
         pipe.step(d_img.data_ptr() + ((i * B) % ring) * w * h, timed=timed)
@@ -197,28 +207,49 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
     for i in range(a.warmup):
         step(i, False)
     torch.cuda.synchronize(dev)
+    # host cost of queueing one step (4 lanes x ~15 launches + the hand-off copies and events): on an idle queue, i.e. not throttled by
+    # the device — what one rank asks of its share of the host cores
+    th = time.perf_counter()
+    for i in range(2):
+        step(a.warmup + i, False)
+    host_submit_ms = (time.perf_counter() - th) * 500.0
+    torch.cuda.synchronize(dev)
     # repeats of the K-step block so that the timed region lasts >= --min-seconds: one untimed calibration block tells how long a
     # block takes (the warm-up steps carry first-call costs); every rank must run the same count
     repeats = 1
     if a.min_seconds > 0:
         tc = time.perf_counter()
         for i in range(a.steps):
-            step(a.warmup + i, False)
+            step(a.warmup + 2 + i, False)
         torch.cuda.synchronize(dev)
         tc = time.perf_counter() - tc
         repeats = max(1, int(math.ceil(a.min_seconds / max(tc, 1e-6))))
     repeats = int(dist_util.agree_max(dist, repeats, dev if a.backend == "nccl" else torch.device("cpu")))
     nsteps = repeats * a.steps
+    first = a.warmup + 2 + (a.steps if a.min_seconds > 0 else 0)      # index of the first timed step (the stream just continues)
     pipe.stage_timing(2 if a.region_timing else 0)
     dist_util.barrier(dist, a.backend, local_rank)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(nsteps):
-        step(a.warmup + i, a.region_timing)
+        step(first + i, a.region_timing)
     torch.cuda.synchronize(dev)
     dist_util.barrier(dist, a.backend, local_rank)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+
+    # parity leg (outside the timed region): the outputs the LAST timed step left on the device against the CPU oracle
+    parity = {"frames": 0, "mismatches": 0, "detail": []}
+    if not a.no_parity:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import parity_sample
+        last = first + nsteps - 1
+        i0 = dist_util.stream_first_index(rank, ring)
+
+        def host_frame(j):
+            return synth.frame(w, h, a.family, i0 + (last * B + j) % ring)
+
+        parity = parity_sample.check_step(pipe, host_frame, parity_sample.sample_indices(B, G), nfeat)
 
     stage = pipe.stage_times()
     pipe.stage_timing(0)
@@ -278,9 +309,12 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
         return ms1
 
     # RCCL: the only collectives of the run (MAX of the timing, all-gather of the counters)
-    tmax, counters, rows = dist_util.reduce_run(dist, elapsed, [nsteps * B, kp_mean * nsteps * B, bad_status, elapsed],
+    tmax, counters, rows = dist_util.reduce_run(dist, elapsed, [nsteps * B, kp_mean * nsteps * B, bad_status, elapsed, parity["frames"],
+                                                                parity["mismatches"], host_submit_ms],
                                                 dev if a.backend == "nccl" else torch.device("cpu"))
+    placement = pipe.placement
     if rank != 0:
+        pipe.close()
         return None
     total_frames = float(counters[0])
     a_extract, a_match, per_stage = algorithmic_bytes(w, h, nfeat)
@@ -315,29 +349,29 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
     hbm = {"bound": "hbm", "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 5),
            "frac_of_achievable": round(dom_gbs / HBM_ACHIEVABLE_GBS, 5), "achievable_peak": HBM_ACHIEVABLE_GBS, "traffic": traffic,
            "algorithmic_bytes_per_launch": dom_bytes,
-           "traffic_note": "HBM-side (FETCH_SIZE + WRITE_SIZE) * 1024 per launch of this kernel, rocprofv3 --pmc passes over the serial command "
-                           "(profiles/%s; replayed only when its source hash equals the library's)" % traffic_file if traffic else rep["note"]}
+           "traffic_note": "HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, in KB) of one launch of this kernel over all %d frames, rocprofv3 --pmc passes "
+                           "over the serial command (profiles/%s; replayed only when its source hash equals the library's)" % (B, traffic_file)
+                           if traffic else rep["note"]}
     timing = ("serial pass after the timed region: 10 steps, one launch per kernel over all %d frames, nothing else on the chip "
               "(HIP events on the launch stream)" % B) if concurrent else "timed region (one stream)"
+    # `roofline` follows the contract: the dominant kernel's ALGORITHMIC bytes per launch / its average launch
+    # duration against the HBM peak, `traffic` = PMC-measured HBM bytes per launch.  The resource that actually binds this integer
+    # kernel is VALU issue (SURVEY.md §8d predicted it, the counters confirm it); that model rides along as roofline.valu_issue.
     roofline = dict(hbm)
     roofline.update({"kernel": dom, "avg_launch_ms": round(stage_ms[dom], 4), "frames_per_launch": B, "timing": timing})
     mix = rep["mix"]
     if mix and wl_tag == "hd_1920x1080_nf2000" and "fast_cells_large" in mix:
         mix = dict(mix, fast_cells=mix["fast_cells_large"])       # 1080p grids take the 512-thread work-item shape of k_fast_cells
     if valu_launch and mix and dom in mix:
-        # The resource that binds this integer path is VALU issue, not HBM (SURVEY.md §8d predicted it, the counters confirm it): the
-        # dominant kernel's wave-level VALU instructions per launch / its duration, against 1024 SIMDs x 2.4 GHz / (cycles per instruction).
         cpi = mix[dom]["cycles_per_inst_lo"]
         ach = valu_launch / (stage_ms[dom] * 1e-3)
         peak = SIMD_CYCLES_PER_S / cpi
-        roofline = {"bound": "valu_issue", "kernel": dom, "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-insts/s",
-                    "frac": round(ach / peak, 4), "wave_insts_per_launch": int(valu_launch), "cycles_per_inst": cpi,
-                    "avg_launch_ms": round(stage_ms[dom], 4), "frames_per_launch": B, "timing": timing,
-                    "pricing": "SQ_INSTS_VALU of the kernel (profiles/traffic.json) priced with its static opcode mix (profiles/valu_mix.json): 2 cycles per "
-                               "wave64 instruction for mov/add/sub/and/or/xor/bitop3/right shifts/f32 add-mul-fma, 4 for every other measured opcode "
-                               "(profiles/r01_valu_issue_rates.txt, r02_valu_issue_rates2.txt)",
-                    "traffic": hbm.get("traffic"),      # HBM-side bytes per launch of this kernel (PMC), as in roofline.hbm
-                    "hbm": hbm}
+        roofline["valu_issue"] = {
+            "bound": "valu_issue", "kernel": dom, "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-insts/s",
+            "frac": round(ach / peak, 4), "wave_insts_per_launch": int(valu_launch), "cycles_per_inst": cpi,
+            "pricing": "SQ_INSTS_VALU of the kernel (profiles/%s) priced with its static opcode mix (profiles/valu_mix.json): 2 cycles per "
+                       "wave64 instruction for mov/add/sub/and/or/xor/bitop3/right shifts/f32 add-mul-fma, 4 for every other measured opcode "
+                       "(profiles/r01_valu_issue_rates.txt, r02_valu_issue_rates2.txt)" % traffic_file}
     out = {
         "metric": "frames/s ORB %s @%dx%d, %d kp" % ("extract+match" if do_match else "extract", w, h, nfeat),
         "value": round(value, 1),
@@ -361,7 +395,12 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
                    "frames_per_step_per_gpu": B, "resident_frames_per_gpu": ring,
                    "parallelism": "one image stream per GPU; a step's %d frames go through %d lanes of %d consecutive frames "
                                   "(own extractor handle + HIP stream each), frame-to-frame matches across lane borders via event-ordered hand-off" % (B, G, b),
-                   "lanes": G, "lane_placement": pipe.placement,
+                   "lanes": G, "lane_placement": placement,
+                   "parity_checked_frames": int(counters[4]), "parity_mismatches": int(counters[5]),
+                   "parity_note": "outputs of the LAST timed step vs the CPU oracle, after the timed region, on every rank: first + last frame of every lane, "
+                                  "the step border, interior frames; keypoints + descriptors byte-equal, top-2 match vs the previous frame integer-equal",
+                   "parity_detail": parity["detail"],
+                   "host_submit_ms_per_step": round(float(counters[6]) / world, 4),
                    "mean_keypoints_per_frame": round(float(counters[1]) / total_frames, 2),
                    "frames_with_error_status": int(counters[2]), "accepted_matches_last_frame": accepted,
                    "library_build_id": capi.build_id()},
@@ -389,6 +428,9 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
         out["roofline_note"] = rep["note"]
     if a.region_timing:
         out["stage_ms_per_launch_timed_region"] = {k: round(v, 4) for k, v in region_ms.items()}
+    pipe.close()
+    del d_img
+    torch.cuda.empty_cache()
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, h, nfeat, do_match, a.cpu_seconds)
         if a.cpu_allcores_seconds > 0:
@@ -440,9 +482,32 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
     dist_util.barrier(dist, a.backend, local_rank)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    kernel_ms = e0.elapsed_time(e1) / nsteps            # split + merge kernels of one call, HIP events on the launch stream
+    region_ms = e0.elapsed_time(e1) / nsteps            # split + merge kernels of one call, averaged over the timed region (calls back to back)
+    # steady-state duration of ONE call: 30 further calls, each between its own pair of HIP events on the launch stream
+    # (the r02 rocprof summary held 7 cold calls and disagreed with the region average; min / median / max are reported,
+    # the roofline uses the MEDIAN)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+    for ea, eb in evs:
+        ea.record(s)
+        step()
+        eb.record(s)
+    torch.cuda.synchronize(dev)
+    per_call = sorted(ea.elapsed_time(eb) for ea, eb in evs)
+    kernel_ms = per_call[len(per_call) // 2]
     checksum = int(out3[1, :nq].sum().item()) if nq else 0
-    tmax, counters, rows = dist_util.reduce_run(dist, elapsed, [float(nq) * n * nsteps, checksum, elapsed],
+    # parity leg (outside the timed region): sampled query rows of the last call against the oracle's sequential scan
+    checked, mism = 0, 0
+    if not a.no_parity and nq:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as orc
+        import numpy as np
+        rows_ = np.unique(np.linspace(0, nq - 1, 64).astype(np.int64))
+        got = out3[:, :nq].cpu().numpy()[:, rows_]
+        Tn_ = synth.descriptors(n, 2)
+        ri, rb, rs = orc.match_top2(np.ascontiguousarray(Qall[q0:q0 + nq][rows_]), Tn_)
+        checked = len(rows_)
+        mism = int((got[0] != ri).sum() + (got[1] != rb).sum() + (got[2] != rs).sum())
+    tmax, counters, rows = dist_util.reduce_run(dist, elapsed, [float(nq) * n * nsteps, checksum, elapsed, checked, mism],
                                                 dev if a.backend == "nccl" else torch.device("cpu"))
     if rank != 0:
         return None
@@ -456,7 +521,10 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
                 "achieved": round(tops, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s (int8 multiply-accumulates x 2)", "frac": round(tops / I8_MFMA_PEAK_TOPS, 4),
                 "peak_note": "dense int8 MFMA = 2 x the 2.5 PFLOP/s bf16 dense peak; tools/microbench/valu_rate2 measures 4470 TOP/s for v_mfma_i32_32x32x32_i8",
                 "avg_launch_ms": round(kernel_ms, 4), "pairs_per_launch": float(nq) * n,
-                "timing": "HIP events on the launch stream around the %d calls of the timed region (split + merge kernel per call)" % nsteps,
+                "per_call_ms": {"min": round(per_call[0], 4), "median": round(kernel_ms, 4), "max": round(per_call[-1], 4), "calls": len(per_call),
+                                "timed_region_average": round(region_ms, 4)},
+                "timing": "median of 30 steady-state calls after the timed region, each between its own HIP events on the launch stream (split + "
+                          "merge kernel per call); timed_region_average = one event pair around the %d back-to-back calls of the timed region" % nsteps,
                 "hbm": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 6),
                         "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 6), "algorithmic_bytes_per_launch": a_match, "traffic": None},
                 "traffic": None}
@@ -467,7 +535,9 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
         "scaling": "strong", "vs_baseline": None, "dtype": "i8 (+-1 encoded bits, i32 accumulate)" if mfma else "u32 xor + popcount", "data": "synthetic",
         "config": {"workload": "match100k: batched N-to-M descriptor match, %d x %d random 256-bit descriptors, dense top-2 (BASELINE.json configs[4])" % (n, n),
                    "queries_per_gpu": nq, "train_descriptors": n, "parallelism": "queries sharded by rank, train set replicated, no exchange",
-                   "best_distance_checksum": int(counters[1]), "library_build_id": capi.build_id()},
+                   "best_distance_checksum": int(counters[1]), "parity_checked_rows": int(counters[3]), "parity_mismatches": int(counters[4]),
+                   "parity_note": "64 evenly spaced query rows per rank of the last call vs the oracle's sequential scan (index, best, second)",
+                   "library_build_id": capi.build_id()},
         "per_rank": [{"rank": r, "pairs": row[0], "elapsed_s": round(row[2], 4)} for r, row in enumerate(rows)],
         "roofline": roofline,
     }
@@ -503,8 +573,12 @@ def main():
                     help="a step's frames go through this many concurrent lanes (own extractor handle + HIP stream each); 1 = one stream")
     ap.add_argument("--region-timing", action="store_true",
                     help="also time every kernel inside the timed region (HIP events between the kernels of every lane: costs a few percent)")
-    ap.add_argument("--min-seconds", type=float, default=2.0,
+    ap.add_argument("--min-seconds", type=float, default=6.0,
                     help="repeat the --steps block until the timed region lasts at least this long (0: exactly --steps steps)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the last timed step's outputs")
+    ap.add_argument("--no-also", action="store_true", help="headline configuration only (the default run also measures hd1080 and match100k)")
+    ap.add_argument("--also-min-seconds", type=float, default=1.5, help="timed region of each embedded configuration")
+    ap.add_argument("--also-cpu-seconds", type=float, default=5.0, help="CPU baseline sample of each embedded configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-allcores-seconds", type=float, default=8.0, help="0 disables the all-core CPU baseline")
@@ -524,17 +598,40 @@ def main():
     dist = dist_util.init(a.backend, world, rank, local_rank)    # "nccl" is RCCL on ROCm
     if a.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (a.gpus, world))
-    cfg = dict(CONFIGS[a.config])
-    for k in ("batch", "ring", "width", "height", "nfeatures"):
-        if getattr(a, k) is not None and k in cfg:
-            cfg[k] = getattr(a, k)
-    if a.no_match and "match" in cfg:
-        cfg["match"] = False
-    out = run_match(a, cfg, world, rank, local_rank, dist, torch) if a.config == "match100k" else run_frontend(a, cfg, world, rank, local_rank, dist, torch)
+    def run(a_, name):
+        cfg = dict(CONFIGS[name])
+        for k in ("batch", "ring", "width", "height", "nfeatures"):
+            if getattr(a_, k) is not None and k in cfg:
+                cfg[k] = getattr(a_, k)
+        if a_.no_match and "match" in cfg:
+            cfg["match"] = False
+        return (run_match if name == "match100k" else run_frontend)(a_, cfg, world, rank, local_rank, dist, torch)
+
+    out = run(a, a.config)
+    bad = 0
+    if a.config == "vga" and not a.no_also:
+        # BASELINE.json's other GPU configurations in the same line (the driver runs this command once): shorter timed regions and CPU
+        # samples, same definitions.  At N > 1 `hd1080` is configs[3] (one 1080p stream per GPU).
+        also = {}
+        for name in ("hd1080", "match100k"):
+            a2 = argparse.Namespace(**vars(a))
+            a2.config, a2.min_seconds, a2.cpu_seconds, a2.cpu_allcores_seconds = name, a.also_min_seconds, a.also_cpu_seconds, 0.0
+            a2.batch = a2.ring = a2.width = a2.height = a2.nfeatures = None
+            a2.region_timing = False
+            r = run(a2, name)
+            if r is not None:
+                also[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "timed_steps", "timed_seconds", "scaling", "dtype", "config",
+                                                "roofline", "roofline_pipeline", "roofline_valu", "stage_ms_per_step", "cpu_baseline", "per_rank") if k in r}
+        if out is not None:
+            out["also"] = also
     if out is not None:
+        bad = int(out["config"].get("parity_mismatches", 0)) + sum(int(v["config"].get("parity_mismatches", 0)) for v in out.get("also", {}).values())
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if bad:
+        sys.stderr.write("bench.py: %d sampled outputs differ from the oracle (config.parity_detail)\n" % bad)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -85,9 +85,18 @@ typedef struct orbs_params {
  * what a gfx950 workgroup can have (160 KiB).  cap = 1000 / qcap = 1000 needs ~60 KiB.  Up to ~2850 train features the
  * descriptors are staged too; larger frames keep them in global memory (25 instead of 57 bytes of LDS per feature), which
  * carries a problem to ~6500 train features — e.g. the 4000-feature initialisation extractor of an nFeatures = 2000 setup.
- * (The grid searches of frames up to ~2400 features add a level-bucketed index, 16 KiB more than this function reports; larger
- * frames are searched without it.  Same results either way.) */
+ * The grid searches of frames up to ~2400 features add a level-bucketed index (16 KiB more; included in the figure returned for
+ * such sizes — the function reports what the launch really uses); larger frames are searched without it.
+ *
+ * PRECONDITION on the caller's grid CSR (d_cell_off / d_cell_feat): every feature is filed in exactly the cell the reference's
+ * Frame::PosInGrid gives it (`round((x - mnMinX) * mfGridElementWidthInv)`, src/Frame.cc:267-277) — what orbf_undistort_grid
+ * builds.  The plain CSR scan visits the reference's fine cell window; the bucketed index visits a superset of it (2 x 2 cells per
+ * bucket) and relies on the exact |dx|,|dy| <= r test, so the two forms agree — and agree with the reference — only for a grid
+ * filed by that rule.  A CSR built differently (floor instead of round, features filed twice, ...) is outside the contract. */
 size_t orbs_lds_bytes(int cap, int qcap);
+/* test hook: -1 = process default (ORBS_BUCKETS in the environment, on unless "0"), 0 = plain CSR scan for every size,
+ * 1 = bucketed index where it fits.  Same results either way under the precondition above (tests/test_gpu_search.py runs both). */
+int orbs_debug_set_buckets(int mode);
 
 /* Outputs per problem: d_q2t[qcap] the train feature each query is finally matched to (-1 none), d_t2q[cap] the query each
  * train feature is finally matched to (-1 none), d_best / d_second[qcap] the two distances the scan left (INT_MAX as in the

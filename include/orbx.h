@@ -118,7 +118,11 @@ int orbm_hamming256(const uint8_t* a, const uint8_t* b);
  * results of the train splits — is allocated and freed in stream order (hipMallocAsync), so concurrent calls on different
  * streams, also from one host thread, never share a buffer).  nt < 2^22.
  * The kernels compute the distances on the matrix cores (int8 MFMA on +-1 encoded bits, exact); ORBX_MATCH_MFMA=0 in the
- * environment selects the xor + popcount kernels instead (same results). */
+ * environment selects the xor + popcount kernels instead as the process default, orbm_debug_set_match_path() at run time
+ * (same results; tests/test_gpu_matcher.py runs every case through both).
+ * Alignment: the reference's DescriptorDistance reads a descriptor as 8 x int32, i.e. needs 4-byte alignment
+ * (src/ORBmatcher.cc:1796-1801).  Here dT needs 4 bytes too; dQ needs 16 (the query block is fetched with 16-byte loads); any
+ * allocator's device pointer + a multiple of 32 bytes satisfies both.  ORBX_ERR_ARG otherwise. */
 int orbm_match_top2(const uint8_t* Q, int nq, const uint8_t* T, int nt,
                     int32_t* best_idx, int32_t* best, int32_t* second, int device);
 int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
@@ -140,6 +144,8 @@ int orbm_match_top2_segments_device(const uint8_t* dQ, int nq, const uint8_t* dT
                                     const int32_t* d_cand, int32_t* d_best_idx, int32_t* d_best, int32_t* d_second, void* stream);
 /* number of queries passing  best <= th && (float)best < ratio*(float)second  (host arrays) */
 int orbm_count_accepted(const int32_t* best, const int32_t* second, int nq, int th, float ratio);
+/* test hook: which kernels the dense top-2 calls use from now on in this process: -1 = default (environment), 0 = xor + popcount, 1 = MFMA */
+int orbm_debug_set_match_path(int path);
 
 /* Device-memory helpers for hosts that do not want to include the HIP headers (a C or C++ translation unit of ORB_SLAM can
  * keep frames, keypoints, descriptors and the search structures resident on the GPU with these four calls and chain the

@@ -31,6 +31,7 @@ EXPORTS = [
     "orbx_stream_create", "orbx_stream_create_priority", "orbx_stream_destroy", "orbx_stream_synchronize", "orbx_event_create", "orbx_event_destroy", "orbx_event_record",
     "orbx_stream_wait_event", "orbx_device_copy_async", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
     "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element", "orbx_debug_geometry",
+    "orbm_debug_set_match_path",
 ]
 # include/orbf.h (Frame-side steps: undistortion, search grid, window query)
 EXPORTS_F = [
@@ -38,7 +39,7 @@ EXPORTS_F = [
     "orbf_features_in_area_device",
 ]
 # include/orbs.h (greedy grid-window searches)
-EXPORTS_S = ["orbs_lds_bytes", "orbs_three_maxima", "orbs_window_search_batch_device", "orbs_list_search_batch_device",
+EXPORTS_S = ["orbs_lds_bytes", "orbs_debug_set_buckets", "orbs_three_maxima", "orbs_window_search_batch_device", "orbs_list_search_batch_device",
              "orbs_bow_ranges_batch_device", "orbs_triangulation_search_batch_device", "orbs_epipolar_bound", "orbs_agreement_batch_device"]
 RULE_MAPPOINTS, RULE_WINDOW, RULE_BEST, RULE_INIT, RULE_BOW, RULE_FREE, RULE_TRIANGULATION = 0, 1, 2, 3, 4, 5, 6
 TH_HIGH, TH_LOW = 100, 50
@@ -132,6 +133,8 @@ def lib():
         L.orbm_match_top2_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp]
         L.orbm_match_top2_batch_device.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, vp]
         L.orbm_count_accepted.argtypes = [vp, vp, ci, ci, cf]
+        L.orbm_debug_set_match_path.argtypes = [ci]
+        L.orbs_debug_set_buckets.argtypes = [ci]
         L.orbm_match_top2_segments.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci]
         L.orbm_match_top2_segments_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp]
         L.orbx_device_alloc.argtypes = [ci, ctypes.c_size_t, ctypes.POINTER(vp)]
@@ -341,6 +344,20 @@ def match_top2_batch_device(dQ, d_nq, dT, d_nt, nbatch, cap, d_idx, d_best, d_se
     rc = lib().orbm_match_top2_batch_device(dQ, d_nq, dT, d_nt, nbatch, cap, d_idx, d_best, d_second, stream or None)
     if rc != ORBX_OK:
         raise OrbxError(rc, "orbm_match_top2_batch_device")
+
+
+def set_match_path(path):
+    """test hook: -1 process default (ORBX_MATCH_MFMA), 0 xor + popcount kernels, 1 MFMA kernels"""
+    rc = lib().orbm_debug_set_match_path(path)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbm_debug_set_match_path")
+
+
+def set_search_buckets(mode):
+    """test hook: -1 process default (ORBS_BUCKETS), 0 plain CSR scan, 1 bucketed index where it fits"""
+    rc = lib().orbs_debug_set_buckets(mode)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbs_debug_set_buckets")
 
 
 def count_accepted(best, second, th=50, ratio=0.6):

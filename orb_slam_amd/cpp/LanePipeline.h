@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -39,8 +40,10 @@ public:
         bool consumed_valid[2] = {false, false};
     };
 
-    LanePipeline(int width, int height, int batch, int lanes, const orbx_params& params, bool do_match = true, bool autotune = true)
+    LanePipeline(int width, int height, int batch, int lanes, const orbx_params& params, bool do_match = true, bool autotune = true,
+                 int placement = -1)
         : w_(width), h_(height), B_(batch), device_(params.device), do_match_(do_match) {
+        if (placement < 0) { const char* e = std::getenv("ORBX_LANE_PLACEMENT"); if (e && *e) placement = std::atoi(e); }
         G_ = lanes < 1 ? 1 : (lanes > batch ? batch : lanes);
         while (B_ % G_) --G_;
         b_ = B_ / G_;
@@ -50,20 +53,22 @@ public:
         // launched in order.  Measured best (rocprofv3 Queue_Id column): every lane stream on a hardware queue of
         // its own, the blur side streams (created inside the extractor handles) sharing those queues.  Creating the G handles
         // first and the G lane streams after them gives that placement in a fresh process, but streams other libraries created
-        // earlier shift it: three candidate sets of lane streams are created (behind 0, 1 and 2 spacer streams), the first call
-        // of step() times two steps on each and keeps the fastest (placement_ms(), placement_chosen()).
+        // earlier shift it: three candidate sets of lane streams are created (behind 0, 1 and 2 spacer streams); tune() — an
+        // explicit, blocking call — times them and keeps the fastest (placement_ms(), placement_chosen()); step() never probes.
+        // `placement` >= 0 (or ORBX_LANE_PLACEMENT=k in the environment) fixes candidate k: no probe (e.g. for 8 ranks tuned once).
         orbx_params p = params;
         p.max_batch = b_;
         for (Lane& L : lanes_) check(orbx_create(&p, &L.ex), "orbx_create");
-        const int ncand = (autotune && G_ > 1) ? 3 : 1;
+        const int ncand = ((autotune || placement >= 0) && G_ > 1) ? 3 : 1;
         sets_.resize(ncand);
         for (int k = 0; k < ncand; ++k) {
             for (int sp = 0; sp < k; ++sp) { void* st = nullptr; check(orbx_stream_create(device_, &st), "orbx_stream_create"); spacers_.push_back(st); }
             sets_[k].resize(G_);
             for (int g = 0; g < G_; ++g) check(orbx_stream_create(device_, &sets_[k][g]), "orbx_stream_create");
         }
-        for (int g = 0; g < G_; ++g) lanes_[g].stream = sets_[0][g];
-        tuned_ = ncand == 1;
+        chosen_ = placement >= 0 ? (placement < ncand ? placement : ncand - 1) : 0;
+        for (int g = 0; g < G_; ++g) lanes_[g].stream = sets_[chosen_][g];
+        tuned_ = ncand == 1 || placement >= 0;
         for (Lane& L : lanes_) {
             cap_ = orbx_max_keypoints(L.ex);
             alloc(L.kps, (size_t)b_ * cap_);
@@ -92,15 +97,41 @@ public:
         }
         for (auto& set : sets_) for (void* st : set) (void)orbx_stream_destroy(device_, st);
         for (void* st : spacers_) (void)orbx_stream_destroy(device_, st);
+        if (zeros_) (void)orbx_device_free(device_, zeros_);
     }
     LanePipeline(const LanePipeline&) = delete;
     LanePipeline& operator=(const LanePipeline&) = delete;
 
-    // d_frames: device address of the step's first frame (B frames, frame_stride bytes apart).  Asynchronous.
+    // Explicit, BLOCKING placement probe: one untimed + `timed_steps` timed steps over the B frames at d_frames on every candidate
+    // stream set, the fastest stays.  Call once after construction, before the real stream starts.  The state the probes touch (step
+    // counter, hand-off slots, counts) is reset; only this pipeline's own streams are synchronised (other streams and handles of the
+    // process keep running).  No-op with a fixed placement or one lane.
+    void tune(const uint8_t* d_frames, ptrdiff_t frame_stride = 0, ptrdiff_t row_stride = 0, int timed_steps = 3) {
+        if (tuned_) return;
+        if (row_stride == 0) row_stride = w_;
+        if (frame_stride == 0) frame_stride = row_stride * h_;
+        tuned_ = true;
+        probe_ms_.clear();
+        for (size_t k = 0; k < sets_.size(); ++k) {
+            for (int g = 0; g < G_; ++g) lanes_[g].stream = sets_[k][g];
+            reset_handoff();
+            step(d_frames, frame_stride, row_stride);
+            synchronize();
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < timed_steps; ++r) step(d_frames, frame_stride, row_stride);
+            synchronize();
+            probe_ms_.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3 / timed_steps);
+        }
+        chosen_ = 0;
+        for (size_t k = 1; k < probe_ms_.size(); ++k) if (probe_ms_[k] < probe_ms_[chosen_]) chosen_ = (int)k;
+        for (int g = 0; g < G_; ++g) lanes_[g].stream = sets_[chosen_][g];
+        reset_handoff();
+    }
+
+    // d_frames: device address of the step's first frame (B frames, frame_stride bytes apart).  Asynchronous; never probes or blocks.
     void step(const uint8_t* d_frames, ptrdiff_t frame_stride = 0, ptrdiff_t row_stride = 0) {
         if (row_stride == 0) row_stride = w_;
         if (frame_stride == 0) frame_stride = row_stride * h_;
-        if (!tuned_) autotune(d_frames, frame_stride, row_stride);
         const long i = steps_done_;
         const int par = (int)(i & 1);
         for (int g = 0; g < G_; ++g) {
@@ -129,7 +160,8 @@ public:
         ++steps_done_;
     }
 
-    void synchronize() { check(orbx_stream_synchronize(device_, nullptr), "orbx_stream_synchronize"); }
+    // waits for this pipeline's lane streams (every side stream joins its lane stream before the lane's last kernel), nothing else
+    void synchronize() { for (Lane& L : lanes_) check(orbx_stream_synchronize(device_, L.stream), "orbx_stream_synchronize"); }
 
     // Results of the last step as host arrays in frame order: n[B], kps[B][cap], desc[B][cap][32], match[3][B][cap].
     void download(std::vector<int32_t>& n, std::vector<orbx_keypoint>& kps, std::vector<uint8_t>& desc, std::vector<int32_t>& match) {
@@ -160,37 +192,17 @@ private:
         check(orbx_device_alloc(device_, count * sizeof(T), &v), "orbx_device_alloc");
         p = static_cast<T*>(v);
     }
-    // Two timed steps (after one untimed) on every candidate stream set; the fastest stays.  The state the probes touch (step
-    // counter, hand-off slots, counts) is reset, so the first real step starts exactly as without them.
+    // counts of the slots in front of every slice and the hand-off slots back to "no previous frame" (queued on the lane's own stream)
     void reset_handoff() {
+        synchronize();
         steps_done_ = 0;
-        const std::vector<int32_t> zeros((size_t)b_ + 1, 0);
+        if (zeros_ == nullptr) alloc(zeros_, (size_t)b_ + 1);       // device zeros (orbx_device_alloc zero-fills)
         for (Lane& L : lanes_) {
             L.consumed_valid[0] = L.consumed_valid[1] = false;
-            check(orbx_device_upload(device_, L.n, zeros.data(), ((size_t)b_ + 1) * 4), "upload");
-            check(orbx_device_upload(device_, L.h_n, zeros.data(), 2 * 4), "upload");
+            check(orbx_device_copy_async(L.n, zeros_, ((size_t)b_ + 1) * 4, L.stream), "copy");
+            check(orbx_device_copy_async(L.h_n, zeros_, 2 * 4, L.stream), "copy");
         }
-    }
-    void autotune(const uint8_t* d_frames, ptrdiff_t frame_stride, ptrdiff_t row_stride) {
-        tuned_ = true;
-        probe_ms_.clear();
-        for (size_t k = 0; k < sets_.size(); ++k) {
-            for (int g = 0; g < G_; ++g) lanes_[g].stream = sets_[k][g];
-            synchronize();
-            reset_handoff();
-            step(d_frames, frame_stride, row_stride);
-            synchronize();
-            const auto t0 = std::chrono::steady_clock::now();
-            step(d_frames, frame_stride, row_stride);
-            step(d_frames, frame_stride, row_stride);
-            synchronize();
-            probe_ms_.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 500.0);
-        }
-        chosen_ = 0;
-        for (size_t k = 1; k < probe_ms_.size(); ++k) if (probe_ms_[k] < probe_ms_[chosen_]) chosen_ = (int)k;
-        for (int g = 0; g < G_; ++g) lanes_[g].stream = sets_[chosen_][g];
         synchronize();
-        reset_handoff();
     }
     static void check(int rc, const char* what) {
         if (rc != ORBX_OK) throw std::runtime_error(std::string(what) + " failed with orbx status " + std::to_string(rc));
@@ -205,6 +217,7 @@ private:
     std::vector<std::vector<void*>> sets_;      // candidate lane-stream sets
     std::vector<void*> spacers_;
     std::vector<double> probe_ms_;
+    int32_t* zeros_ = nullptr;
 };
 
 }  // namespace ORB_SLAM

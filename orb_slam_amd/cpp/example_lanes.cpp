@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
         for (int run = 0; run < 2; ++run) {
             ORB_SLAM::LanePipeline pipe(w, h, B, run == 0 ? lanes : 1, p);
             cap = pipe.cap();
+            pipe.tune(static_cast<const uint8_t*>(d_frames));       // explicit, blocking placement probe (no-op for one lane)
             for (int i = 0; i < steps; ++i) pipe.step(static_cast<const uint8_t*>(d_frames) + (size_t)i * B * fbytes);
             pipe.synchronize();
             pipe.download(n[run], kps[run], desc[run], match[run]);

@@ -68,11 +68,18 @@ ORBX_HD bool window_cells(const orbf_bounds& b, float x, float y, float r, int* 
 }
 
 // the octave filter and the |dx|,|dy| <= r box of GetFeaturesInArea (src/Frame.cc:241-256)
-ORBX_HD bool in_window(float kx, float ky, int octave, float x, float y, float r, int minLevel, int maxLevel) {
+// the octave filter alone (src/Frame.cc:214-221, :241-249): no check when both arguments are -1, equality when they are equal,
+// otherwise the closed range — which is empty for maxLevel < minLevel (e.g. the callers' (level, -1))
+ORBX_HD bool level_passes(int octave, int minLevel, int maxLevel) {
     const bool check = !(minLevel == -1 && maxLevel == -1);
     const bool same = check && minLevel == maxLevel;
     if (check && !same) { if (octave < minLevel || octave > maxLevel) return false; }
     else if (same) { if (octave != minLevel) return false; }
+    return true;
+}
+
+ORBX_HD bool in_window(float kx, float ky, int octave, float x, float y, float r, int minLevel, int maxLevel) {
+    if (!level_passes(octave, minLevel, maxLevel)) return false;
     if (fabsf(kx - x) > r || fabsf(ky - y) > r) return false;
     return true;
 }

@@ -12,6 +12,7 @@
 // key carries the second-smallest distance counted with multiplicity — exactly what the
 // `if(d<best){best2=best;best=d;idx=i}else if(d<best2)best2=d` scan produces.  Because it is a
 // plain two-smallest reduction, the train set can be split across workgroups and merged in any order.
+#include <atomic>
 #include <climits>
 #include <cstring>
 #include <type_traits>
@@ -506,10 +507,42 @@ int orbm_count_accepted(const int32_t* best, const int32_t* second, int nq, int 
     return n;
 }
 
-// ORBX_MATCH_MFMA=0 selects the xor + popcount kernels (the A/B baseline of the MFMA form); read once per process.
+// ORBX_MATCH_MFMA=0 selects the xor + popcount kernels (the A/B baseline of the MFMA form) as the process default;
+// orbm_debug_set_match_path() overrides it per process at run time (the parity tests run both forms in one process).
+static std::atomic<int> g_match_path{-1};        // -1: environment default, 0: xor + popcount, 1: MFMA
 static bool use_mfma() {
-    static const bool v = [] { const char* e = getenv("ORBX_MATCH_MFMA"); return !(e && e[0] == '0'); }();
-    return v;
+    static const bool env_default = [] { const char* e = getenv("ORBX_MATCH_MFMA"); return !(e && e[0] == '0'); }();
+    const int f = g_match_path.load(std::memory_order_relaxed);
+    return f < 0 ? env_default : f != 0;
+}
+
+int orbm_debug_set_match_path(int path) {
+    if (path < -1 || path > 1) return ORBX_ERR_ARG;
+    g_match_path.store(path, std::memory_order_relaxed);
+    return ORBX_OK;
+}
+
+// Scratch of the split form (partial top-2 per train split): stream-ordered allocation.  The device's default pool keeps what it
+// has handed out once (release threshold raised on first use: with the default of 0 every synchronise returned the memory to the
+// driver and the next large match paid the allocation again); where the runtime has no memory pools the call falls back to
+// hipMalloc + a stream synchronise before the free.
+static bool pool_ready(hipStream_t) {
+    static thread_local int done_for = -1;
+    static thread_local bool ok = false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (done_for == dev) return ok;
+    done_for = dev;
+    ok = false;
+    int supported = 0;
+    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, dev) != hipSuccess || !supported) { (void)hipGetLastError(); return false; }
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    uint64_t keep = 256ull << 20;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    (void)hipGetLastError();
+    ok = true;
+    return true;
 }
 
 int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt, int32_t* d_best_idx, int32_t* d_best,
@@ -532,7 +565,11 @@ int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
     // call stays asynchronous (the free is queued behind the merge kernel).
     const size_t need = (size_t)2 * nsplit * nq * sizeof(uint32_t);
     uint32_t* pk1 = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void**>(&pk1), need, stream) != hipSuccess) return ORBX_ERR_DEVICE;
+    const bool pooled = pool_ready(stream);
+    if ((pooled ? hipMallocAsync(reinterpret_cast<void**>(&pk1), need, stream) : hipMalloc(reinterpret_cast<void**>(&pk1), need)) != hipSuccess) {
+        (void)hipGetLastError();
+        return ORBX_ERR_DEVICE;
+    }
     uint32_t* pk2 = pk1 + (size_t)nsplit * nq;
     if (mfma) hipLaunchKernelGGL(k_match_split_mfma<QT>, dim3(qblocks, nsplit), dim3(256), MF_LDS_BYTES, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt,
                                  chunk, pk1, pk2);
@@ -543,7 +580,12 @@ int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
         hipLaunchKernelGGL(k_match_merge, dim3((nq + 255) / 256), dim3(256), 0, stream, pk1, pk2, nq, nsplit, d_best_idx, d_best, d_second);
         if (hipGetLastError() != hipSuccess) rc = ORBX_ERR_DEVICE;
     }
-    if (hipFreeAsync(pk1, stream) != hipSuccess) rc = ORBX_ERR_DEVICE;
+    if (pooled) {
+        if (hipFreeAsync(pk1, stream) != hipSuccess) rc = ORBX_ERR_DEVICE;
+    } else {
+        if (hipStreamSynchronize(stream) != hipSuccess) rc = ORBX_ERR_DEVICE;      // no pools on this runtime: the call is synchronous
+        if (hipFree(pk1) != hipSuccess) rc = ORBX_ERR_DEVICE;
+    }
     return rc;
 }
 

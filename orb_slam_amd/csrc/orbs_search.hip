@@ -14,6 +14,7 @@
 // in vectorised rounds (see k_window_search).  Claims only ever remove candidates, so a query's exact best / second are
 // the first two still-admissible entries of its list; only a list that runs dry makes the wave rescan that one window
 // (8 columns x 8 lanes, two DPP min-reductions).  Nothing on the in-order path touches global memory.
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <climits>
@@ -217,11 +218,19 @@ __device__ __forceinline__ uint32_t candidate_key(const Staged& S, int rule, int
 
 // level buckets a query's level range can hold entries in (Frame::GetFeaturesInArea: no check when both are -1; with a check and
 // maxLevel < minLevel nothing passes)
+// Derived from orbf::level_passes itself (the test in_window applies), so the two cannot drift: bucket k files the octaves
+// clamp(octave, 0, BK_LEVELS - 1) == k, i.e. bucket 0 everything <= 0 and the last bucket everything >= BK_LEVELS - 1; it has to be
+// visited iff some octave it may hold passes, and for the two open-ended buckets the octave most likely to pass is the range end
+// itself.  The passing octaves form an interval, so the visited buckets are lb0 .. lb1 (empty: lb1 < lb0).
 __device__ __forceinline__ void bk_levels(int minLevel, int maxLevel, int& lb0, int& lb1) {
-    if (minLevel == -1 && maxLevel == -1) { lb0 = 0; lb1 = BK_LEVELS - 1; return; }
-    lb0 = min(max(minLevel, 0), BK_LEVELS - 1);
-    lb1 = maxLevel < minLevel ? lb0 - 1 : min(max(maxLevel, 0), BK_LEVELS - 1);
-    if (maxLevel < 0) lb1 = lb0 - 1;
+    lb0 = BK_LEVELS;
+    lb1 = -1;
+#pragma unroll
+    for (int k = 0; k < BK_LEVELS; ++k) {
+        const int rep = k == 0 ? min(0, minLevel) : k == BK_LEVELS - 1 ? max(BK_LEVELS - 1, maxLevel) : k;
+        if (orbf::level_passes(rep, minLevel, maxLevel)) { lb0 = min(lb0, k); lb1 = max(lb1, k); }
+    }
+    if (lb1 < lb0) { lb0 = 0; lb1 = -1; }
 }
 
 // packed 16-bit counters in LDS (two per dword): add v to entry idx, return its old value (entries stay below 65536)
@@ -707,10 +716,19 @@ static int orbs_set_lds(size_t, bool bucketed = false) {
 
 extern "C" {
 
-// ORBS_BUCKETS=0 in the environment (read once): the plain 64 x 48 CSR scan for the grid searches too (A/B measurements)
+// ORBS_BUCKETS=0 in the environment (the process default): the plain 64 x 48 CSR scan for the grid searches too;
+// orbs_debug_set_buckets() overrides it at run time (the parity tests run the same problems through both forms).
+static std::atomic<int> g_buckets{-1};           // -1: environment default, 0: plain CSR scan, 1: bucketed index where it fits
 static bool orbs_use_buckets() {
-    static const bool on = [] { const char* e = getenv("ORBS_BUCKETS"); return !(e && e[0] == '0'); }();
-    return on;
+    static const bool env_default = [] { const char* e = getenv("ORBS_BUCKETS"); return !(e && e[0] == '0'); }();
+    const int f = g_buckets.load(std::memory_order_relaxed);
+    return f < 0 ? env_default : f != 0;
+}
+
+int orbs_debug_set_buckets(int mode) {
+    if (mode < -1 || mode > 1) return ORBX_ERR_ARG;
+    g_buckets.store(mode, std::memory_order_relaxed);
+    return ORBX_OK;
 }
 
 // the layout a problem of this size gets: descriptors staged when that fits the 160 KiB of a workgroup
@@ -720,10 +738,13 @@ static size_t orbs_choose_layout(int cap, int qcap, int& desc_in_lds) {
     return desc_in_lds ? with : orbs::make_layout(cap, qcap, false).total;
 }
 
+// what a grid search of this size actually launches with: the bucketed layout (descriptors + level buckets) where it fits
 size_t orbs_lds_bytes(int cap, int qcap) {
     if (cap < 1 || qcap < 1) return 0;
     int d;
-    return orbs_choose_layout(cap, qcap, d);
+    const size_t plain = orbs_choose_layout(cap, qcap, d);
+    const size_t bk = orbs::make_layout(cap, qcap, true, true).total;
+    return d && bk <= 160 * 1024 && orbs_use_buckets() ? bk : plain;
 }
 
 float orbs_epipolar_bound(float sigma2) {

@@ -4,6 +4,7 @@ consecutive frames, each lane with its own extractor handle and HIP stream, ever
 Lanes never join.  The only cross-lane dependency is the one frame per lane whose predecessor lies in the lane to its left
 (lane 0: in the last lane's slice of the previous step): that frame's descriptors travel through a two-slot hand-off buffer
 ordered by HIP events.  torch is used for device memory, streams and events only."""
+import os
 import time
 
 import torch
@@ -32,7 +33,11 @@ class _Lane:
 
 
 class LanePipeline:
-    def __init__(self, width, height, batch, lanes=4, nfeatures=1000, device=0, do_match=True, autotune=True, **extractor_kw):
+    def __init__(self, width, height, batch, lanes=4, nfeatures=1000, device=0, do_match=True, autotune=True, placement=None,
+                 **extractor_kw):
+        """autotune: create the candidate stream sets tune() chooses from (nothing is probed until tune() is called).
+        placement (or ORBX_LANE_PLACEMENT=k in the environment): use candidate k and never probe — what a process that was tuned once,
+        or one of 8 ranks that should not each spend probe steps, passes."""
         G = max(1, min(lanes, batch))
         while batch % G:
             G -= 1
@@ -45,70 +50,84 @@ class LanePipeline:
         # lane streams after them, back to back, gives that placement in a fresh process — but any library that created streams
         # earlier (torch's pool, an RCCL communicator) shifts it.  So the pipeline does not trust the creation order: it creates
         # three candidate sets of lane streams (with 0, 1 and 2 spacer streams in front, i.e. rotated against the side streams'
-        # queues), times two steps on each at the first call of step() and keeps the fastest (`self.placement` reports the
-        # timings and the choice).  Raw HIP streams from the C ABI (torch creates its pool streams lazily, in an order of its own).
+        # queues); tune() — an explicit, blocking call — times them and keeps the fastest (`self.placement` reports the timings
+        # and the choice).  Raw HIP streams from the C ABI (torch creates its pool streams lazily, in an order of its own).
+        if placement is None and os.environ.get("ORBX_LANE_PLACEMENT", "") != "":
+            placement = int(os.environ["ORBX_LANE_PLACEMENT"])
         dev = torch.device("cuda", device)
         handles = [capi.ORBextractor(nfeatures=nfeatures, device=device, max_batch=self.b, **extractor_kw) for _ in range(G)]
         self._raw_sets, self._spacers = [], []
-        for spacer in ((0, 1, 2) if (autotune and G > 1) else (0,)):
+        ncand = 3 if (G > 1 and (autotune or placement is not None)) else 1
+        for spacer in range(ncand):
             self._spacers += [capi.stream_create(device) for _ in range(spacer)]
             self._raw_sets.append([capi.stream_create(device) for _ in range(G)])
         self._sets = [[torch.cuda.ExternalStream(p, device=dev) for p in raw] for raw in self._raw_sets]
-        self.lanes = [_Lane(handles[g], device, self.b, self._sets[0][g]) for g in range(G)]
+        chosen = min(max(placement, 0), ncand - 1) if placement is not None else 0
+        self.lanes = [_Lane(handles[g], device, self.b, self._sets[chosen][g]) for g in range(G)]
         self.device = device
         self.cap = self.lanes[0].ex.max_keypoints
         self.steps_done = 0
         self.match_events = []
-        self.placement = {"candidates": len(self._sets), "chosen": 0, "probe_ms_per_step": None,
+        self.placement = {"candidates": ncand, "chosen": chosen, "probe_ms_per_step": None, "fixed": placement is not None,
                           "note": "candidate k = lane streams created behind k spacer streams (and behind the handles' side streams)"}
-        self._tuned = len(self._sets) == 1
+        self._fixed = placement is not None or ncand == 1
         torch.cuda.synchronize(dev)      # the zero-fills above ran on the default stream; the lane streams do not wait for it
 
     def _use_set(self, k):
         for g, ln in enumerate(self.lanes):
             ln.stream = self._sets[k][g]
 
+    def _sync_lanes(self):
+        """waits for this pipeline's own streams only (every side stream joins its lane stream before the lane's last kernel):
+        other streams and handles of the process keep running"""
+        for ln in self.lanes:
+            ln.stream.synchronize()
+
     def _reset_handoff(self):
         self.steps_done = 0
         self.match_events = []
         for ln in self.lanes:
             ln.h_written, ln.h_consumed = [None, None], [None, None]
-            ln.n.zero_()
-            ln.h_n.zero_()
+            with torch.cuda.stream(ln.stream):
+                ln.n.zero_()
+                ln.h_n.zero_()
 
-    def _autotune(self, d_frames_ptr, frame_stride, row_stride):
-        """Two timed steps (after one untimed) on every candidate stream set; the fastest stays.  State touched by the probes (step
-        counter, hand-off slots, counts) is reset, so the first real step starts exactly as without the probes."""
-        dev = torch.device("cuda", self.device)
-        self._tuned = True
+    def tune(self, d_frames_ptr, frame_stride=None, row_stride=None, timed_steps=3):
+        """Explicit, BLOCKING placement probe: one untimed + `timed_steps` timed steps over the B frames at d_frames_ptr on every
+        candidate stream set; the fastest stays.  Call it once after construction, before the real stream starts (the bench does, in
+        front of its warm-up).  State the probes touch (step counter, hand-off slots, counts) is reset, so the first real step starts
+        exactly as without them.  Only this pipeline's streams are synchronised.  No-op with a fixed placement."""
+        if self._fixed:
+            return self.placement
+        row_stride = row_stride or self.w
+        frame_stride = frame_stride or row_stride * self.h
         ms = []
         for k in range(len(self._sets)):
             self._use_set(k)
             self._reset_handoff()
-            torch.cuda.synchronize(dev)
+            self._sync_lanes()
             self.step(d_frames_ptr, frame_stride, row_stride)
-            torch.cuda.synchronize(dev)
+            self._sync_lanes()
             t = time.perf_counter()
-            self.step(d_frames_ptr, frame_stride, row_stride)
-            self.step(d_frames_ptr, frame_stride, row_stride)
-            torch.cuda.synchronize(dev)
-            ms.append((time.perf_counter() - t) * 500.0)
+            for _ in range(timed_steps):
+                self.step(d_frames_ptr, frame_stride, row_stride)
+            self._sync_lanes()
+            ms.append((time.perf_counter() - t) * 1e3 / timed_steps)
         best = min(range(len(ms)), key=lambda k: ms[k])
         self._use_set(best)
-        torch.cuda.synchronize(dev)
         self._reset_handoff()
-        torch.cuda.synchronize(dev)
+        self._sync_lanes()
+        self._fixed = True
         self.placement.update({"chosen": best, "probe_ms_per_step": [round(v, 4) for v in ms]})
+        return self.placement
 
     def step(self, d_frames_ptr, frame_stride=None, row_stride=None, timed=False):
         """d_frames_ptr: device address of the step's first frame (B frames, frame_stride bytes apart).  Asynchronous: lane g
         extracts frames [g*b, (g+1)*b) on its own stream, publishes its last frame, takes the frame before its slice from the
-        lane on its left and matches every frame against its predecessor."""
+        lane on its left and matches every frame against its predecessor.  Never probes or blocks (tune() is the explicit probe)."""
         w, h, b, G, cap = self.w, self.h, self.b, self.G, self.cap
         row_stride = row_stride or w
         frame_stride = frame_stride or row_stride * h
-        if not self._tuned:
-            self._autotune(d_frames_ptr, frame_stride, row_stride)
         i = self.steps_done
         par = i & 1
         for g, ln in enumerate(self.lanes):

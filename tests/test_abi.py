@@ -65,7 +65,7 @@ def test_library_exports_every_symbol_of_orbs_h_and_three_maxima():
     L = capi.lib()
     assert declared == sorted(capi.EXPORTS_S) and not [f for f in declared if not hasattr(L, f)]
     assert ctypes.sizeof(capi.SearchParams) == 16
-    assert 40 * 1024 < L.orbs_lds_bytes(1000, 1000) < 64 * 1024 and L.orbs_lds_bytes(0, 5) == 0
+    assert 40 * 1024 < L.orbs_lds_bytes(1000, 1000) < 80 * 1024 and L.orbs_lds_bytes(0, 5) == 0      # incl. the 16 KiB level-bucketed index such a frame is searched with
     # ORBmatcher::ComputeThreeMaxima (host helper) against the oracle's verbatim restatement
     import oracle_lib as ol
     rng = np.random.default_rng(3)

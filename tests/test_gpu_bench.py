@@ -33,12 +33,38 @@ def _contract(d):
 
 
 def test_two_ranks_bare_command():
+    """the N > 1 path of all three configurations of the default line: VGA stream per rank, 1080p stream per rank (BASELINE configs[3]),
+    100k x 100k with the queries sharded by rank"""
     d = _bench("--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "2", "--warmup", "1", "--batch", "64", "--ring", "128", "--min-seconds", "0",
-               "--no-cpu-baseline")
+               "--also-min-seconds", "0", "--no-cpu-baseline")
     _contract(d)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and len(d["per_rank"]) == 2
     assert d["per_rank"][0]["frames"] == d["per_rank"][1]["frames"] == 2 * 64
     assert d["config"]["frames_with_error_status"] == 0 and d["config"]["mean_keypoints_per_frame"] > 900
+    assert d["config"]["parity_checked_frames"] >= 16 and d["config"]["parity_mismatches"] == 0       # both ranks checked their last step
+    assert d["config"]["host_submit_ms_per_step"] > 0
+    hd, mt = d["also"]["hd1080"], d["also"]["match100k"]
+    assert hd["scaling"] == "weak" and len(hd["per_rank"]) == 2 and hd["per_rank"][0]["frames"] == hd["per_rank"][1]["frames"] == 2 * 128
+    assert hd["config"]["parity_checked_frames"] >= 16 and hd["config"]["parity_mismatches"] == 0
+    assert mt["scaling"] == "strong" and mt["config"]["queries_per_gpu"] == 50000 and len(mt["per_rank"]) == 2
+    assert mt["config"]["parity_checked_rows"] >= 100 and mt["config"]["parity_mismatches"] == 0
+
+
+def test_default_line_carries_every_baseline_config():
+    """the command the driver runs, shortened: headline VGA keys unchanged, `also` holds hd1080 (BASELINE configs[2]) and match100k
+    (configs[4]) with their own roofline and cpu_baseline; the parity leg ran on the timed shapes"""
+    d = _bench("--steps", "2", "--warmup", "1", "--min-seconds", "0.3", "--also-min-seconds", "0.2", "--cpu-seconds", "1", "--cpu-allcores-seconds", "0",
+               "--also-cpu-seconds", "1")
+    _contract(d)
+    assert "640x480" in d["metric"] and d["roofline"]["bound"] == "hbm" and d["roofline"]["kernel"] and "cpu_baseline" in d
+    assert d["config"]["frames_per_step_per_gpu"] == 1024 and d["config"]["lanes"] == 4
+    assert d["config"]["parity_checked_frames"] >= 8 and d["config"]["parity_mismatches"] == 0
+    hd, mt = d["also"]["hd1080"], d["also"]["match100k"]
+    assert "1920x1080" in hd["metric"] and hd["value"] > 0 and hd["roofline"]["bound"] == "hbm" and hd["cpu_baseline"]["value"] > 0
+    assert hd["config"]["parity_checked_frames"] >= 8 and hd["config"]["parity_mismatches"] == 0
+    assert mt["unit"] == "pairs/s" and mt["roofline"]["bound"] == "mfma" and mt["cpu_baseline"]["value"] > 0
+    assert mt["roofline"]["per_call_ms"]["calls"] == 30 and mt["roofline"]["per_call_ms"]["min"] <= mt["roofline"]["avg_launch_ms"]
+    assert mt["config"]["parity_checked_rows"] >= 50 and mt["config"]["parity_mismatches"] == 0
 
 
 def test_single_rank_configs_and_min_duration():

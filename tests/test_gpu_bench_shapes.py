@@ -1,0 +1,118 @@
+"""Parity at the launch shapes bench.py actually times (missing #3): the throughput numbers are quoted on 640x480 /
+nFeatures 1000 in launch groups of 256 frames (per-level k_resize, frame -> XCD block renumbering on, k_fast_cells<true,256,2>) and
+on 1920x1080 / nFeatures 2000 in groups of 32 (the 512-thread FAST work-item shape).  Here EVERY frame of such a group is compared
+with the oracle byte for byte, and the bench's own pipeline configuration (1024 frames, 4 lanes of 256, match vs the previous
+frame) is checked at every lane border and the step border.  Contract: src/ORBextractor.cc:718-779, src/ORBmatcher.cc:201-222."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+import parity_sample
+from orb_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cores():
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        c = int(float(q) / float(p)) if q != "max" else len(os.sched_getaffinity(0))
+    except Exception:
+        c = len(os.sched_getaffinity(0))
+    return max(1, min(c, 32))
+
+
+def _oracle_all(frames, nfeatures):
+    """the oracle on every frame, one extractor instance per worker thread (instances are not re-entrant; ctypes releases the GIL)"""
+    workers = _cores()
+    chunks = [list(range(i, len(frames), workers)) for i in range(workers)]
+
+    def run(idx):
+        o = orc.OracleExtractor(nfeatures=nfeatures)
+        return [(j, o(frames[j])) for j in idx]
+
+    out = [None] * len(frames)
+    with ThreadPoolExecutor(workers) as ex:
+        for part in ex.map(run, chunks):
+            for j, r in part:
+                out[j] = r
+    return out
+
+
+def _group_vs_oracle(w, h, nfeatures, frames, max_batch):
+    torch = pytest.importorskip("torch")
+    B = len(frames)
+    want = _oracle_all(frames, nfeatures)
+    ex = capi.ORBextractor(nfeatures=nfeatures, max_batch=max_batch)
+    try:
+        cap = ex.max_keypoints
+        d_img = torch.from_numpy(frames).cuda()
+        d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+        d_st = torch.full((B,), -99, dtype=torch.int32, device="cuda")
+        ex.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, d_st.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        n = d_n.cpu().numpy()
+        assert (d_st.cpu().numpy() == 0).all()
+        kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+        desc = d_desc.cpu().numpy()
+        for f in range(B):
+            ok, od = want[f]
+            assert n[f] == len(ok), f
+            assert kps[f, :n[f]].tobytes() == ok.tobytes(), f
+            np.testing.assert_array_equal(desc[f, :n[f]], od, err_msg="frame %d" % f)
+    finally:
+        ex.close()
+
+
+def test_vga_one_launch_group_of_256_frames():
+    """the headline shape: 640x480, nFeatures 1000, ONE launch group of 256 frames — every frame against the oracle"""
+    w, h = 640, 480
+    frames = np.concatenate([synth.frames(w, h, synth.BLOCKS, 3000, 240), synth.frames(w, h, synth.NOISE, 3300, 6),
+                             synth.frames(w, h, synth.LOWTEX, 3400, 8), synth.frames(w, h, synth.FLAT, 3500, 2)])
+    _group_vs_oracle(w, h, 1000, frames, 256)
+
+
+def test_hd1080_one_launch_group_of_32_frames():
+    """BASELINE configs[2]'s shape: 1920x1080, nFeatures 2000, one launch group of 32 frames (what a lane of the bench runs)"""
+    w, h = 1920, 1080
+    frames = np.concatenate([synth.frames(w, h, synth.BLOCKS, 4000, 28), synth.frames(w, h, synth.NOISE, 4100, 2),
+                             synth.frames(w, h, synth.LOWTEX, 4200, 2)])
+    _group_vs_oracle(w, h, 2000, frames, 32)
+
+
+def test_hd1080_launch_group_of_72_frames_with_xcd_affinity():
+    """1080p in a group large enough for the frame -> XCD block renumbering (>= 64 frames; 72 is a multiple of 8, 70 below leaves the
+    last group of eight incomplete)"""
+    w, h = 1920, 1080
+    frames = synth.frames(w, h, synth.BLOCKS, 4300, 70)
+    _group_vs_oracle(w, h, 2000, frames, 72)
+
+
+@pytest.mark.parametrize("cfg", ["vga", "hd1080"])
+def test_bench_pipeline_configuration(cfg):
+    """bench.py's own configuration — 1024 VGA frames as 4 lanes of 256 (128 1080p frames as 4 lanes of 32), three steps back to
+    back with the placement probe in front — checked exactly the way bench.py's parity leg checks its last timed step"""
+    torch = pytest.importorskip("torch")
+    from orb_slam_amd.pipeline import LanePipeline
+    w, h, nf, B = (640, 480, 1000, 1024) if cfg == "vga" else (1920, 1080, 2000, 128)
+    steps = 3
+    ring = B * 2
+    frames = synth.frames(w, h, synth.BLOCKS, 7000, ring)
+    d_img = torch.from_numpy(frames).cuda()
+    pipe = LanePipeline(w, h, B, lanes=4, nfeatures=nf)
+    try:
+        pipe.tune(d_img.data_ptr())
+        for i in range(steps):
+            pipe.step(d_img.data_ptr() + ((i * B) % ring) * w * h)
+        torch.cuda.synchronize()
+        last = steps - 1
+        res = parity_sample.check_step(pipe, lambda j: frames[(last * B + j) % ring], parity_sample.sample_indices(B, pipe.G), nf)
+        assert res["frames"] >= 8 and res["mismatches"] == 0, res
+    finally:
+        pipe.close()

@@ -7,6 +7,17 @@ from orb_slam_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 
+PATHS = {"mfma": 1, "popcount": 0}
+
+
+@pytest.fixture(params=sorted(PATHS))
+def match_path(request):
+    """Every dense top-2 case runs through both kernel families the library ships: the int8 MFMA form (default) and the
+    xor + popcount form `north_star` describes (ORBX_MATCH_MFMA=0) — selected at run time through the C ABI's test hook."""
+    capi.set_match_path(PATHS[request.param])
+    yield request.param
+    capi.set_match_path(-1)
+
 
 def _check(Q, T):
     gi, gb, gs = capi.match_top2(Q, T)
@@ -17,11 +28,11 @@ def _check(Q, T):
 
 
 @pytest.mark.parametrize("nq,nt", [(1, 1), (1, 2), (5, 3), (64, 64), (513, 1000), (1000, 1000), (2000, 2000), (300, 4097), (1025, 70001)])
-def test_random(nq, nt):
+def test_random(nq, nt, match_path):
     _check(synth.descriptors(nq, 10 + nq), synth.descriptors(nt, 20 + nt))
 
 
-def test_empty_train_and_empty_query():
+def test_empty_train_and_empty_query(match_path):
     gi, gb, gs = capi.match_top2(synth.descriptors(7, 1), np.zeros((0, 32), np.uint8))
     assert (gi == -1).all() and (gb == 2**31 - 1).all() and (gs == 2**31 - 1).all()
     gi, gb, gs = capi.match_top2(np.zeros((0, 32), np.uint8), synth.descriptors(7, 1))
@@ -30,7 +41,7 @@ def test_empty_train_and_empty_query():
     assert (gs == 2**31 - 1).all() and (gi == 0).all()
 
 
-def test_ties_duplicates_and_extremes():
+def test_ties_duplicates_and_extremes(match_path):
     rng = np.random.default_rng(7)
     T = synth.descriptors(3000, 5)
     T[100:2000:7] = T[50]                 # many exact duplicates -> best==second, first index must win
@@ -42,7 +53,7 @@ def test_ties_duplicates_and_extremes():
     _check(few[:1500], few[1500:])
 
 
-def test_batch_device():
+def test_batch_device(match_path):
     torch = pytest.importorskip("torch")
     B, cap = 9, 1000
     nq = np.array([1000, 999, 0, 1, 513, 1000, 37, 512, 1000], np.int32)
@@ -65,7 +76,7 @@ def test_batch_device():
         assert (o[:, i, nq[i]:] == -7).all()          # nothing written past nq
 
 
-def test_full_size_properties():
+def test_full_size_properties(match_path):
     """100k x 100k (BASELINE config 5) is too slow for the scalar oracle; check size-independent properties:
     self-match (best=0 at own index when descriptors are unique) and agreement with the oracle on a query sample."""
     n = 100_000
@@ -93,6 +104,14 @@ def test_full_size_every_row_against_the_oracle():
     Q[::4999] = T[40000:40000 + len(Q[::4999])]        # exact matches (distance 0)
     Q[7::9973] = T[123]                                 # best = 0 with multiplicity: second = 0
     gi, gb, gs = capi.match_top2(Q, T)
+    capi.set_match_path(0)                              # the xor + popcount kernels on the same problem (the oracle scan runs once)
+    try:
+        pi, pb, ps = capi.match_top2(Q, T)
+    finally:
+        capi.set_match_path(-1)
+    np.testing.assert_array_equal(pi, gi)
+    np.testing.assert_array_equal(pb, gb)
+    np.testing.assert_array_equal(ps, gs)
     try:
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
         cores = int(float(q) / float(p)) if q != "max" else len(os.sched_getaffinity(0))
@@ -168,7 +187,7 @@ def test_distinctive_descriptors():
     assert len(gi) == 0
 
 
-def test_top2_property_hypothesis():
+def test_top2_property_hypothesis(match_path):
     """for ANY query / train multiset (hypothesis explores tiny alphabets, duplicates, empty sets) the GPU top-2 equals
     the sequential-scan semantics: two smallest distances with multiplicity, first index on ties"""
     hyp = pytest.importorskip("hypothesis")

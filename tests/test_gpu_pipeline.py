@@ -100,7 +100,8 @@ def test_cpp_lane_pipeline(tmp_path):
 
 def test_lane_placement_is_probed_and_survives_foreign_streams():
     """Streams created by other libraries before the pipeline shift the runtime's stream -> hardware-queue placement; the pipeline
-    times its candidate stream sets at the first step, reports the choice, and the probes leave no trace in the results."""
+    times its candidate stream sets in an explicit tune() call (step() itself never probes or blocks), reports the choice, and the
+    probes leave no trace in the results; a fixed placement (argument or ORBX_LANE_PLACEMENT) skips the probe."""
     torch = pytest.importorskip("torch")
     foreign = [capi.stream_create(0) for _ in range(6)]
     try:
@@ -119,10 +120,16 @@ def test_lane_placement_is_probed_and_survives_foreign_streams():
         pipe = LanePipeline(w, h, B, lanes=4, nfeatures=nf)
         pipe.step(d_img.data_ptr())
         torch.cuda.synchronize()
+        assert pipe.placement["probe_ms_per_step"] is None          # step() alone never probes
+        pipe.tune(d_img.data_ptr())
         p = pipe.placement
         assert p["candidates"] == 3 and len(p["probe_ms_per_step"]) == 3 and 0 <= p["chosen"] < 3
         assert p["probe_ms_per_step"][p["chosen"]] == min(p["probe_ms_per_step"])
+        assert pipe.steps_done == 0 and int(pipe.counts().abs().sum().item()) == 0      # the probes left no state behind
         pipe.close()
+        fixed = LanePipeline(w, h, B, lanes=4, nfeatures=nf, placement=2)
+        assert fixed.tune(d_img.data_ptr())["probe_ms_per_step"] is None and fixed.placement["chosen"] == 2
+        fixed.close()
     finally:
         for s in foreign:
             capi.stream_destroy(0, s)

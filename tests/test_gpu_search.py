@@ -11,6 +11,15 @@ pytestmark = pytest.mark.gpu
 CAM = capi.Camera.make(517.3, 516.5, 318.6, 255.3, (0.2624, -0.9531, -0.0054, 0.0026), 640, 480)
 
 
+@pytest.fixture(params=["bucketed", "plain"])
+def index_form(request):
+    """The grid searches come in two forms with the same results (include/orbs.h): the level-bucketed index (frames up to ~2400
+    features) and the plain 64 x 48 CSR scan (larger frames, or ORBS_BUCKETS=0).  The same problems go through both."""
+    capi.set_search_buckets(1 if request.param == "bucketed" else 0)
+    yield request.param
+    capi.set_search_buckets(-1)
+
+
 def _problem(seed, nt, nq, radius, crowd=False, level_mode="pm1"):
     """a train frame + ordered queries that compete for its features: queries are noisy copies of train features (several
     per feature when crowd), so later queries meet claimed candidates"""
@@ -128,7 +137,7 @@ SCALE = np.float32(1.2) ** np.arange(8, dtype=np.float32)
     (capi.RULE_FREE, capi.TH_HIGH, 0.9, True, "below", 10.0 * SCALE),           # LoopClosing.cc:370 SearchByProjection(pKF, Scw, points, matched, 10)
 ], ids=["mappoints_r4", "mappoints_r20", "window100_rot", "window200_rot", "window15", "best15_rot", "best30_all", "init100_rot", "init40_all",
         "free_fuse3", "free_sim10"])
-def test_rules_against_oracle(rule, th, ratio, check, level_mode, radius):
+def test_rules_against_oracle(rule, th, ratio, check, level_mode, radius, index_form):
     cap = qcap = 1000
     problems = [_problem(10 + i, nt, nq, radius, crowd=(i % 2 == 1), level_mode=level_mode)
                 for i, (nt, nq) in enumerate([(1000, 1000), (1000, 1000), (700, 1000), (1000, 300), (1, 5), (0, 7), (5, 0), (64, 65), (999, 513)])]
@@ -157,7 +166,7 @@ def test_contention_changes_results():
     assert free > 20
 
 
-def test_large_frames_and_capacity():
+def test_large_frames_and_capacity(index_form):
     radius = 25.0
     problems = [_problem(200 + i, 2000, 2000, radius, crowd=(i == 1), level_mode="pm1") for i in range(2)]
     _run_batch(problems, capi.RULE_WINDOW, 100, 0.8, True, False, False, cap=2000, qcap=2000)
