@@ -107,6 +107,22 @@ int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int nfra
                               orbx_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, int cap,
                               int32_t* d_status, void* stream);
 
+/* The same call cut into the three parts a host can interleave with other work on other streams (the phased lanes of
+ * orb_slam_amd/pipeline.py run the VALU-bound part of one lane next to the memory-bound parts of another):
+ *   ORBX_PHASE_PYRAMID   ComputePyramid                                              (src/ORBextractor.cc:781-822)
+ *   ORBX_PHASE_DETECT    FAST + NMS per cell, quotas, retainBest, GaussianBlur       (:527-707, :760)
+ *   ORBX_PHASE_DESCRIBE  IC_Angle, rBRIEF, scaling, outputs                          (:124-194, :709-779)
+ * `phases` is a bit mask; the parts of one batch must be queued in this order on ONE stream with identical arguments, and
+ * nframes <= max_batch (the handle's scratch holds one launch group).  ORBX_PHASE_ALL == orbx_extract_batch_device. */
+#define ORBX_PHASE_PYRAMID  1
+#define ORBX_PHASE_DETECT   2
+#define ORBX_PHASE_DESCRIBE 4
+#define ORBX_PHASE_ALL      7
+int orbx_extract_batch_device_phases(orbx_extractor* h, const uint8_t* d_imgs, int nframes, int w, int hgt,
+                                     ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                                     orbx_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, int cap,
+                                     int32_t* d_status, void* stream, int phases);
+
 /* ---- matcher ---------------------------------------------------------------------------------- */
 /* Hamming distance of two 256-bit descriptors (pure, re-entrant, host). */
 int orbm_hamming256(const uint8_t* a, const uint8_t* b);

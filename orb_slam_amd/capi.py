@@ -24,7 +24,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 # every symbol include/orbx.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "orbx_default_params", "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_scale_factor",
-    "orbx_max_keypoints", "orbx_last_error", "orbx_build_id", "orbx_extract", "orbx_extract_batch_device",
+    "orbx_max_keypoints", "orbx_last_error", "orbx_build_id", "orbx_extract", "orbx_extract_batch_device", "orbx_extract_batch_device_phases",
     "orbm_hamming256", "orbm_match_top2", "orbm_match_top2_device", "orbm_match_top2_batch_device",
     "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbm_distinctive", "orbm_distinctive_device",
     "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_device_download",
@@ -41,6 +41,7 @@ EXPORTS_F = [
 # include/orbs.h (greedy grid-window searches)
 EXPORTS_S = ["orbs_lds_bytes", "orbs_debug_set_buckets", "orbs_three_maxima", "orbs_window_search_batch_device", "orbs_list_search_batch_device",
              "orbs_bow_ranges_batch_device", "orbs_triangulation_search_batch_device", "orbs_epipolar_bound", "orbs_agreement_batch_device"]
+PHASE_PYRAMID, PHASE_DETECT, PHASE_DESCRIBE, PHASE_ALL = 1, 2, 4, 7
 RULE_MAPPOINTS, RULE_WINDOW, RULE_BEST, RULE_INIT, RULE_BOW, RULE_FREE, RULE_TRIANGULATION = 0, 1, 2, 3, 4, 5, 6
 TH_HIGH, TH_LOW = 100, 50
 # include/orbv.h (bag-of-words transform)
@@ -128,6 +129,7 @@ def lib():
         L.orbx_build_id.restype = ctypes.c_char_p
         L.orbx_extract.argtypes = [vp, vp, ci, ci, pd, vp, vp, ci, ctypes.POINTER(ci)]
         L.orbx_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, pd, pd, vp, vp, vp, ci, vp, vp]
+        L.orbx_extract_batch_device_phases.argtypes = [vp, vp, ci, ci, ci, pd, pd, vp, vp, vp, ci, vp, vp, ci]
         L.orbm_hamming256.argtypes = [vp, vp]
         L.orbm_match_top2.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci]
         L.orbm_match_top2_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp]
@@ -240,10 +242,11 @@ class ORBextractor:
             raise self._err(rc)
         return kps[:n.value].copy(), desc[:n.value].copy()
 
-    def extract_batch_device(self, d_imgs, nframes, w, h, row_stride, frame_stride, d_kps, d_desc, d_n, cap, d_status=0, stream=0):
-        """All pointer arguments are integer device addresses (e.g. torch tensor.data_ptr()).  Asynchronous."""
-        rc = self.L.orbx_extract_batch_device(self.h, d_imgs, nframes, w, h, row_stride, frame_stride, d_kps, d_desc, d_n, cap,
-                                              d_status or None, stream or None)
+    def extract_batch_device(self, d_imgs, nframes, w, h, row_stride, frame_stride, d_kps, d_desc, d_n, cap, d_status=0, stream=0, phases=PHASE_ALL):
+        """All pointer arguments are integer device addresses (e.g. torch tensor.data_ptr()).  Asynchronous.
+        phases: PHASE_* bit mask (orbx_extract_batch_device_phases); the parts of one batch go to one stream, in order."""
+        rc = self.L.orbx_extract_batch_device_phases(self.h, d_imgs, nframes, w, h, row_stride, frame_stride, d_kps, d_desc, d_n, cap,
+                                                     d_status or None, stream or None, phases)
         if rc != ORBX_OK:
             raise self._err(rc)
 

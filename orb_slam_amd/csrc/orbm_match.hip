@@ -180,6 +180,10 @@ typedef int i32x16_t __attribute__((ext_vector_type(16)));
 constexpr int MF_PITCH = 272;                      // bytes per expanded train row in LDS (256 + 16)
 constexpr int MF_TILE_BYTES = 32 * MF_PITCH;
 constexpr int MF_LDS_BYTES = 4096 + 4 * MF_TILE_BYTES;   // two tables + ring of four train tiles
+// query tiles of 32 per wave.  2 (199 VGPRs, two waves per SIMD) is the measured optimum: 3 and 4 tiles compile without spills into
+// the AGPR half of the register file at one wave per SIMD and are slower (100k x 100k: 1.99 / 2.58 / 2.25 ms; per-frame batches
+// 0.255 / 0.376 / 0.311 ms per 1024 frames)
+constexpr int MF_QT = 2;
 
 // Per-query-tile scan state as four named scalars per field: an array here is promoted to a vector register tuple, and every
 // conditional update then shuffles the whole tuple (v_mov_b64 x 4 per key).
@@ -552,7 +556,7 @@ int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
     if (nq == 0) return ORBX_OK;
     if (((uintptr_t)dQ & 15) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
     const bool mfma = use_mfma();
-    constexpr int QPL = 2, QT = 2;                            // popcount form: 2 queries per lane; MFMA form: 2 query tiles per wave
+    constexpr int QPL = 2, QT = MF_QT;                        // popcount form: 2 queries per lane; MFMA form: QT query tiles per wave
     const int q_per_block = mfma ? 128 * QT : MATCH_BLOCK * QPL;
     const int qblocks = (nq + q_per_block - 1) / q_per_block;
     // enough workgroups to fill 256 CUs several times over, but chunks of >= 256 train descriptors
@@ -596,7 +600,7 @@ int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const u
     if (nbatch == 0) return ORBX_OK;
     if (((uintptr_t)dQ & 15) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
     if (use_mfma()) {
-        constexpr int QT = 2;                                    // 256 queries per workgroup: four workgroups per ~1000-feature frame
+        constexpr int QT = MF_QT;                                // 256 queries per workgroup: four workgroups per ~1000-feature frame
         hipLaunchKernelGGL(k_match_batch_mfma<QT>, dim3((cap + 128 * QT - 1) / (128 * QT), nbatch), dim3(256), MF_LDS_BYTES, stream, (const uint32_t*)dQ, d_nq,
                            (const uint32_t*)dT, d_nt, cap, d_best_idx, d_best, d_second);
         return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;

@@ -200,9 +200,17 @@ int orbx_max_keypoints(const orbx_extractor* h) {
 int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int nframes, int w, int hgt, ptrdiff_t row_stride,
                               ptrdiff_t frame_stride, orbx_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, int cap,
                               int32_t* d_status, void* stream_) {
+    return orbx_extract_batch_device_phases(h, d_imgs, nframes, w, hgt, row_stride, frame_stride, d_kps, d_desc, d_n, cap, d_status, stream_, ORBX_PHASE_ALL);
+}
+
+int orbx_extract_batch_device_phases(orbx_extractor* h, const uint8_t* d_imgs, int nframes, int w, int hgt, ptrdiff_t row_stride,
+                                     ptrdiff_t frame_stride, orbx_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, int cap,
+                                     int32_t* d_status, void* stream_, int phases) {
     if (!h) return ORBX_ERR_ARG;
     if (!d_imgs || nframes <= 0 || w <= 0 || hgt <= 0) return ORBX_EMPTY;
     if (!d_kps || !d_desc || !d_n || cap < 1 || row_stride < w) { h->err = "bad argument"; return ORBX_ERR_ARG; }
+    if (phases < 1 || phases > ORBX_PHASE_ALL) { h->err = "bad phase mask"; return ORBX_ERR_ARG; }
+    if (phases != ORBX_PHASE_ALL && nframes > h->p.max_batch) { h->err = "a phased call covers one launch group: nframes <= max_batch"; return ORBX_ERR_ARG; }
     HIPCHK(h, hipSetDevice(h->p.device));
     int rc = ensure_geometry(h, w, hgt);
     if (rc != ORBX_OK) return rc;
@@ -222,7 +230,7 @@ int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int nfra
         b.out_n = d_n + f0;
         b.out_status = d_status ? d_status + f0 : nullptr;
         b.cap = cap;
-        rc = launch_extract(b, h->hg, stream, h->stop_after, &h->timer, &h->side);
+        rc = launch_extract(b, h->hg, stream, h->stop_after, &h->timer, &h->side, phases);
         if (rc != ORBX_OK) { h->err = "kernel launch failed (no gfx950 code object for this device?)"; return rc; }
         h->last = b;
         h->have_last = true;

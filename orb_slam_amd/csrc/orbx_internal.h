@@ -214,6 +214,8 @@ struct SideStream {
     hipStream_t aux = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
-int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int stop_after, StageTimer* timer, const SideStream* side);
+// `phases`: ORBX_PHASE_* bits of include/orbx.h (which parts of the sequence to queue; ORBX_PHASE_ALL = everything)
+int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int stop_after, StageTimer* timer, const SideStream* side,
+                   int phases = ORBX_PHASE_ALL);
 
 }  // namespace orbx

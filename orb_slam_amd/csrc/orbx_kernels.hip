@@ -1451,14 +1451,14 @@ struct StageScope {   // records (start, stop) events around one stage when timi
     }
 };
 
-int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int stop_after, StageTimer* timer, const SideStream* side) {
+int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int stop_after, StageTimer* timer, const SideStream* side, int phases) {
     const DevGeom& g = hg.g;
     const int F = b.nframes;
     if (F <= 0) return ORBX_OK;
     const bool fused_pyramid = g.npyr_groups > 0 && F < PYR_FUSED_MAX_FRAMES;
     // per-frame status starts at ORBX_OK: a fill launch for full batches, folded into the first k_pyramid launch otherwise
-    if (!fused_pyramid && hipMemsetAsync(b.status, 0, sizeof(int32_t) * F, stream) != hipSuccess) return ORBX_ERR_DEVICE;
-    {
+    if ((phases & ORBX_PHASE_PYRAMID) && !fused_pyramid && hipMemsetAsync(b.status, 0, sizeof(int32_t) * F, stream) != hipSuccess) return ORBX_ERR_DEVICE;
+    if (phases & ORBX_PHASE_PYRAMID) {
         StageScope sc(timer, stream, ST_PYRAMID);
         const bool al0 = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
         // Fused launches when the batch is too small to fill the chip (the drop-in call: one frame): there the chain of dependent
@@ -1491,6 +1491,8 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         }
     }
     if (stop_after == ST_PYRAMID) return ORBX_OK;
+    if (!(phases & ORBX_PHASE_DETECT)) goto describe;
+    {
     auto launch_blur = [&](hipStream_t st) -> int {
         StageScope sc(timer, st, ST_BLUR);
         const bool aligned = (((uintptr_t)b.img | (uintptr_t)b.img_row_stride | (uintptr_t)b.img_frame_stride) & 3) == 0;
@@ -1578,7 +1580,9 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         if (hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) return ORBX_ERR_DEVICE;
     } else if (!fuse_blur && launch_blur(stream) != ORBX_OK) return ORBX_ERR_DEVICE;
     if (stop_after == ST_BLUR) return ORBX_OK;
-    {
+    }
+describe:
+    if (phases & ORBX_PHASE_DESCRIBE) {
         StageScope sc(timer, stream, ST_DESCRIBE);
         hipLaunchKernelGGL(k_describe, dim3(frame_item_blocks(b, (g.nquads + DESC_WAVES - 1) / DESC_WAVES)), dim3(DESC_WAVES * 64), 0, stream, b);
         ORBX_LAUNCH_CHECK();

@@ -401,3 +401,37 @@ def test_single_frame_copy_engine_path(monkeypatch):
                 np.testing.assert_array_equal(gd, od)
         finally:
             ex.close()
+
+
+def test_phased_call_equals_the_whole_call(gpu_extractor_factory):
+    """orbx_extract_batch_device_phases: pyramid, detection and description of one launch group queued as three calls (other work
+    may run in between on other streams) leave exactly what the one call leaves; a phased call larger than the launch group, or a
+    bad mask, is refused"""
+    torch = pytest.importorskip("torch")
+    B, w, h, nf = 40, 322, 246, 400
+    frames = np.concatenate([synth.frames(w, h, synth.BLOCKS, 1500, 34), synth.frames(w, h, synth.NOISE, 1600, 6)])
+    d_img = torch.from_numpy(frames).cuda()
+    ex = gpu_extractor_factory(nfeatures=nf, max_batch=B)
+    cap = ex.max_keypoints
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for masks in ((capi.PHASE_ALL,), (capi.PHASE_PYRAMID, capi.PHASE_DETECT, capi.PHASE_DESCRIBE), (capi.PHASE_PYRAMID | capi.PHASE_DETECT, capi.PHASE_DESCRIBE)):
+        d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+        for m in masks:
+            ex.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, 0, st, phases=m)
+        torch.cuda.synchronize()
+        outs.append((d_n.cpu().numpy(), d_kps.cpu().numpy().tobytes(), d_desc.cpu().numpy().tobytes()))
+    assert outs[0][0].sum() > 0.8 * B * nf
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o[0], outs[0][0])
+        assert o[1] == outs[0][1] and o[2] == outs[0][2]
+    ok, od = orc.OracleExtractor(nfeatures=nf)(frames[3])
+    assert outs[0][0][3] == len(ok)
+    small = gpu_extractor_factory(nfeatures=nf, max_batch=8)
+    for kw in (dict(phases=capi.PHASE_DETECT), dict(phases=0), dict(phases=8)):
+        with pytest.raises(capi.OrbxError) as e:
+            small.extract_batch_device(d_img.data_ptr(), 16 if kw["phases"] == capi.PHASE_DETECT else 4, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(),
+                                       d_n.data_ptr(), cap, 0, st, **kw)
+        assert e.value.code == capi.ORBX_ERR_ARG
