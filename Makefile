@@ -24,7 +24,7 @@ oracle/liborb_oracle.so: oracle/orb_oracle.cpp oracle/bow_oracle.cpp oracle/fram
 	$(MAKE) -C oracle liborb_oracle.so
 
 # the reference's own sources compiled against stand-in cv headers (only where /root/reference exists): oracle/Makefile
-oracle_ref: oracle/liborb_oracle.so
+oracle_ref: oracle/liborb_oracle.so orb_slam_amd/liborbx.so
 	$(MAKE) -C oracle ref
 
 # C++ shim demo: the reference's Frame-side call sequence against the drop-in classes (host C++, links the C ABI)

@@ -86,6 +86,15 @@ public:
     template <typename T> T& at(int i) { return cols == 1 ? at<T>(i, 0) : at<T>(0, i); }
     template <typename T> const T& at(int i) const { return cols == 1 ? at<T>(i, 0) : at<T>(0, i); }
 
+    // container semantics of cv::Mat::create / release (as far as the extractor shim and Frame use them)
+    void create(int r, int c, int type) {
+        if (data && r == rows && c == cols && type == type_) return;
+        *this = Mat(r, c, type);
+    }
+    void release() { store_.reset(); data = 0; rows = cols = 0; step = 0; }
+    uchar* ptr(int y = 0) { return data + (size_t)y * step; }
+    const uchar* ptr(int y = 0) const { return data + (size_t)y * step; }
+
     Mat t() const {
         Mat m(cols, rows, CV_32F);
         for (int y = 0; y < rows; y++) for (int x = 0; x < cols; x++) m.at<float>(x, y) = at<float>(y, x);
@@ -101,6 +110,26 @@ private:
     int type_;
     std::shared_ptr<std::vector<uchar> > store_;
 };
+
+// OpenCV 2.4's proxy classes (core.hpp: `typedef const _InputArray& InputArray; typedef const _OutputArray& OutputArray;`) as far as
+// the ORBextractor signature and body use them — for the Frame pin that runs the reference's constructor against the PRODUCT's
+// orb_slam_amd/cpp/ORBextractor.h (oracle/ref_frame_product_wrap.cpp)
+class _InputArray {
+public:
+    _InputArray(const Mat& m) : m_(&m) {}
+    Mat getMat() const { return *m_; }
+    bool empty() const { return m_->empty(); }
+protected:
+    const Mat* m_;
+};
+class _OutputArray : public _InputArray {
+public:
+    _OutputArray(Mat& m) : _InputArray(m) {}
+    void create(int r, int c, int type) const { const_cast<Mat*>(m_)->create(r, c, type); }
+    void release() const { const_cast<Mat*>(m_)->release(); }
+};
+typedef const _InputArray& InputArray;
+typedef const _OutputArray& OutputArray;
 
 inline Mat operator*(const Mat& a, const Mat& b) {
     Mat m(a.rows, b.cols, CV_32F);

@@ -1,0 +1,92 @@
+// =====================================================================================
+// ORACLE SUPPORT — TEST INFRASTRUCTURE ONLY (never part of the product path).
+//
+// The drop-in claim, executed: the reference's OWN src/Frame.cc + include/Frame.h compiled where they lie (oracle/Makefile ->
+// oracle/_ref/libref_frame_product.so) with the PRODUCT's orb_slam_amd/cpp/ORBextractor.h in place of the reference's
+// include/ORBextractor.h (oracle/matcherstub/stubs.h includes the one and cuts the other by its include guard — the effect of the
+// file swap a maintainer makes) and linked against orb_slam_amd/liborbx.so.  Frame::Frame (src/Frame.cc:56-128) runs from the reference's source text; its line :60
+//     (*mpORBextractor)(im, cv::Mat(), mvKeys, mDescriptors);
+// lands in orbx_extract on the GPU.  tests/test_gpu_frame_dropin.py compares mvKeys / mDescriptors with the reference's own
+// extractor (oracle/_ref/libref_orbextractor.so) and mvKeysUn / mGrid / the bounds with the same Frame.cc driven by that
+// extractor's output (oracle/_ref/libref_frame.so).
+// MapPoint.h / KeyFrame.h / Converter.h / ORBVocabulary.h stay cut (g2o, Boost, the SLAM graph: out of scope); cv::Mat is the
+// matcherstub container; cv::undistortPoints — an OpenCV primitive — forwards to the oracle's restatement.
+// =====================================================================================
+#include <memory>
+
+#include "Frame.h"
+
+namespace {
+struct OKeyPoint { float x, y, size, angle, response; int32_t octave, class_id; };
+struct OCamera { float K[9]; float dist[8]; int32_t ndist; int32_t width, height; };
+struct OBounds { int32_t min_x, max_x, min_y, max_y; float inv_w, inv_h; };
+std::unique_ptr<ORB_SLAM::ORBextractor> g_extractor;      // the PRODUCT class (orb_slam_amd/cpp/ORBextractor.h)
+int g_nfeatures = -1;
+ORB_SLAM::ORBVocabulary g_voc;
+static_assert(sizeof(cv::KeyPoint) == sizeof(OKeyPoint), "KeyPoint layout");
+}
+extern "C" void orc_frame_undistort(const void* cam, const void* kps, int n, void* out);
+
+namespace cv {
+void undistortPoints(const Mat& src, Mat& dst, const Mat& K, const Mat& dist, const Mat&, const Mat&) {
+    OCamera c;
+    memset(&c, 0, sizeof(c));
+    for (int i = 0; i < 9; i++) c.K[i] = K.at<float>(i / 3, i % 3);
+    const int nd = dist.rows * dist.cols;
+    for (int i = 0; i < nd && i < 8; i++) c.dist[i] = dist.at<float>(i);
+    c.ndist = nd;
+    const int n = src.rows;
+    std::vector<OKeyPoint> in(n > 0 ? n : 1), out(n > 0 ? n : 1);
+    for (int i = 0; i < n; i++) { in[i].x = src.at<float>(i, 0); in[i].y = src.at<float>(i, 1); }
+    orc_frame_undistort(&c, in.data(), n, out.data());
+    for (int i = 0; i < n; i++) { dst.at<float>(i, 0) = out[i].x; dst.at<float>(i, 1) = out[i].y; }
+}
+}  // namespace cv
+
+extern "C" {
+
+// Frame::Frame(im, timeStamp, extractor, voc, K, distCoef) with the product's extractor.  img: 8-bit rows `stride` bytes apart.
+// Outputs (caller buffers sized for cap key points): mvKeys, mDescriptors (N x 32), mvKeysUn, the bounds, mGrid as CSR (cell = x * 48 + y,
+// push_back order).  Returns N (= mvKeys.size()), -1 if the extractor cannot be created (no GPU), -2 on a thrown error, -3 if N > cap.
+int ref_frame_product_build(const void* cam_, const uint8_t* img, int stride, int nfeatures, int cap, void* keys_out, uint8_t* desc_out,
+                            void* keys_un_out, void* bounds_out, int32_t* cell_off, int32_t* cell_feat, int32_t* levels_out, float* scale_out) {
+    using namespace ORB_SLAM;
+    const OCamera& c = *(const OCamera*)cam_;
+    try {
+        if (!g_extractor || g_nfeatures != nfeatures) {
+            g_extractor.reset();
+            g_extractor.reset(new ORBextractor(nfeatures, 1.2f, 8, ORBextractor::FAST_SCORE, 20));      // src/Tracking.cc:111 (default arguments spelled out)
+            g_nfeatures = nfeatures;
+        }
+    } catch (const std::exception&) { return -1; }
+    cv::Mat im(c.height, c.width, CV_8U), K(3, 3, CV_32F), D(c.ndist > 0 ? c.ndist : 4, 1, CV_32F);
+    for (int y = 0; y < c.height; y++) memcpy(im.ptr(y), img + (size_t)y * stride, (size_t)c.width);
+    for (int i = 0; i < 9; i++) K.at<float>(i / 3, i % 3) = c.K[i];
+    for (int i = 0; i < c.ndist; i++) D.at<float>(i) = c.dist[i];
+    Frame::mbInitialComputations = true;
+    std::unique_ptr<Frame> pF;
+    try { pF.reset(new Frame(im, 0.0, g_extractor.get(), &g_voc, K, D)); } catch (const std::exception&) { return -2; }
+    Frame& F = *pF;
+    const int N = (int)F.mvKeys.size();
+    if (N > cap) return -3;
+    *levels_out = F.mnScaleLevels;
+    *scale_out = F.mfScaleFactor;
+    if (N == 0) return 0;
+    memcpy(keys_out, F.mvKeys.data(), (size_t)N * sizeof(OKeyPoint));
+    for (int i = 0; i < N; i++) memcpy(desc_out + (size_t)i * 32, F.mDescriptors.ptr(i), 32);
+    memcpy(keys_un_out, F.mvKeysUn.data(), F.mvKeysUn.size() * sizeof(OKeyPoint));
+    OBounds b = {Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv};
+    memcpy(bounds_out, &b, sizeof(b));
+    int pos = 0;
+    for (int x = 0; x < FRAME_GRID_COLS; x++)
+        for (int y = 0; y < FRAME_GRID_ROWS; y++) {
+            cell_off[x * FRAME_GRID_ROWS + y] = pos;
+            for (size_t k = 0; k < F.mGrid[x][y].size(); k++) cell_feat[pos++] = (int32_t)F.mGrid[x][y][k];
+        }
+    cell_off[FRAME_GRID_COLS * FRAME_GRID_ROWS] = pos;
+    return N;
+}
+
+void ref_frame_product_close() { g_extractor.reset(); }
+
+}  // extern "C"

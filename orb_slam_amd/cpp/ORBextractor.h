@@ -6,6 +6,7 @@
 //   * the mask argument is accepted and ignored — it has no effect in the reference either
 //     (cellMask is built but never passed to cv::FAST, reference src/ORBextractor.cc:601-607).
 #pragma once
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -34,9 +35,13 @@ public:
     ORBextractor(const ORBextractor&) = delete;
     ORBextractor& operator=(const ORBextractor&) = delete;
 
-    // Compute the ORB features and descriptors on an image (reference include/ORBextractor.h:43-45)
-    void operator()(cv::InputArray image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors) {
-        if (image.empty()) return;                                   // reference :721-722: outputs untouched
+    // Compute the ORB features and descriptors on an image (reference include/ORBextractor.h:43-45).  Written against the proxy
+    // classes the way the reference's own body is (src/ORBextractor.cc:718-742: _image.empty(), _image.getMat(),
+    // _descriptors.release() / create() / getMat()), so it compiles against a real OpenCV 2.4 (-DORBX_WITH_OPENCV) as well as
+    // against cvcompat.h.
+    void operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors) {
+        if (_image.empty()) return;                                  // reference :721-722: outputs untouched
+        cv::Mat image = _image.getMat();
         kps_.resize(cap_);
         desc_.resize((size_t)cap_ * 32);
         int n = 0;
@@ -44,12 +49,13 @@ public:
                                     reinterpret_cast<orbx_keypoint*>(kps_.data()), desc_.data(), cap_, &n);
         if (rc == ORBX_EMPTY) return;
         if (rc != ORBX_OK) throw std::runtime_error(std::string("orbx_extract: ") + orbx_last_error(h_));
-        if (n == 0) descriptors.release();                            // reference :738-739
+        if (n == 0) _descriptors.release();                           // reference :738-739
         else {
-            descriptors.create(n, 32, CV_8U);                         // reference :742
+            _descriptors.create(n, 32, CV_8U);                        // reference :742
+            cv::Mat descriptors = _descriptors.getMat();
             for (int i = 0; i < n; i++) std::memcpy(descriptors.ptr(i), desc_.data() + (size_t)i * 32, 32);
         }
-        keypoints.assign(kps_.begin(), kps_.begin() + n);             // reference :746-747,:777
+        _keypoints.assign(kps_.begin(), kps_.begin() + n);            // reference :746-747,:777
     }
 
     int inline GetLevels() { return nlevels_; }

@@ -69,8 +69,24 @@ private:
     std::shared_ptr<std::vector<uchar>> owner_;
 };
 
-typedef const Mat& InputArray;
-typedef Mat& OutputArray;
+// the proxy classes of OpenCV 2.4's core.hpp (`typedef const _InputArray& InputArray; typedef const _OutputArray& OutputArray;`),
+// reduced to what the ORBextractor signature and body use: a Mat (lvalue or temporary) converts implicitly, as there
+class _InputArray {
+public:
+    _InputArray(const Mat& m) : m_(&m) {}
+    Mat getMat() const { return *m_; }
+    bool empty() const { return m_->empty(); }
+protected:
+    const Mat* m_;
+};
+class _OutputArray : public _InputArray {
+public:
+    _OutputArray(Mat& m) : _InputArray(m) {}
+    void create(int r, int c, int type) const { const_cast<Mat*>(m_)->create(r, c, type); }
+    void release() const { const_cast<Mat*>(m_)->release(); }
+};
+typedef const _InputArray& InputArray;
+typedef const _OutputArray& OutputArray;
 
 }  // namespace cv
 #endif
