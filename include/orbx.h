@@ -41,7 +41,7 @@ extern "C" {
 #define ORBX_ERR_ARG       -1
 #define ORBX_ERR_DEVICE    -2   /* no GPU, HIP error, or kernel image missing */
 #define ORBX_ERR_CAPACITY  -3   /* caller buffer or internal list too small; or an implementation limit the reference does not have
-                                 * (a grid cell wider than 2000 px, > 1024 cells on a level — far outside ORB_SLAM's settings) */
+                                 * (a grid cell wider than 6500 px, > 16384 cells on a level — far outside ORB_SLAM's settings) */
 #define ORBX_ERR_GEOMETRY  -4   /* image/grid geometry the reference itself cannot process (cv::Exception / div-by-zero there) */
 
 /* ORBextractor::{HARRIS_SCORE, FAST_SCORE} (include/ORBextractor.h:36) */

@@ -136,7 +136,8 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
         L.cellH = (int)std::ceil((float)H / levelRows);
         L.ncells = levelRows * levelCols;
         L.nfeat_cell = (int)std::ceil((float)L.ndesired / L.ncells);
-        if (L.ncells > 1024) { err = "more than 1024 grid cells on a level"; return ORBX_ERR_CAPACITY; }   // k_quota LDS arrays
+        if (L.ncells > QUOTA_MAX_CELLS) { err = "more than " + std::to_string(QUOTA_MAX_CELLS) + " grid cells on a level"; return ORBX_ERR_CAPACITY; }   // k_quota keeps a level's cells in LDS
+        g.quota_cells = std::max(g.quota_cells, align_up(L.ncells, 64));
         // every cell but the last of a row/column keeps its full cellW+6 view: it must fit the level
         if ((levelCols - 1) * L.cellW > W || (levelRows - 1) * L.cellH > H) {
             err = "level " + std::to_string(l) + ": degenerate cell grid (cell views leave the image in the reference)";
@@ -330,7 +331,7 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
             const int cw = c.x1 - c.x0 + 1, ch = c.ey1 - c.ey0 + 1;
             if (cw <= 0 || ch <= 0) continue;
             max_px = std::max(max_px, cw * ch);
-            if (cw > shape.max_cw) { err = "grid cell wider than " + std::to_string(shape.max_cw) + " pixels"; return ORBX_ERR_CAPACITY; }   // row pitch of the staged band <= 2048 (exact float division in the kernel)
+            if (cw > shape.max_cw) { err = "grid cell wider than " + std::to_string(shape.max_cw) + " pixels"; return ORBX_ERR_CAPACITY; }   // two own rows + halo of the staged band must fit 64 KiB (16-bit pixel offsets)
             const int nd = (3 + cw + 6 + 3) / 4;
             max_img = std::max(max_img, nd * 4 * (ch + 6));
             max_chunks = std::max(max_chunks, (nd * 4 * (c.y1 - c.y0 + 1) + 63) / 64);

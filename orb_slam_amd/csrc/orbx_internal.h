@@ -85,10 +85,12 @@ struct FastShape { int threads, ppt, band_px, max_cw; };
 #define ORBX_FS 256, 2, 8192, 500
 #endif
 #ifndef ORBX_FL
-#define ORBX_FL 512, 2, 10240, 2000
+#define ORBX_FL 512, 2, 10240, 6500
 #endif
 constexpr FastShape FAST_SMALL = {ORBX_FS};   // VGA-class grids
-constexpr FastShape FAST_LARGE = {ORBX_FL};   // 720p / 1080p-class grids
+constexpr FastShape FAST_LARGE = {ORBX_FL};   // 720p / 1080p-class grids.  max_cw 6500: two own rows + 2 halo rows + the 6 ring rows of a staged band
+                                              // (pitch <= 6512) stay below 64 KiB, the range of the 16-bit pixel offsets; the kernel's float division
+                                              // p -> (p / S, p % S) is exact for every S <= 8192, p < 65536 (checked exhaustively)
 constexpr int FAST_Q1CAP = 320, FAST_Q2CAP = 128, FAST_Q3CAP = 256;
 constexpr int fast_q0cap(int ppt) { return 64 * ppt + 64; }
 constexpr int fast_wave_queue_bytes(int ppt) { return fast_q0cap(ppt) * 4 + FAST_Q1CAP * 2 + FAST_Q2CAP * 2 + FAST_Q3CAP * 2; }
@@ -123,6 +125,8 @@ struct PyrGroup {
 #define ORBX_PYR_TILE 16, 16
 #endif
 
+constexpr int QUOTA_LDS_PER_CELL = 10;                              // k_quota: two ints + two bytes of LDS per cell of a level
+constexpr int QUOTA_MAX_CELLS = 160 * 1024 / QUOTA_LDS_PER_CELL / 64 * 64;   // 16384: what one workgroup's LDS holds
 struct CellState { int32_t n_all, n_hi, n_lo; };     // survivors total, with score>=fastTh, with score>=7
 struct CellSel { int32_t thr, nkeys, nretain, out_off; };
 
@@ -133,6 +137,7 @@ struct DevGeom {
     int nbtiles_total, nbtiles_total_s;
     int nslots;              // sum of ndesired (max keypoints per frame)
     int nquads;              // sum of ceil(ndesired / 4): k_describe waves per frame
+    int quota_cells;         // cells of the level with the most cells, rounded up to 64 (k_quota LDS arrays)
     int score_type, fast_th, tmin;
     int frame_plane_bytes;   // bytes of one frame's pyramid block (== blur block == nms block)
     int frame_cands;         // Cand slots per frame

@@ -80,7 +80,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 
 
-// p -> (p / cw, p % cw) for p < 65536, cw <= 2048 with full-rate VALU ops only (v_mul_lo/hi_u32 are quarter
+// p -> (p / cw, p % cw) for p < 65536, cw <= 8192 with full-rate VALU ops only (v_mul_lo/hi_u32 are quarter
 // rate): q = trunc((p + 0.5) * (1/cw)), exact for every (p, cw) in that range (exhaustively checked offline).
 __device__ __forceinline__ void split_px(int p, int cw, float inv_cw, int& y, int& x) {
     y = (int)(((float)p + 0.5f) * inv_cw);
@@ -708,16 +708,18 @@ __global__ __launch_bounds__(NT) void k_fast_cells(Batch b) {
 // lanes over their cells plus two wave reductions, and the output offsets are a wave prefix sum in cell order.  Lane i owns the
 // cells i, i + 64, ...; nothing a lane writes is read by another lane, so the LDS arrays need no barriers.  (A single lane walking
 // the cells one by one took 10 us per level: nothing for a full batch, 7 % of the one-frame call.)
-constexpr int QUOTA_MAX_CELLS = 1024;   // checked on the host
-
-struct QuotaLds {
-    int nkeys[QUOTA_MAX_CELLS], nret[QUOTA_MAX_CELLS];
-    uint8_t thr[QUOTA_MAX_CELLS], done[QUOTA_MAX_CELLS];
-};
+// LDS: four per-cell arrays sized by the level with the most cells (DevGeom::quota_cells, a multiple of 64; the host bounds it by
+// QUOTA_MAX_CELLS = what 160 KiB hold)
+struct QuotaLds { int *nkeys, *nret; uint8_t *thr, *done; };
 
 __global__ __launch_bounds__(64) void k_quota(Batch b) {
-    __shared__ QuotaLds q;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const DevGeom& g = b.g;
+    QuotaLds q;
+    q.nkeys = reinterpret_cast<int*>(smem);
+    q.nret = q.nkeys + g.quota_cells;
+    q.thr = reinterpret_cast<uint8_t*>(q.nret + g.quota_cells);
+    q.done = q.thr + g.quota_cells;
     const int frame = blockIdx.x / g.nlevels, level = blockIdx.x - frame * g.nlevels;
     const int lane = (int)threadIdx.x;
     const LevelGeom& L = g.lv[level];
@@ -1547,7 +1549,9 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     }
     {
         StageScope sc(timer, stream, ST_QUOTA);
-        hipLaunchKernelGGL(k_quota, dim3(F * g.nlevels), dim3(64), 0, stream, b);
+        const size_t lds = (size_t)g.quota_cells * QUOTA_LDS_PER_CELL;
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_quota), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ORBX_ERR_DEVICE;
+        hipLaunchKernelGGL(k_quota, dim3(F * g.nlevels), dim3(64), lds, stream, b);
         ORBX_LAUNCH_CHECK();
     }
     if (stop_after == ST_QUOTA) return ORBX_OK;

@@ -435,3 +435,17 @@ def test_phased_call_equals_the_whole_call(gpu_extractor_factory):
             small.extract_batch_device(d_img.data_ptr(), 16 if kw["phases"] == capi.PHASE_DETECT else 4, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(),
                                        d_n.data_ptr(), cap, 0, st, **kw)
         assert e.value.code == capi.ORBX_ERR_ARG
+
+
+@pytest.mark.parametrize("w,h,nf,nl,family", [(4200, 3000, 40, 2, synth.BLOCKS), (4200, 3000, 60, 1, synth.NOISE), (6532, 4600, 20, 1, synth.BLOCKS),
+                                               (2080, 1568, 12000, 1, synth.NOISE), (1632, 1232, 6000, 1, synth.BLOCKS)],
+                         ids=["cell_4168px", "cell_2084px", "cell_6500px_the_limit", "cells_2310", "cells_1170"])
+def test_beyond_the_round2_limits(gpu_extractor_factory, w, h, nf, nl, family):
+    """grid cells wider than 2000 px and levels with more than 1024 cells — configurations the reference handles and rounds 1-2
+    refused with ORBX_ERR_CAPACITY — against the oracle"""
+    img = synth.frame(w, h, family, 21)
+    ok, od = orc.OracleExtractor(nfeatures=nf, nlevels=nl)(img)
+    gk, gd = gpu_extractor_factory(nfeatures=nf, nlevels=nl)(img)
+    assert len(ok) > 0.5 * nf
+    _assert_kps_equal(gk, ok)
+    np.testing.assert_array_equal(gd, od)

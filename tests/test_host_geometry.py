@@ -64,6 +64,14 @@ def test_rejections_are_classified():
         with pytest.raises(capi.OrbxError) as e:
             capi.geometry(**args)
         assert e.value.code == capi.ORBX_ERR_GEOMETRY, args
+    # cells 2084 / 4168 px wide and levels of 1170 / 2310 cells were refused until round 3 (limits of 2000 px and 1024 cells): accepted now
+    assert capi.geometry(w=4200, h=900, nfeatures=40, nlevels=1)[0]["cell_w"] == 4168
+    assert capi.geometry(w=4200, h=3000, nfeatures=60, nlevels=1)[0]["cell_w"] == 2084
+    assert capi.geometry(w=4200, h=3000, nfeatures=40, nlevels=2)[0]["cell_w"] == 4168
+    assert [l["grid_cols"] * l["grid_rows"] for l in capi.geometry(w=2080, h=1568, nfeatures=12000, nlevels=1)] == [2310]
+    # the boundary of what is left: a staged band is two own rows + 2 halo + 6 ring rows of the cell's width and must stay below
+    # 64 KiB (16-bit pixel offsets): 6500 px is accepted, 6501 is ORBX_ERR_CAPACITY (the reference has no such limit)
+    assert capi.geometry(w=6532, h=4600, nfeatures=20, nlevels=1)[0]["cell_w"] == 6500
     with pytest.raises(capi.OrbxError) as e:
-        capi.geometry(w=4200, h=900, nfeatures=40, nlevels=1)           # cells 2084 px wide: fine for the reference, not for k_fast_cells
+        capi.geometry(w=6533, h=4600, nfeatures=20, nlevels=1)
     assert e.value.code == capi.ORBX_ERR_CAPACITY
