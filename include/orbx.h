@@ -136,9 +136,8 @@ int orbm_hamming256(const uint8_t* a, const uint8_t* b);
  * The kernels compute the distances on the matrix cores (int8 MFMA on +-1 encoded bits, exact); ORBX_MATCH_MFMA=0 in the
  * environment selects the xor + popcount kernels instead as the process default, orbm_debug_set_match_path() at run time
  * (same results; tests/test_gpu_matcher.py runs every case through both).
- * Alignment: the reference's DescriptorDistance reads a descriptor as 8 x int32, i.e. needs 4-byte alignment
- * (src/ORBmatcher.cc:1796-1801).  Here dT needs 4 bytes too; dQ needs 16 (the query block is fetched with 16-byte loads); any
- * allocator's device pointer + a multiple of 32 bytes satisfies both.  ORBX_ERR_ARG otherwise. */
+ * Alignment: 4 bytes for every descriptor array of every matcher entry point — what the reference's DescriptorDistance needs, which
+ * reads a descriptor as 8 x int32 (src/ORBmatcher.cc:1796-1801).  ORBX_ERR_ARG otherwise. */
 int orbm_match_top2(const uint8_t* Q, int nq, const uint8_t* T, int nt,
                     int32_t* best_idx, int32_t* best, int32_t* second, int device);
 int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,

@@ -79,14 +79,17 @@ __device__ __forceinline__ void scan_range(const uint32_t* __restrict__ T, int t
     }
 }
 
+struct __attribute__((aligned(4))) dwords4 { uint32_t x, y, z, w; };    // a 16-byte load that only assumes dword alignment
+
 template <int QPL>
 __device__ __forceinline__ void load_queries(const uint32_t* __restrict__ Q, int nq, int qbase, uint32_t (&q)[QPL][8]) {
 #pragma unroll
     for (int j = 0; j < QPL; j++) {
         const int qi = qbase + j * MATCH_BLOCK;
         if (qi < nq) {
-            const uint4* p = reinterpret_cast<const uint4*>(Q + (long long)qi * 8);
-            const uint4 a = p[0], c = p[1];
+            // 16 bytes per load, 4-byte alignment: all the reference asks of a descriptor row (it reads 8 x int32, src/ORBmatcher.cc:1796-1801)
+            const dwords4* p = reinterpret_cast<const dwords4*>(Q + (long long)qi * 8);
+            const dwords4 a = p[0], c = p[1];
             q[j][0] = a.x; q[j][1] = a.y; q[j][2] = a.z; q[j][3] = a.w;
             q[j][4] = c.x; q[j][5] = c.y; q[j][6] = c.z; q[j][7] = c.w;
         } else {
@@ -429,8 +432,8 @@ __global__ __launch_bounds__(256) void k_match_segments(const uint32_t* __restri
             const int t = cand[p];
             uint32_t key = KEY_NONE - 1;   // invalid candidate index: never wins, never reported
             if ((unsigned)t < (unsigned)nt) {
-                const uint4* tp = reinterpret_cast<const uint4*>(T + (long long)t * 8);
-                const uint4 a = tp[0], c = tp[1];
+                const dwords4* tp = reinterpret_cast<const dwords4*>(T + (long long)t * 8);
+                const dwords4 a = tp[0], c = tp[1];
                 uint32_t d = 0;
                 d = bcnt_acc(qw[0] ^ a.x, d); d = bcnt_acc(qw[1] ^ a.y, d); d = bcnt_acc(qw[2] ^ a.z, d); d = bcnt_acc(qw[3] ^ a.w, d);
                 d = bcnt_acc(qw[4] ^ c.x, d); d = bcnt_acc(qw[5] ^ c.y, d); d = bcnt_acc(qw[6] ^ c.z, d); d = bcnt_acc(qw[7] ^ c.w, d);
@@ -554,7 +557,7 @@ int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
     hipStream_t stream = (hipStream_t)stream_;
     if (nq < 0 || nt < 0 || nt >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
     if (nq == 0) return ORBX_OK;
-    if (((uintptr_t)dQ & 15) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
+    if (((uintptr_t)dQ & 3) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
     const bool mfma = use_mfma();
     constexpr int QPL = 2, QT = MF_QT;                        // popcount form: 2 queries per lane; MFMA form: QT query tiles per wave
     const int q_per_block = mfma ? 128 * QT : MATCH_BLOCK * QPL;
@@ -598,7 +601,7 @@ int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const u
     hipStream_t stream = (hipStream_t)stream_;
     if (nbatch < 0 || cap < 1 || cap >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
     if (nbatch == 0) return ORBX_OK;
-    if (((uintptr_t)dQ & 15) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
+    if (((uintptr_t)dQ & 3) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
     if (use_mfma()) {
         constexpr int QT = MF_QT;                                // 256 queries per workgroup: four workgroups per ~1000-feature frame
         hipLaunchKernelGGL(k_match_batch_mfma<QT>, dim3((cap + 128 * QT - 1) / (128 * QT), nbatch), dim3(256), MF_LDS_BYTES, stream, (const uint32_t*)dQ, d_nq,
@@ -620,7 +623,7 @@ int orbm_match_top2_segments_device(const uint8_t* dQ, int nq, const uint8_t* dT
     hipStream_t stream = (hipStream_t)stream_;
     if (nq < 0 || nt < 0 || !d_seg_off || !d_cand) return ORBX_ERR_ARG;
     if (nq == 0) return ORBX_OK;
-    if (((uintptr_t)dQ & 3) || ((uintptr_t)dT & 15)) return ORBX_ERR_ARG;
+    if (((uintptr_t)dQ & 3) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
     hipLaunchKernelGGL(k_match_segments, dim3((nq + 3) / 4), dim3(256), 0, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt, d_seg_off,
                        d_cand, d_best_idx, d_best, d_second);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;

@@ -207,3 +207,42 @@ def test_top2_property_hypothesis(match_path):
         assert np.array_equal(gi, ri) and np.array_equal(gb, rb) and np.array_equal(gs, rs)
 
     prop()
+
+
+def test_descriptor_arrays_need_only_dword_alignment(match_path):
+    """device arrays that start 4 bytes into an allocation — all the alignment the reference's DescriptorDistance needs
+    (8 x int32 reads, src/ORBmatcher.cc:1796-1801) — through the dense, the batched and the candidate-list kernels"""
+    torch = pytest.importorskip("torch")
+    nq, nt = 700, 1300
+    Q, T = synth.descriptors(nq, 91), synth.descriptors(nt, 92)
+    T[100:900:5] = T[7]
+    bq = torch.zeros(nq * 32 + 4, dtype=torch.uint8, device="cuda"); bq[4:] = torch.from_numpy(Q.reshape(-1)).cuda()
+    bt = torch.zeros(nt * 32 + 4, dtype=torch.uint8, device="cuda"); bt[4:] = torch.from_numpy(T.reshape(-1)).cuda()
+    out = torch.zeros((3, nq), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert (bq.data_ptr() + 4) % 16 == 4
+    ri, rb, rs = orc.match_top2(Q, T)
+    capi.match_top2_device(bq.data_ptr() + 4, nq, bt.data_ptr() + 4, nt, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), st)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    np.testing.assert_array_equal(o[0], ri); np.testing.assert_array_equal(o[1], rb); np.testing.assert_array_equal(o[2], rs)
+    dn = torch.tensor([nq, nt], dtype=torch.int32, device="cuda")
+    out.zero_()
+    capi.match_top2_batch_device(bq.data_ptr() + 4, dn[0:1].data_ptr(), bt.data_ptr() + 4, dn[1:2].data_ptr(), 1, nt, out[0].data_ptr(), out[1].data_ptr(),
+                                 out[2].data_ptr(), st)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    np.testing.assert_array_equal(o[0], ri); np.testing.assert_array_equal(o[1], rb); np.testing.assert_array_equal(o[2], rs)
+    rng = np.random.default_rng(5)
+    seg, cand = _random_segments(rng, nq, nt, 50)
+    dseg, dcand = torch.from_numpy(seg).cuda(), torch.from_numpy(cand).cuda()
+    out.zero_()
+    rc = capi.lib().orbm_match_top2_segments_device(bq.data_ptr() + 4, nq, bt.data_ptr() + 4, nt, dseg.data_ptr(), dcand.data_ptr(), out[0].data_ptr(),
+                                                    out[1].data_ptr(), out[2].data_ptr(), st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    si, sb, ss = orc.match_top2_segments(Q, T, seg, cand)
+    np.testing.assert_array_equal(o[0], si); np.testing.assert_array_equal(o[1], sb); np.testing.assert_array_equal(o[2], ss)
+    # 2-byte alignment is refused
+    assert capi.lib().orbm_match_top2_device(bq.data_ptr() + 2, nq, bt.data_ptr() + 4, nt, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), st) == capi.ORBX_ERR_ARG
