@@ -1,4 +1,4 @@
-// LanePipeline — the throughput configuration of the ORB front-end for C++ hosts, written against the C ABI
+// LanePipeline — the throughput configuration of the ORB front-end for C++ hosts (NOTES.md §4.5), written against the C ABI
 // only (include/orbx.h): no HIP headers, no torch.  The Python twin is orb_slam_amd/pipeline.py.
 //
 // A step's B consecutive frames are cut into G lanes of B/G consecutive frames.  Every lane owns an extractor handle
@@ -50,7 +50,7 @@ public:
         lanes_.resize(G_);
         // Stream placement.  The HIP runtime binds a stream to one of its hardware queues (GPU_MAX_HW_QUEUES, 4 by default) when
         // the stream is created: new queues until 4 exist, then the least-loaded one.  Streams on one hardware queue are
-        // launched in order.  Measured best (rocprofv3 Queue_Id column): every lane stream on a hardware queue of
+        // launched in order.  Measured best (NOTES.md §4.5, rocprofv3 Queue_Id column): every lane stream on a hardware queue of
         // its own, the blur side streams (created inside the extractor handles) sharing those queues.  Creating the G handles
         // first and the G lane streams after them gives that placement in a fresh process, but streams other libraries created
         // earlier shift it: three candidate sets of lane streams are created (behind 0, 1 and 2 spacer streams); tune() — an

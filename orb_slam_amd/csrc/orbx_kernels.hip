@@ -1072,7 +1072,7 @@ int launch_debug_nth(const float* d_resp, int n, int nth, int* d_out) {
 // come from lanes j-1 / j+1 by DPP wave shifts; the 7 taps of each of the lane's pixels are byte-weight dwords over the
 // three aligned dwords (v_dot4_u32_u8, no shifted copies).  The last row sums live in registers as row pairs (loop fully
 // unrolled), so the column pass is three v_dot2_u32_u16 + one multiply-add per pixel; each lane stores its 4 output pixels as
-// one dword.  Details at blur_strip below and in DESIGN.md 4.2.
+// one dword.  Details at blur_strip below and in NOTES.md 4.2.
 // Reads the UNBLURRED plane and writes a separate blurred plane, which is what the reference's in-place
 // filter computes (its border taps read the unblurred reflect-101 border; here: reflect-101 index math).
 constexpr int BLUR_STRIP_DW = 62;   // useful dwords per wave (lanes 1..62; lanes 0 and 63 are halo)

@@ -18,7 +18,7 @@ def init(backend, world, rank, local_rank=0):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     # No device_id here: with it torch builds the RCCL communicator (and RCCL its streams) eagerly, BEFORE the pipeline creates
-    # its lane streams, and the runtime's stream -> hardware-queue placement the lanes rely on would shift.
+    # its lane streams, and the runtime's stream -> hardware-queue placement the lanes rely on would shift (NOTES.md §4.5).
     # The communicator is built lazily at the first collective instead: the barrier in front of the timed region.
     dist.init_process_group(backend, rank=rank, world_size=world)
     return dist

@@ -1,4 +1,4 @@
-"""Host side of the throughput configuration: a step's B consecutive frames go through G lanes of B/G
+"""Host side of the throughput configuration (NOTES.md §4.5): a step's B consecutive frames go through G lanes of B/G
 consecutive frames, each lane with its own extractor handle and HIP stream, every frame matched against its predecessor.
 
 Lanes never join.  The only cross-lane dependency is the one frame per lane whose predecessor lies in the lane to its left
@@ -45,7 +45,7 @@ class LanePipeline:
         self.do_match = do_match
         # Stream placement.  The HIP runtime binds a stream to one of its hardware queues (GPU_MAX_HW_QUEUES, 4 by default) when the
         # stream is created: new queues until 4 exist, then the least-loaded one.  Streams on one hardware queue are launched in
-        # order.  Measured best (rocprofv3 Queue_Id column): every lane stream on a hardware queue of its own, the
+        # order.  Measured best (NOTES.md §4.5, rocprofv3 Queue_Id column): every lane stream on a hardware queue of its own, the
         # blur side streams (created inside the extractor handles) sharing those queues.  Creating the G handles first and the G
         # lane streams after them, back to back, gives that placement in a fresh process — but any library that created streams
         # earlier (torch's pool, an RCCL communicator) shifts it.  So the pipeline does not trust the creation order: it creates

@@ -20,7 +20,7 @@ ap.add_argument("--nfeatures", type=int, default=1000)
 ap.add_argument("--batch", type=int, default=512); ap.add_argument("--ring", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--window", type=float, default=100.0)
 ap.add_argument("--voc-k", type=int, default=10); ap.add_argument("--voc-l", type=int, default=6)
-ap.add_argument("--lanes", type=int, default=4, help="the step's frames go through this many free-running lanes (own handles + stream each, DESIGN.md §4.5)")
+ap.add_argument("--lanes", type=int, default=4, help="the step's frames go through this many free-running lanes (own handles + stream each, NOTES.md §4.5)")
 a = ap.parse_args()
 B, w, h = a.batch, a.w, a.h
 G = max(1, min(a.lanes, B))
@@ -36,7 +36,7 @@ dev = "cuda"
 i32, u8, f32, f64 = torch.int32, torch.uint8, torch.float32, torch.float64
 names = ["extract", "undistort_grid", "bow", "query_setup", "window_search", "dense_match"]
 acc = {k: 0.0 for k in names}
-# handles first, then the lane streams back to back (stream -> hardware queue placement)
+# handles first, then the lane streams back to back (stream -> hardware queue placement, NOTES.md §4.5)
 exs = [capi.ORBextractor(nfeatures=a.nfeatures, max_batch=b) for _ in range(G)]
 vocs = [capi.ORBVocabulary.from_nodes(a.voc_k, a.voc_l, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"]) for _ in range(G)]   # a handle owns scratch
 raw = [capi.stream_create(0) for _ in range(G)]
