@@ -509,11 +509,10 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     const float inv_nd = 1.0f / (float)nd;
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;          // fill of this wave's queues (wave-uniform)
 
-    // B: exact FAST score of m <= 64 queued pixels (all of them passed the pair test); scored corners are remembered in q3
-    auto score_step = [&](const uint16_t* q, int m) {
-        int p = 0, sc = 0;
-        if (lane < m) {
-            p = q[lane];
+    // B: exact FAST score of <= 64 queued pixels (`on` lanes hold one each); scored corners are remembered in q3
+    auto score_vals = [&](bool on, int p) {
+        int sc = 0;
+        if (on) {
             const uint8_t* c = s_img + p;
             sc = fast_score_raw(c, S, c[0], tmin);
             s_sc[p] = (uint8_t)sc;
@@ -525,6 +524,7 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
             n3 += add;                              // beyond Q3CAP: the band takes the dense NMS sweep
         }
     };
+    auto score_step = [&](const uint16_t* q, int m) { score_vals(lane < m, lane < m ? (int)q[lane] : 0); };
     // A2: OpenCV's opposite-pair pre-test of m <= 64 queued pixels; survivors go to q2, which is scored whenever it holds a full wave
     auto pair_step = [&](const uint16_t* q, int m) {
         int pass = 0, p = 0;
@@ -612,10 +612,17 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
         for (; base + RG <= i_end; base += RG) round(std::true_type{}, base);
         if (base < i_end) round(std::false_type{}, base);
     }
-    // drain this wave's queues
+    // Drain this wave's queues.  The remainders (< 64 each) run with a fraction of the lanes whatever is done, and this tail is a chain
+    // of dependent LDS round trips (measured by cutting the kernel short: the drain costs 0.28 of the 1.08 ms per 1024 VGA frames,
+    // the whole dense phase 0.34).  So the pair test is skipped here: it is only a filter (a pixel that fails it scores below tmin,
+    // i.e. 0) and costs a queue round trip plus the same 16 ring reads the score needs; the pixel remainder and the pair-tested
+    // remainder are scored together in one pass (two when they exceed a wave).
     if (n0) expand_step(q0, n0);
-    if (n1) pair_step(q1, n1);
-    if (n2) score_step(q2, n2);
+    for (int base = 0; base < n1 + n2; base += 64) {
+        const int i = base + lane;
+        const bool on = i < n1 + n2;
+        score_vals(on, on ? (int)(i < n1 ? q1[i] : q2[i - n1]) : 0);
+    }
     if (n3 > Q3CAP && lane == 0) hdr->overflow = 1;
     __syncthreads();
 
