@@ -77,9 +77,9 @@ constexpr int BLUR_ROWS = ORBX_BLUR_ROWS;   // k_blur: output rows per wave stri
 constexpr int BLUR_ROWS_SMALL = 8;          // ... when the launch group cannot fill the chip anyway (a wave's strip is a serial chain of rows)
 constexpr int RZ_ROWS = ORBX_RZ_ROWS;       // k_resize: output rows per workgroup (a tall tile amortises the table -> source -> LDS latency chain)
 // The two launch shapes of k_fast_cells: threads per work item, dwords (4 pixels) per lane and round, band size in pixels, widest
-// cell.  Per WAVE the kernel keeps a queue of flagged dwords (one round plus one slice of 64), of expanded pixel offsets (a slice of
-// 64 dwords = up to 256 pixels on top of a remainder < 64), of pair-test survivors (one step of 64 on top of a remainder < 64)
-// and of scored corners (the NMS work list; a band that overflows it takes a dense sweep instead).
+// cell.  Per WAVE the kernel keeps a queue of flagged dwords (one step of 64 on top of a remainder < 64), of expanded pixel offsets
+// (two of a dword's four pixels per 64 dwords = up to 128 on top of a remainder < 64), of pair-test survivors (one step of 64 on top
+// of a remainder < 64) and of scored corners (the NMS work list; a band that overflows it takes a dense sweep instead).
 struct FastShape { int threads, ppt, band_px, max_cw; };
 #ifndef ORBX_FS
 #define ORBX_FS 256, 2, 8192, 500
@@ -91,8 +91,11 @@ constexpr FastShape FAST_SMALL = {ORBX_FS};   // VGA-class grids
 constexpr FastShape FAST_LARGE = {ORBX_FL};   // 720p / 1080p-class grids.  max_cw 6500: two own rows + 2 halo rows + the 6 ring rows of a staged band
                                               // (pitch <= 6512) stay below 64 KiB, the range of the 16-bit pixel offsets; the kernel's float division
                                               // p -> (p / S, p % S) is exact for every S <= 8192, p < 65536 (checked exhaustively)
-constexpr int FAST_Q1CAP = 320, FAST_Q2CAP = 128, FAST_Q3CAP = 256;
-constexpr int fast_q0cap(int ppt) { return 64 * ppt + 64; }
+// (round 3: the kernel is latency-bound at the occupancy its LDS allows — 1.06 / 1.15 / 1.30 / 1.56 ms per 1024 VGA frames at
+//  6 / 5 / 4 / 3 workgroups per CU — so the queues are kept as small as their invariants allow: every producer drains as soon as
+//  a slice of 64 is full)
+constexpr int FAST_Q1CAP = 192, FAST_Q2CAP = 128, FAST_Q3CAP = 192;
+constexpr int fast_q0cap(int) { return 128; }
 constexpr int fast_wave_queue_bytes(int ppt) { return fast_q0cap(ppt) * 4 + FAST_Q1CAP * 2 + FAST_Q2CAP * 2 + FAST_Q3CAP * 2; }
 struct BandGeom {
     int16_t x0, x1;           // the cell's column range (inclusive)

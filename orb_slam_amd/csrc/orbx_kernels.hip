@@ -558,8 +558,8 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
                 if (f[j]) q1[n1 + lane_rank(mk)] = (uint16_t)(4 * idx + j);
                 n1 += __popcll(mk);
             }
+            if (j & 1) while (n1 >= 64) { n1 -= 64; pair_step(q1 + n1, 64); }      // after two pixels per dword: q1 never holds more than 63 + 128
         }
-        while (n1 >= 64) { n1 -= 64; pair_step(q1 + n1, 64); }
     };
 
     // A1: SWAR compass test, 4 pixels per lane and step (see the header of this section)
@@ -603,9 +603,9 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
             if (mk) {
                 if (Q) q0[n0 + lane_rank(mk)] = Q | (uint32_t)i;
                 n0 += __popcll(mk);
+                if (n0 >= 64) { n0 -= 64; expand_step(q0 + n0, 64); }          // q0 never holds more than 63 + 64
             }
         }
-        while (n0 >= 64) { n0 -= 64; expand_step(q0 + n0, 64); }
     };
     {
         int base = i_begin;
