@@ -48,7 +48,7 @@ I8_MFMA_PEAK_TOPS = 5000.0   # dense int8 = 2x the 2.5 PFLOP/s bf16 dense peak (
 CONFIGS = {
     "vga": dict(width=640, height=480, nfeatures=1000, batch=1024, ring=2048, match=True, baseline_config=1),
     "vga_extract": dict(width=640, height=480, nfeatures=1000, batch=1024, ring=2048, match=False, baseline_config=1),
-    "hd1080": dict(width=1920, height=1080, nfeatures=2000, batch=128, ring=256, match=True, baseline_config=2),
+    "hd1080": dict(width=1920, height=1080, nfeatures=2000, batch=256, ring=512, match=True, baseline_config=2),
     "match100k": dict(n=100000, baseline_config=4),
 }
 

@@ -332,7 +332,7 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
             if (cw <= 0 || ch <= 0) continue;
             max_px = std::max(max_px, cw * ch);
             if (cw > shape.max_cw) { err = "grid cell wider than " + std::to_string(shape.max_cw) + " pixels"; return ORBX_ERR_CAPACITY; }   // two own rows + halo of the staged band must fit 64 KiB (16-bit pixel offsets)
-            const int nd = (3 + cw + 6 + 3) / 4;
+            const int nd = fast_row_dwords(3, cw);
             max_img = std::max(max_img, nd * 4 * (ch + 6));
             max_chunks = std::max(max_chunks, (nd * 4 * (c.y1 - c.y0 + 1) + 63) / 64);
         }

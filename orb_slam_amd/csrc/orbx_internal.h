@@ -97,6 +97,9 @@ constexpr FastShape FAST_LARGE = {ORBX_FL};   // 720p / 1080p-class grids.  max_
 constexpr int FAST_Q1CAP = 192, FAST_Q2CAP = 128, FAST_Q3CAP = 192;
 constexpr int fast_q0cap(int) { return 128; }
 constexpr int fast_wave_queue_bytes(int ppt) { return fast_q0cap(ppt) * 4 + FAST_Q1CAP * 2 + FAST_Q2CAP * 2 + FAST_Q3CAP * 2; }
+// dwords per row of a staged band (k_fast_cells): the cell's columns + 3 ring columns either side from the dword-aligned start
+// `xoff` bytes to the left, rounded up to whole 16-byte chunks (the LDS-DMA staging moves 16 bytes per lane)
+__host__ __device__ constexpr int fast_row_dwords(int xoff, int cw) { return (((xoff + cw + 6 + 3) >> 2) + 3) & ~3; }
 struct BandGeom {
     int16_t x0, x1;           // the cell's column range (inclusive)
     int16_t y0, y1;           // rows this band owns (inclusive)

@@ -44,7 +44,7 @@ def test_two_ranks_bare_command():
     assert d["config"]["parity_checked_frames"] >= 16 and d["config"]["parity_mismatches"] == 0       # both ranks checked their last step
     assert d["config"]["host_submit_ms_per_step"] > 0
     hd, mt = d["also"]["hd1080"], d["also"]["match100k"]
-    assert hd["scaling"] == "weak" and len(hd["per_rank"]) == 2 and hd["per_rank"][0]["frames"] == hd["per_rank"][1]["frames"] == 2 * 128
+    assert hd["scaling"] == "weak" and len(hd["per_rank"]) == 2 and hd["per_rank"][0]["frames"] == hd["per_rank"][1]["frames"] == 2 * 256
     assert hd["config"]["parity_checked_frames"] >= 16 and hd["config"]["parity_mismatches"] == 0
     assert mt["scaling"] == "strong" and mt["config"]["queries_per_gpu"] == 50000 and len(mt["per_rank"]) == 2
     assert mt["config"]["parity_checked_rows"] >= 100 and mt["config"]["parity_mismatches"] == 0
