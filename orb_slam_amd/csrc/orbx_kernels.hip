@@ -73,6 +73,18 @@ static inline int frame_item_blocks(const Batch& b, int per_frame) {
 
 constexpr unsigned long long UMAX_NIBBLES = 0x3689ABCDDEEEFFFFull;   // umax[v] for v = 0..15 (15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3)
 
+// inclusive prefix sum over the 64 lanes in six DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast15 / row_bcast31
+// across them) — no LDS round trips (__shfl_up is a ds_bpermute per step).  Needs all 64 lanes active.
+__device__ __forceinline__ int wave_scan_inclusive(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -635,21 +647,36 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
 
     // N: 3x3 strict NMS of the scored pixels of the band's own rows.  Scores of the halo columns / rows and of every non-corner
     // are 0, which is what cv::FAST's NMS sees outside the cell view.
-    auto nms_px = [&](int p, int s) {
+    auto nms_test = [&](int p, int s) -> bool {       // strict maximum of its 3 x 3 neighbourhood: the survivor's bit is set
         const uint8_t* sp = s_sc + p;
         const int mx = imax3(imax3(sp[-1], sp[1], sp[-S]), imax3(sp[S], sp[-S - 1], sp[-S + 1]), imax(sp[S - 1], sp[S + 1]));
         if (s > mx) {
             const int bit = p - q_own_lo;
             atomicOr(&cmask[bit >> 6], 1ull << (bit & 63));
+        }
+        return s > mx;
+    };
+    auto nms_px = [&](int p, int s) {                 // ... counted per lane (the dense sweep's lanes are out of step)
+        if (nms_test(p, s)) {
             if (s >= g.fast_th) atomicAdd(&hdr->n_hi, 1);
             if (s >= 7) atomicAdd(&hdr->n_lo, 1);
         }
     };
     if (!hdr->overflow) {
-        for (int i = lane; i < n3; i += 64) {
-            const int p = q3[i];
-            if (p >= q_own_lo && p < q_own_hi) nms_px(p, s_sc[p]);
+        int c_hi = 0, c_lo = 0;                       // counted per wave: two ballots per pass instead of two LDS atomics per survivor
+        for (int i0 = 0; i0 < n3; i0 += 64) {
+            const int i = i0 + lane;
+            int s = 0;
+            bool keep = false;
+            if (i < n3) {
+                const int p = q3[i];
+                s = s_sc[p];
+                keep = p >= q_own_lo && p < q_own_hi && nms_test(p, s);
+            }
+            c_hi += __popcll(__ballot(keep && s >= g.fast_th));
+            c_lo += __popcll(__ballot(keep && s >= 7));
         }
+        if (lane == 0 && (c_hi | c_lo)) { atomicAdd(&hdr->n_hi, c_hi); atomicAdd(&hdr->n_lo, c_lo); }      // (fastTh < 7: scores of 5 and 6 count in n_hi only)
     } else {
         const int d_lo = q_own_lo >> 2, d_hi = q_own_hi >> 2;
         for (int i = d_lo + tid; i < d_hi; i += NT) {
@@ -671,17 +698,12 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
         unsigned long long m = 0ull;
         if (c0 + tid < nchunks) m = cmask[c0 + tid];
         const int cnt = __popcll(m);
-        int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
+        const int incl = wave_scan_inclusive(cnt);
         if (NW > 1) {
             if (lane == 63) hdr->wsum[wave] = incl;
             __syncthreads();
         }
-        int run = run_base + incl - cnt, total = NW > 1 ? 0 : __shfl(incl, 63, 64);
+        int run = run_base + incl - cnt, total = NW > 1 ? 0 : __builtin_amdgcn_readlane(incl, 63);
         if (NW > 1) {
 #pragma unroll
             for (int wv = 0; wv < NW; wv++) { const int t = hdr->wsum[wv]; if (wv < wave) run += t; total += t; }
@@ -779,9 +801,7 @@ __global__ __launch_bounds__(64) void k_quota(Batch b) {
     for (int c0 = 0; c0 < nCells; c0 += 64) {
         const int c = c0 + lane;
         const int v = c < nCells ? q.nret[c] : 0;
-        int incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        const int incl = wave_scan_inclusive(v);
         if (c < nCells) {
             CellSel r;
             r.thr = q.thr[c]; r.nkeys = q.nkeys[c];
@@ -789,7 +809,7 @@ __global__ __launch_bounds__(64) void k_quota(Batch b) {
             r.out_off = bad ? 0 : base + incl - v;
             sel[c] = r;
         }
-        base += __shfl(incl, 63, 64);
+        base += __builtin_amdgcn_readlane(incl, 63);
     }
     if (lane == 0) {
         if (bad) b.status[frame] = ORBX_ERR_CAPACITY;
