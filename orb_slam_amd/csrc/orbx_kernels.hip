@@ -85,9 +85,14 @@ __device__ __forceinline__ int wave_scan_inclusive(int v) {
     return v;
 }
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_scan_inclusive(v), 63); }   // all 64 lanes active
+
+// sum over each row of 16 lanes, left in every lane of the row: four rotate-and-add steps (DPP row_ror 8, 4, 2, 1)
+__device__ __forceinline__ int row16_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);
     return v;
 }
 
@@ -1386,9 +1391,7 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
         }
         int p10 = (int)a_su - HALF_PATCH * (int)a_si;
         int p01 = (par - HALF_PATCH) * (int)a_si + 2 * (int)a_i;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) { p10 += __shfl_xor(p10, off, 64); p01 += __shfl_xor(p01, off, 64); }
-        m10 = p10; m01 = p01;
+        m10 = row16_sum(p10); m01 = row16_sum(p01);             // the keypoint's 16 lanes (no LDS round trips: this sits in front of the angle arithmetic)
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
