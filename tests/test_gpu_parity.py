@@ -264,11 +264,11 @@ def test_randomised_configurations():
     """a slice of tools/fuzz_parity.py: random sizes / constructor arguments / families, byte-exact or a documented rejection"""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "60", "7"], capture_output=True, text=True, timeout=600)
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "400", "7"], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads(res.stdout.strip().splitlines()[-1])
-    assert out["mismatches"] == [] and out["bit_exact"] >= 30
-    assert out["bit_exact"] + out["geometry_the_reference_cannot_process"] + out["implementation_limit"] == 60
+    assert out["mismatches"] == [] and out["bit_exact"] >= 200
+    assert out["bit_exact"] + out["geometry_the_reference_cannot_process"] + out["implementation_limit"] == 400
 
 
 def test_cpp_device_resident_pipeline(tmp_path):

@@ -6,11 +6,11 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; D=$R/gpurun_out/$1; mkdir -p $D; cd /tmp; export TMPDIR=/tmp
 B=1024      # bench.py's default frames per step = frames per launch of the serial command
 if [ "$2" != "lines" ]; then
-SER="--steps 10 --warmup 2 --no-cpu-baseline --lanes 1 --region-timing --min-seconds 0"
+SER="--steps 10 --warmup 2 --no-cpu-baseline --lanes 1 --region-timing --min-seconds 0 --no-also --no-parity"
 # serial command (one stream, one launch per kernel over all B frames): kernel-trace stats and the two HBM counter passes
 ORBX_OVERLAP=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats -- python $R/bench.py $SER > $D/stats.log 2>&1
-ORBX_OVERLAP=0 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D -o fetch -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --lanes 1 --region-timing --min-seconds 0 > $D/fetch.log 2>&1
-ORBX_OVERLAP=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D -o write -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --lanes 1 --region-timing --min-seconds 0 > $D/write.log 2>&1
+ORBX_OVERLAP=0 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D -o fetch -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --lanes 1 --region-timing --min-seconds 0 --no-also --no-parity > $D/fetch.log 2>&1
+ORBX_OVERLAP=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D -o write -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --lanes 1 --region-timing --min-seconds 0 --no-also --no-parity > $D/write.log 2>&1
 $R/tools/run_pmc.sh $1_pmc
 python $R/tools/pmc_traffic.py $D/fetch_counter_collection.csv $D/write_counter_collection.csv $R/profiles/traffic.json $B $R/gpurun_out/$1_pmc 256 > $D/traffic.log 2>&1
 cp $R/profiles/traffic.json $D/traffic.json
@@ -19,18 +19,18 @@ python $R/tools/pmc_table.py $R/gpurun_out/$1_pmc/a_counter_collection.csv $R/gp
 python $R/tools/pmc_table.py $D/fetch_counter_collection.csv $D/write_counter_collection.csv > $D/pmc_fetch_write.txt 2>&1
 fi
 # the default command (4 lanes) under the kernel trace, then the bench lines proper
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_overlap -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --min-seconds 0 > $D/stats_overlap.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_match -- python $R/bench.py --config match100k --steps 5 --warmup 2 --no-cpu-baseline --min-seconds 0 > $D/stats_match.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_overlap -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --min-seconds 0 --no-also --no-parity > $D/stats_overlap.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_match -- python $R/bench.py --config match100k --steps 40 --warmup 5 --no-cpu-baseline --min-seconds 0 --no-parity > $D/stats_match.log 2>&1
 cd $R
-timeout 400 python bench.py > $D/bench.json 2> $D/bench.err
-timeout 300 python bench.py --lanes 1 --no-cpu-baseline > $D/bench_one_lane.json 2>/dev/null
-timeout 300 python bench.py --region-timing --no-cpu-baseline > $D/bench_region_timing.json 2>/dev/null
-timeout 300 python bench.py --config vga_extract --no-cpu-baseline > $D/bench_extract_only.json 2>/dev/null
-timeout 400 python bench.py --config hd1080 > $D/bench_hd.json 2>/dev/null
-timeout 300 python bench.py --family 0 --no-cpu-baseline > $D/bench_noise.json 2>/dev/null
-timeout 300 python bench.py --config match100k > $D/bench_match100k.json 2>/dev/null
-ORBX_MATCH_MFMA=0 timeout 300 python bench.py --config match100k --no-cpu-baseline > $D/bench_match100k_popcount.json 2>/dev/null
-timeout 300 python bench.py --gpus 2 --backend gloo --share-device --no-cpu-baseline --batch 512 > $D/bench_two_ranks_one_gpu_gloo.json 2>/dev/null
+timeout 600 python bench.py > $D/bench.json 2> $D/bench.err          # the driver's command: headline + also{hd1080, match100k}, parity legs, CPU baselines
+Q="--no-cpu-baseline --no-also --min-seconds 2"
+timeout 300 python bench.py --lanes 1 $Q > $D/bench_one_lane.json 2>/dev/null
+timeout 300 python bench.py --region-timing $Q > $D/bench_region_timing.json 2>/dev/null
+timeout 300 python bench.py --config vga_extract $Q > $D/bench_extract_only.json 2>/dev/null
+timeout 300 python bench.py --family 0 $Q > $D/bench_noise.json 2>/dev/null
+ORBX_MATCH_MFMA=0 timeout 300 python bench.py --config match100k --no-cpu-baseline --min-seconds 2 > $D/bench_match100k_popcount.json 2>/dev/null
+timeout 600 python bench.py --gpus 2 --backend gloo --share-device --no-cpu-baseline --batch 512 --min-seconds 2 --also-min-seconds 1 > $D/bench_two_ranks_one_gpu_gloo.json 2>/dev/null
+timeout 200 python tools/corun_probe.py > $D/corun_probe.json 2>/dev/null
 (timeout 100 python tools/bench_single_frame.py; timeout 100 python tools/bench_single_frame.py 1920 1080 2000; timeout 100 orb_slam_amd/cpp/bench_single_frame; timeout 100 orb_slam_amd/cpp/bench_single_frame 1920 1080 2000) > $D/single_frame.txt 2>/dev/null
 timeout 100 tools/microbench/valu_rate2 > $D/valu_issue_rates2.txt 2>&1
 timeout 100 tools/microbench/mfma_valu_mix > $D/mfma_valu_mix.txt 2>&1
@@ -39,4 +39,4 @@ timeout 200 python tools/bench_kf_search.py 2>/dev/null | tail -1 > $D/kf_search
 timeout 300 python tools/bench_frontend.py --window 15 2>/dev/null | tail -1 > $D/frontend_w15.json
 timeout 300 python tools/bench_frontend.py 2>/dev/null | tail -1 > $D/frontend_w100.json
 ls $D | wc -l
-python -c "import json; d=json.load(open('$D/bench.json')); print(d['value'], d['ms_per_step'], d['roofline'], d['cpu_baseline']['value'], d.get('cpu_baseline_allcores'))"
+python -c "import json; d=json.load(open('$D/bench.json')); print(d['value'], d['ms_per_step'], d['roofline'], d['cpu_baseline']['value'], d.get('cpu_baseline_allcores')); print({k: (v['value'], v['roofline']['frac']) for k, v in d['also'].items()})"
