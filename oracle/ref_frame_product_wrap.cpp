@@ -69,9 +69,9 @@ int ref_frame_product_build(const void* cam_, const uint8_t* img, int stride, in
     Frame& F = *pF;
     const int N = (int)F.mvKeys.size();
     if (N > cap) return -3;
+    if (N == 0) return 0;                      // the constructor returned at src/Frame.cc:64-65: nothing after the extractor call ran
     *levels_out = F.mnScaleLevels;
     *scale_out = F.mfScaleFactor;
-    if (N == 0) return 0;
     memcpy(keys_out, F.mvKeys.data(), (size_t)N * sizeof(OKeyPoint));
     for (int i = 0; i < N; i++) memcpy(desc_out + (size_t)i * 32, F.mDescriptors.ptr(i), 32);
     memcpy(keys_un_out, F.mvKeysUn.data(), F.mvKeysUn.size() * sizeof(OKeyPoint));
