@@ -403,6 +403,8 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
                    "host_submit_ms_per_step": round(float(counters[6]) / world, 4),
                    "mean_keypoints_per_frame": round(float(counters[1]) / total_frames, 2),
                    "frames_with_error_status": int(counters[2]), "accepted_matches_last_frame": accepted,
+                   "accepted_note": "consecutive S-blocks frames are independent images, so few matches pass best <= 50 && best < 0.6 * second; "
+                                    "what the match leg computes is checked against the oracle in the parity leg (integer-equal top-2)",
                    "library_build_id": capi.build_id()},
         "per_rank": [{"rank": r, "frames": int(row[0]), "elapsed_s": round(row[3], 4), "frames_per_s": round(row[0] / row[3], 1)} for r, row in enumerate(rows)],
         "roofline": roofline,
