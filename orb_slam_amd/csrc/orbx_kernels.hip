@@ -426,6 +426,12 @@ __global__ __launch_bounds__(256) void k_pyramid(Batch b, int group) {
 //   * every wave remembers the pixels it gave a score; the NMS visits those (a dense sweep over the score plane only where a
 //     wave's list overflowed: noise-like bands), survivors set bits in a q-space bitmask, the raster-ordered list comes from
 //     the same chunk scan as before.
+// Round 3 (1.12 -> 0.99 ms per 1024 VGA frames).  Cut short phase by phase the kernel costs staging 0.33 + dense phase 0.34 + drain
+// 0.28 + NMS 0.06 + list 0.07 ms, and with its dynamic LDS padded 1.06 / 1.15 / 1.30 / 1.56 ms at 6 / 5 / 4 / 3 workgroups per CU: it is
+// bound by latency at the occupancy its LDS allows, not by instruction issue alone.  Hence: the queues are as small as their
+// invariants allow (7 workgroups per CU on VGA grids), the staging moves 16 bytes per lane, the drain scores both remainders in
+// one pass without the pair test, the list output scans with DPP adds instead of ds_bpermute and counts by ballot.  (NOTES.md 8.2b;
+// what did NOT help: pooling the waves' remainders behind extra barriers, an L2 prefetch of a later band, smaller bands.)
 struct FastHdr { int n_hi, n_lo, overflow, pad1; int wsum[8]; int pad2[4]; };
 static_assert(sizeof(FastHdr) == 64, "LDS carve");
 
