@@ -375,9 +375,9 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
 
 
 // Shape of k_fast_cells (orbx_internal.h: FAST_SMALL / FAST_LARGE).  VGA-class grids (largest cell view <= 12288 px and at most
-// 500 px wide) take the small shape: 256 threads over 8192-pixel bands.  Everything else takes the large shape: 512 threads over
-// 10240-pixel bands, 4 work items per CU as long as one needs <= 40 KB; where the cell shape pushes it over, slightly smaller
-// bands restore the fourth.
+// 500 px wide) take the small shape: 256 threads over 8192-pixel bands.  Everything else takes the large shape: since round 3
+// 256 threads over 7168-pixel bands (rounds 1-2: 512 threads over 10240-pixel bands, kept at 4 work items per CU by the
+// band-shrinking loop below, which only applies to shapes whose bands start above 8192 px).
 int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::string& err) {
     constexpr int LDS_FOR_FOUR = (160 * 1024) / 4 - 64;
     const FastShape small = FAST_SMALL, large = FAST_LARGE;

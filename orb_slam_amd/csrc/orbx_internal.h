@@ -85,10 +85,12 @@ struct FastShape { int threads, ppt, band_px, max_cw; };
 #define ORBX_FS 256, 2, 8192, 500
 #endif
 #ifndef ORBX_FL
-#define ORBX_FL 512, 2, 10240, 6500
+#define ORBX_FL 256, 2, 7168, 6500
 #endif
 constexpr FastShape FAST_SMALL = {ORBX_FS};   // VGA-class grids
-constexpr FastShape FAST_LARGE = {ORBX_FL};   // 720p / 1080p-class grids.  max_cw 6500: two own rows + 2 halo rows + the 6 ring rows of a staged band
+constexpr FastShape FAST_LARGE = {ORBX_FL};   // 720p / 1080p-class grids (round 3: 256 threads over 7168-px bands — per 256 1080p frames 1.84 ms
+                                              // against 2.06 for the 512 threads over 10240-px bands of rounds 1-2; 256 threads at 5120 / 6144 / 8192 /
+                                              // 12288 px: 1.91 / 1.91 / 1.90 / 1.95).  max_cw 6500: two own rows + 2 halo rows + the 6 ring rows of a staged band
                                               // (pitch <= 6512) stay below 64 KiB, the range of the 16-bit pixel offsets; the kernel's float division
                                               // p -> (p / S, p % S) is exact for every S <= 8192, p < 65536 (checked exhaustively)
 // (round 3: the kernel is latency-bound at the occupancy its LDS allows — 1.06 / 1.15 / 1.30 / 1.56 ms per 1024 VGA frames at
