@@ -360,8 +360,6 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
     roofline = dict(hbm)
     roofline.update({"kernel": dom, "avg_launch_ms": round(stage_ms[dom], 4), "frames_per_launch": B, "timing": timing})
     mix = rep["mix"]
-    if mix and wl_tag == "hd_1920x1080_nf2000" and "fast_cells_large" in mix:
-        mix = dict(mix, fast_cells=mix["fast_cells_large"])       # 1080p grids take the 512-thread work-item shape of k_fast_cells
     if valu_launch and mix and dom in mix:
         cpi = mix[dom]["cycles_per_inst_lo"]
         ach = valu_launch / (stage_ms[dom] * 1e-3)
