@@ -271,6 +271,18 @@ def test_randomised_configurations():
     assert out["bit_exact"] + out["geometry_the_reference_cannot_process"] + out["implementation_limit"] == 400
 
 
+def test_randomised_launch_groups():
+    """a slice of tools/fuzz_batch.py: the throughput path (per-level resize, full-batch kernels, XCD renumbering from 64 frames, calls
+    spanning several launch groups) on random sizes / arguments / families / batch sizes, every frame against the oracle"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_batch.py"), "40", "5"], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["mismatches"] == [] and out["bit_exact_cases"] >= 20 and out["frames_checked"] >= 1000
+    assert out["bit_exact_cases"] + out["geometry_the_reference_cannot_process"] + out["implementation_limit"] == 40
+
+
 def test_cpp_device_resident_pipeline(tmp_path):
     """orb_slam_amd/cpp/example_pipeline.cpp: extract -> undistort/grid -> bag of words -> WindowSearch(last, current) chained on the
     device from plain C++ through the C ABI (device buffers via orbx_device_alloc), compared with the oracle chain"""
