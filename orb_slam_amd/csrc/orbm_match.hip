@@ -172,21 +172,26 @@ __global__ __launch_bounds__(MATCH_BLOCK) void k_match_batch(const uint32_t* __r
 //   A (32 trains x 32 k): lane l supplies row l % 32, k-bytes 16 * (l / 32) .. + 15 of the chunk;  B (32 k x 32 queries): likewise
 //   with the query as column;  D: lane l holds column (query) l % 32, register r row (train) 8 * (r / 4) + 4 * (l / 32) + r % 4
 //   (tools/microbench/mfma_layout.hip checks this on the device).  Both operands use the same bit -> k map, so its order is free.
-// Workgroup = 4 waves; wave w keeps QT tiles of 32 queries as B operands (+-1) in registers for the whole scan.  Train tiles of
+// Workgroup = 4 waves; wave w keeps QT = 4 tiles of 32 queries as B operands (+-1) in registers for the whole scan.  Train tiles of
 // 32 descriptors are expanded cooperatively into LDS (-+64, i.e. negated and scaled) through a 256-entry byte -> 8 bytes table
 // and kept in a ring of four; rows are padded to 272 bytes so that the 16-byte operand reads of 16 consecutive lanes cover all
-// 64 banks.  Measured (100k x 100k): 2.27 ms = 4.4e12 pairs/s against 5.25 ms for the popcount kernels; 1024 x (1000 x 1000):
-// 0.265 against 0.57 ms.  What did not work: a min3 tree per tile with the key updates only behind a wave vote (the vote fires
+// 64 banks.  Measured (100k x 100k): 1.75 ms = 5.7e12 pairs/s (round 2: 1.99) against 5.2 ms for the popcount kernels; 1024 x
+// (1000 x 1000): 0.21 (0.26) against 0.57 ms.  What did not work: a min3 tree per tile with the key updates only behind a wave vote (the vote fires
 // for ~half the tiles at these chunk lengths and its branches keep the scheduler from pairing VALU with MFMAs: 3.2 ms).
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
 constexpr int MF_PITCH = 272;                      // bytes per expanded train row in LDS (256 + 16)
 constexpr int MF_TILE_BYTES = 32 * MF_PITCH;
 constexpr int MF_LDS_BYTES = 4096 + 4 * MF_TILE_BYTES;   // two tables + ring of four train tiles
-// query tiles of 32 per wave.  2 (199 VGPRs, two waves per SIMD) is the measured optimum: 3 and 4 tiles compile without spills into
-// the AGPR half of the register file at one wave per SIMD and are slower (100k x 100k: 1.99 / 2.58 / 2.25 ms; per-frame batches
-// 0.255 / 0.376 / 0.311 ms per 1024 frames)
-constexpr int MF_QT = 2;
+// Query tiles of 32 per wave.  Round 2 ran chunk-major (every chunk's MFMA for all QT tiles, 2 x QT accumulator sets): QT = 2 at 199
+// VGPRs was all that fitted two waves per SIMD (QT = 3 / 4 at one wave: 100k x 100k 1.99 / 2.58 / 2.25 ms).  The chain-major loop
+// below keeps two accumulator sets whatever QT is, so QT = 4 fits 256 VGPRs (amdgpu_waves_per_eu(2, 2) on the kernels; one B
+// register quad is spilled around the first tile, nothing inside the loop): 100k x 100k 1.75 ms, per-frame batches 0.212 ms per 1024
+// frames (chain-major with QT = 2: 1.98 / 0.246; QT = 4 at one wave per SIMD: 2.18 / 0.290).
+#ifndef ORBX_MF_QT
+#define ORBX_MF_QT 4
+#endif
+constexpr int MF_QT = ORBX_MF_QT;
 
 // Per-query-tile scan state as four named scalars per field: an array here is promoted to a vector register tuple, and every
 // conditional update then shuffles the whole tuple (v_mov_b64 x 4 per key).
@@ -264,16 +269,6 @@ __device__ __forceinline__ void mfma_scan(const uint32_t* __restrict__ Qp, int n
         const uint4 av = *reinterpret_cast<const uint4*>(p);
         return (i32x4_t){(int)av.x, (int)av.y, (int)av.z, (int)av.w};
     };
-    // 8 * QT MFMAs of one train tile against the wave's query tiles (prologue form, nothing to overlap with)
-    auto mfma_tile = [&](i32x16_t (&acc)[QT], int buf) {
-        const uint8_t* tile = tiles + buf * MF_TILE_BYTES + n * MF_PITCH + 16 * kh;
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const i32x4_t a = load_a(tile + 32 * c);
-#pragma unroll
-            for (int qt = 0; qt < QT; qt++) acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, breg[qt][c], c == 0 ? cinit : acc[qt], 0, 0, 0);
-        }
-    };
     // tile-local pair (k1 <= k2, 16-bit keys) of the tile at tbase -> global keys, merged into the running pair
     auto merge_tile = [&](uint32_t& G1, uint32_t& G2, uint32_t k1, uint32_t k2, uint32_t tbase) {
         const uint32_t g1 = ((k1 >> 7) << KEY_SHIFT) + (k1 & 127u) + tbase;
@@ -282,69 +277,104 @@ __device__ __forceinline__ void mfma_scan(const uint32_t* __restrict__ Qp, int n
         G1 = min(G1, g1);
         G2 = min(hi, min(G2, g2));
     };
-    // ... of the last tile of the range: rows beyond t1 are zero padding, their keys must not compete
-    auto top2_last = [&](const i32x16_t (&acc)[QT], int it) {
-        const int tbase = t0 + it * 32;
-        static_for<QT>([&](auto qc) {
-            constexpr int qt = decltype(qc)::value;
-            uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                if (tbase + 8 * (r / 4) + (r % 4) + 4 * kh < t1) top2_update(k1, k2, (uint32_t)acc[qt][r]);
-            if (k1 != KEY_NONE) merge_tile(K1.at<qt>(), K2.at<qt>(), k1, k2, (uint32_t)tbase);
-        });
-    };
-    // Software pipeline over a ring of four LDS tiles.  In iteration `it` the wave ISSUES the MFMAs of tile it + 1 (A operands
-    // already in registers) and, while the matrix pipe works on them, runs the VALU top-2 of tile it: a wave issues in order, so
-    // VALU placed behind the MFMA block would wait for the pipe — every MFMA is followed by the top-2 steps of two accumulator
-    // registers of the PREVIOUS tile (4 VALU ops in the MFMA's ~36-cycle shadow; tools/microbench/mfma_valu_mix: up to 6 hide
-    // completely), pinned with sched_barrier.  Once a chunk's MFMAs are issued its A register is refilled from tile it + 2, a whole
-    // iteration ahead of its use; tile it + 3 is expanded and tile it + 4 loaded.  No branches: everything beyond the range is
-    // predicated or lands in ring slots nobody consumes.
+    // Chain-major software pipeline (round 3).  A "chain" is the 8 dependent MFMAs (K = 256) of one train tile against ONE of the
+    // wave's query tiles; chains alternate between two accumulator sets.  While the matrix pipe works on chain n the VALU runs the
+    // top-2 of chain n - 1 (two accumulator registers behind every MFMA, pinned with sched_barrier) — so only 2 x 16 accumulator
+    // registers are live whatever QT is, and a wave can keep FOUR query tiles (128 VGPRs of B operands) at two waves per SIMD:
+    // every 16-byte A operand read from LDS feeds four MFMAs instead of two, and the train-tile expansion and the barrier are paid
+    // once per 32 MFMAs.  (Round 2 ran chunk-major with 2 x QT accumulator sets: QT = 2 was all that fitted.)
+    static_assert(QT == 2 || QT == 4, "chains alternate accumulator sets by the parity of the query tile");
     expand(load_raw(0), 0);
     expand(load_raw(1), 1);
     expand(load_raw(2), 2);
     uint32_t raw_next = load_raw(3);
     __syncthreads();
-    i32x16_t accA[QT], accB[QT];
-    mfma_tile(accA, 0);
+    i32x16_t accP, accQ;                                       // chain qt writes accP (qt even) or accQ (qt odd)
     i32x4_t areg[8];
     const uint8_t* lane_tile = tiles + n * MF_PITCH + 16 * kh;
 #pragma unroll
-    for (int c = 0; c < 8; c++) areg[c] = load_a(lane_tile + 1 * MF_TILE_BYTES + 32 * c);
-    auto body = [&](i32x16_t (&cur)[QT], i32x16_t (&nxt)[QT], int it) {      // requires it + 1 < ntiles; tile `it` is complete (not the padded one)
-        const uint8_t* next_tile = lane_tile + ((it + 2) & 3) * MF_TILE_BYTES;
-        uint32_t k1[QT], k2[QT];
+    for (int c = 0; c < 8; c++) areg[c] = load_a(lane_tile + 32 * c);
+    // one chain: MFMAs of (tile, qt) into `acc`; in their shadow the top-2 of the previous chain `prv` (HAVE: there is one; MASKED:
+    // it belongs to the padded last tile); REFILL: the A registers are reloaded for the next tile as their last user issues
+    auto chain = [&](auto qc, i32x16_t& acc, const i32x16_t& prv, auto have_c, auto masked_c, uint32_t& pk1, uint32_t& pk2, int prv_tbase,
+                     bool refill, const uint8_t* next_tile) {
+        constexpr int qt = decltype(qc)::value;
+        constexpr bool HAVE = decltype(have_c)::value, MASKED = decltype(masked_c)::value;
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-            static_for<QT>([&](auto qc) {
-                constexpr int qt = decltype(qc)::value;
-                nxt[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[c], breg[qt][c], c == 0 ? cinit : nxt[qt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (c == 0) {
-                    k1[qt] = min((uint32_t)cur[qt][0], (uint32_t)cur[qt][1]);
-                    k2[qt] = max((uint32_t)cur[qt][0], (uint32_t)cur[qt][1]);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[c], breg[qt][c], c == 0 ? cinit : acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (HAVE) {
+                if (MASKED) {
+                    if (c == 0) { pk1 = KEY_NONE; pk2 = KEY_NONE; }
+#pragma unroll
+                    for (int r = 2 * c; r < 2 * c + 2; r++)
+                        if (prv_tbase + 8 * (r / 4) + (r % 4) + 4 * kh < t1) top2_update(pk1, pk2, (uint32_t)prv[r]);
+                } else if (c == 0) {
+                    pk1 = min((uint32_t)prv[0], (uint32_t)prv[1]);
+                    pk2 = max((uint32_t)prv[0], (uint32_t)prv[1]);
                 } else {
-                    top2_update(k1[qt], k2[qt], (uint32_t)cur[qt][2 * c]);
-                    top2_update(k1[qt], k2[qt], (uint32_t)cur[qt][2 * c + 1]);
+                    top2_update(pk1, pk2, (uint32_t)prv[2 * c]);
+                    top2_update(pk1, pk2, (uint32_t)prv[2 * c + 1]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            areg[c] = load_a(next_tile + 32 * c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (refill) areg[c] = load_a(next_tile + 32 * c);
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    auto finish = [&](auto qc, uint32_t pk1, uint32_t pk2, int tbase) {      // the finished chain's tile-local pair into the query tile's running pair
+        constexpr int qt = decltype(qc)::value;
+        if (pk1 != KEY_NONE) merge_tile(K1.at<qt>(), K2.at<qt>(), pk1, pk2, (uint32_t)tbase);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    uint32_t pk1 = KEY_NONE, pk2 = KEY_NONE;
+    // one tile: its QT chains; the first one finishes the last chain of the tile before (if any)
+    auto tile_pass = [&](int it, auto first_c, auto last_c) {
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;      // no tile before / the padded last tile
+        const int tbase = t0 + it * 32;
+        const uint8_t* next_tile = lane_tile + ((it + 1) & 3) * MF_TILE_BYTES;
         static_for<QT>([&](auto qc) {
             constexpr int qt = decltype(qc)::value;
-            merge_tile(K1.at<qt>(), K2.at<qt>(), k1[qt], k2[qt], (uint32_t)(t0 + it * 32));
+            i32x16_t& acc = (qt & 1) ? accQ : accP;
+            const i32x16_t& prv = (qt & 1) ? accP : accQ;
+            const bool refill = !LAST && qt == QT - 1;
+            if constexpr (qt == 0) {
+                if constexpr (FIRST) chain(qc, acc, prv, F{}, F{}, pk1, pk2, 0, refill, next_tile);
+                else {
+                    chain(qc, acc, prv, T{}, F{}, pk1, pk2, tbase - 32, refill, next_tile);
+                    finish(std::integral_constant<int, QT - 1>{}, pk1, pk2, tbase - 32);
+                }
+            } else {
+                if constexpr (LAST) chain(qc, acc, prv, T{}, T{}, pk1, pk2, tbase, refill, next_tile);
+                else chain(qc, acc, prv, T{}, F{}, pk1, pk2, tbase, refill, next_tile);
+                finish(std::integral_constant<int, qt - 1>{}, pk1, pk2, tbase);
+            }
         });
+    };
+    auto advance = [&](int it) {                               // tile it + 3 into the ring, tile it + 4 requested
         expand(raw_next, (it + 3) & 3);
         raw_next = load_raw(it + 4);
         __syncthreads();
     };
-    int it = 0;
-    for (; it + 2 < ntiles; it += 2) { body(accA, accB, it); body(accB, accA, it + 1); }
-    if (it + 1 < ntiles) { body(accA, accB, it); top2_last(accB, it + 1); }
-    else top2_last(accA, it);
+    if (ntiles == 1) tile_pass(0, T{}, T{});
+    else {
+        tile_pass(0, T{}, F{});
+        advance(0);
+        int it = 1;
+        for (; it + 1 < ntiles; ++it) { tile_pass(it, F{}, F{}); advance(it); }
+        tile_pass(it, F{}, T{});
+    }
+    {   // the last chain of the last tile: nothing left to overlap it with
+        const int tbase = t0 + (ntiles - 1) * 32;
+        const i32x16_t& prv = ((QT - 1) & 1) ? accQ : accP;
+        pk1 = KEY_NONE; pk2 = KEY_NONE;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (tbase + 8 * (r / 4) + (r % 4) + 4 * kh < t1) top2_update(pk1, pk2, (uint32_t)prv[r]);
+        finish(std::integral_constant<int, QT - 1>{}, pk1, pk2, tbase);
+    }
     // lanes l and l + 32 hold the two row halves of the same query
     static_for<QT>([&](auto qc) {
         constexpr int qt = decltype(qc)::value;
@@ -359,7 +389,7 @@ __device__ __forceinline__ void mfma_scan(const uint32_t* __restrict__ Qp, int n
 
 // Many small problems (frame-to-frame matching): blockIdx.y = problem, sizes read on the device.
 template <int QT>
-__global__ __launch_bounds__(256) void k_match_batch_mfma(const uint32_t* __restrict__ Q, const int32_t* __restrict__ nqs, const uint32_t* __restrict__ T,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_match_batch_mfma(const uint32_t* __restrict__ Q, const int32_t* __restrict__ nqs, const uint32_t* __restrict__ T,
                                                           const int32_t* __restrict__ nts, int cap, int32_t* __restrict__ idx, int32_t* __restrict__ best,
                                                           int32_t* __restrict__ second) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -384,7 +414,7 @@ __global__ __launch_bounds__(256) void k_match_batch_mfma(const uint32_t* __rest
 
 // Large single problem: grid = (query blocks, train splits); partial (k1, k2) per (split, query) for k_match_merge.
 template <int QT>
-__global__ __launch_bounds__(256) void k_match_split_mfma(const uint32_t* __restrict__ Q, int nq, const uint32_t* __restrict__ T, int nt, int chunk,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_match_split_mfma(const uint32_t* __restrict__ Q, int nq, const uint32_t* __restrict__ T, int nt, int chunk,
                                                           uint32_t* __restrict__ pk1, uint32_t* __restrict__ pk2) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int qblock0 = blockIdx.x * (128 * QT);
@@ -603,7 +633,7 @@ int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const u
     if (nbatch == 0) return ORBX_OK;
     if (((uintptr_t)dQ & 3) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
     if (use_mfma()) {
-        constexpr int QT = MF_QT;                                // 256 queries per workgroup: four workgroups per ~1000-feature frame
+        constexpr int QT = MF_QT;                                // 512 queries per workgroup: two workgroups per ~1000-feature frame
         hipLaunchKernelGGL(k_match_batch_mfma<QT>, dim3((cap + 128 * QT - 1) / (128 * QT), nbatch), dim3(256), MF_LDS_BYTES, stream, (const uint32_t*)dQ, d_nq,
                            (const uint32_t*)dT, d_nt, cap, d_best_idx, d_best, d_second);
         return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
