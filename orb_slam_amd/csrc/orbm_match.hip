@@ -559,6 +559,20 @@ int orbm_debug_set_match_path(int path) {
     return ORBX_OK;
 }
 
+// compute units of the current device (cached per host thread and device)
+static int device_cus() {
+    static thread_local int cached_dev = -1, cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return cus;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        (void)hipGetLastError();
+        cached_dev = dev;
+    }
+    return cus;
+}
+
 // Scratch of the split form (partial top-2 per train split): stream-ordered allocation.  The device's default pool keeps what it
 // has handed out once (release threshold raised on first use: with the default of 0 every synchronise returned the memory to the
 // driver and the next large match paid the allocation again); where the runtime has no memory pools the call falls back to
@@ -595,6 +609,20 @@ int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
     // enough workgroups to fill 256 CUs several times over, but chunks of >= 256 train descriptors
     const int target_wgs = mfma ? 2048 : 4096;
     int nsplit = std::max(1, std::min((nt + 255) / 256, (target_wgs + qblocks - 1) / qblocks));
+    if (mfma) {
+        // The MFMA workgroups run two per CU and take as long as their chunk is, so the launch proceeds in rounds of 2 x CUs
+        // workgroups: a split count that leaves the last round nearly empty wastes it (100k x 100k: 196 query blocks x 11 splits =
+        // 4.2 rounds took 1.69 ms, x 13 = 4.98 rounds 1.62 ms, x 8 = 3.06 rounds 1.81 ms).  Cost model: rounds x tiles per chunk, in
+        // the neighbourhood of the target; the smallest split count among the best wins (less to merge).
+        const int slots = 2 * device_cus();
+        const int lo = std::max(1, nsplit / 2), hi = std::max(1, std::min((nt + 255) / 256, 2 * nsplit));
+        long best_cost = LONG_MAX;
+        for (int ns = lo; ns <= hi; ++ns) {
+            const long rounds = ((long)qblocks * ns + slots - 1) / slots, tiles = ((nt + ns - 1) / ns + 31) / 32;
+            const long cost = rounds * tiles * 64 + ns;              // (+ ns: the merge kernel reads 2 keys per split and query)
+            if (cost < best_cost) { best_cost = cost; nsplit = ns; }
+        }
+    }
     int chunk = nt > 0 ? (nt + nsplit - 1) / nsplit : 1;
     if (mfma) chunk = (chunk + 31) / 32 * 32;                // whole train tiles
     nsplit = nt > 0 ? (nt + chunk - 1) / chunk : 1;
