@@ -1,0 +1,20 @@
+#!/bin/bash
+# Everything a round ends with, in ONE call on the GPU box (≈12 GPU-minutes): the artifacts of profiles/ (collect_round_artifacts.sh,
+# run_pmc_hd.sh), the whole GPU test suite, the torchrun two-rank line, the C++ lanes example, a front-end fuzz slice and the default line.
+# usage: tools/round_end.sh <name>   (-> gpurun_out/<name>/, gpurun_out/<name>hd/)
+N=${1:?name}
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+tools/collect_round_artifacts.sh $N 2>&1 | tail -3 | cut -c1-300
+tools/run_pmc_hd.sh ${N}hd 2>&1 | tail -1 | cut -c1-200
+cd $R; (time python -m pytest tests -m gpu -q) > gpurun_out/$N/pytest_gpu.txt 2>&1; grep "passed\|failed" gpurun_out/$N/pytest_gpu.txt
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --backend gloo --share-device --no-cpu-baseline --batch 512 --min-seconds 1 --also-min-seconds 0.5 2>/dev/null | grep "^{" > gpurun_out/$N/bench_torchrun_two_ranks.json
+python - <<PY
+import numpy as np, sys
+sys.path.insert(0, "$R")
+from orb_slam_amd import synth
+synth.frames(640, 480, synth.BLOCKS, 0, 2048).tofile("/tmp/frames.raw")
+PY
+(orb_slam_amd/cpp/example_lanes 640 480 1024 2 4 /tmp/frames.raw "" 200; orb_slam_amd/cpp/example_lanes 640 480 1024 2 1 /tmp/frames.raw "" 200) > gpurun_out/$N/cpp_example_lanes.txt 2>&1; grep "frames/s\|IDENT" gpurun_out/$N/cpp_example_lanes.txt
+timeout 600 python tools/fuzz_frontend.py 3000 1004 > gpurun_out/$N/fuzz_frontend_3000.json 2>/dev/null; tail -c 200 gpurun_out/$N/fuzz_frontend_3000.json
+timeout 300 python bench.py > gpurun_out/$N/bench_final.json 2>/dev/null; python -c "
+import json; d=json.load(open('gpurun_out/$N/bench_final.json')); print(d['value'], d['roofline']['frac'], d['roofline']['traffic'], d['config']['parity_mismatches'], {k:(v['value'], v['roofline'].get('frac'), v['roofline'].get('traffic'), v['config']['parity_mismatches']) for k,v in d['also'].items()})"
