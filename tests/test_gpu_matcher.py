@@ -246,3 +246,14 @@ def test_descriptor_arrays_need_only_dword_alignment(match_path):
     np.testing.assert_array_equal(o[0], si); np.testing.assert_array_equal(o[1], sb); np.testing.assert_array_equal(o[2], ss)
     # 2-byte alignment is refused
     assert capi.lib().orbm_match_top2_device(bq.data_ptr() + 2, nq, bt.data_ptr() + 4, nt, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), st) == capi.ORBX_ERR_ARG
+
+
+def test_randomised_sizes_and_entry_points():
+    """a slice of tools/fuzz_match.py: the dense, per-frame batch and candidate-list entry points on both kernel families, sizes around the
+    kernels' tile / block / split boundaries, duplicates, low-entropy descriptors, 4-byte-aligned arrays — integer exact vs the oracle"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_match.py"), "800", "11"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["mismatches"] == 0 and out["ok"] == 800 and min(out["by_entry_point"].values()) >= 100
