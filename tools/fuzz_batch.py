@@ -82,4 +82,4 @@ for c in range(cases):
     else:
         ok += 1
 print(json.dumps({"cases": cases, "seed": seed, "bit_exact_cases": ok, "frames_checked": frames_checked, "geometry_the_reference_cannot_process": geo,
-                  "implementation_limit": lim, "mismatches": bad, "seconds": round(time.time() - t0, 1)}))
+                  "implementation_limit": lim, "mismatches": bad, "seconds": round(time.time() - t0, 1), "build": capi.build_id()}))

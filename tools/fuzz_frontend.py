@@ -142,4 +142,4 @@ for c in range(cases):
         if (int(gi[p]), int(gm[p])) != ol.distinctive(dd[segs[p]:segs[p + 1]]):
             bad.append(("distinctive", c, p)); break
     done["distinctive"] += 1
-print(json.dumps({"cases": cases, "seed": seed, "checked": done, "mismatches": bad, "seconds": round(time.time() - t0, 1)}))
+print(json.dumps({"cases": cases, "seed": seed, "checked": done, "mismatches": bad, "seconds": round(time.time() - t0, 1), "build": capi.build_id()}))

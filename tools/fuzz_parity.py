@@ -45,4 +45,4 @@ for c in range(cases):
         ok += 1
     else:
         bad.append(dict(case=c, w=w, h=h, nf=nf, sf=sf, nl=nl, st=st, th=th, fam=fam, blur=blur, n_gpu=len(got[0]), n_oracle=len(k)))
-print(json.dumps({"cases": cases, "seed": seed, "bit_exact": ok, "geometry_the_reference_cannot_process": geo, "implementation_limit": lim, "mismatches": bad, "seconds": round(time.time() - t0, 1)}))
+print(json.dumps({"cases": cases, "seed": seed, "bit_exact": ok, "geometry_the_reference_cannot_process": geo, "implementation_limit": lim, "mismatches": bad, "seconds": round(time.time() - t0, 1), "build": capi.build_id()}))
