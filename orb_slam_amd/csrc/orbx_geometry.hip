@@ -177,6 +177,12 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
                     const int bh = std::max(0, bg.y1 - bg.y0 + 1);
                     bg.cand_off = cand_off;
                     bg.cand_cap = ((cw + 1) / 2) * ((bh + 1) / 2);    // strict 3x3 maxima cannot be adjacent
+                    if (cw > 0) {                                     // (same row geometry as fast_band_task derives from x0 and cw)
+                        const int nd = fast_row_dwords((bg.x0 - 3) & 3, cw);
+                        bg.inv_nd = 1.0f / (float)nd;
+                        bg.inv_s = 1.0f / (float)(nd * 4);
+                        bg.inv_cpr = 1.0f / (float)(nd >> 2);
+                    }
                     cand_off += bg.cand_cap;
                     c.cand_cap += bg.cand_cap;
                     c.nbands++;
@@ -363,6 +369,7 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
     }
     g.ncells_total = cell_base;
     g.nbands_total = (int)out.bands.size();
+    g.nbands_magic = g.nbands_total > 1 ? (uint32_t)((1ull << 32) / (unsigned)g.nbands_total) + 1u : 0u;
     g.nbtiles_total = btile_base;
     g.nbtiles_total_s = btile_base_s;
     g.nslots = slot_base;

@@ -109,6 +109,9 @@ struct BandGeom {
     int16_t level, pad;
     int32_t cand_off;         // first Cand slot of its sub-list relative to the level's cand_base
     int32_t cand_cap;
+    // 1 / (dwords, bytes, 16-byte chunks per row of the staged band): the divisors of k_fast_cells' p -> (row, column) splits.  Computed
+    // on the host (IEEE single division, the bits the device's own 1.0f / x gives): three division sequences less in front of every wave
+    float inv_nd, inv_s, inv_cpr;
 };
 
 // Fused pyramid (k_pyramid): one launch produces `depth` consecutive levels l0+1 .. l0+depth from level l0.  A workgroup owns a
@@ -142,6 +145,7 @@ struct DevGeom {
     int nlevels;
     int ncells_total;
     int nbands_total;        // k_fast_cells work items per frame (>= ncells_total)
+    uint32_t nbands_magic;   // floor(2^32 / nbands_total) + 1 (0 for one band): block -> (frame, band) with a scalar multiply instead of a division
     int nbtiles_total, nbtiles_total_s;
     int nslots;              // sum of ndesired (max keypoints per frame)
     int nquads;              // sum of ceil(ndesired / 4): k_describe waves per frame

@@ -67,6 +67,18 @@ __device__ __forceinline__ bool frame_item(const Batch& b, int block, int per_fr
     }
     return frame < b.nframes;
 }
+// The same split with the division replaced by a multiply with magic = floor(2^32 / per_frame) + 1 (host: DevGeom::nbands_magic; 0 = one
+// item per frame): umulhi(n, magic) is n / per_frame or one more for every 32-bit n (the excess n * (magic * per_frame - 2^32) / (per_frame * 2^32)
+// is below n / 2^32 < 1), so one compare corrects it.  Everything is wave-uniform: scalar multiplies instead of the ~20 vector instructions of
+// an integer division in front of every wave of a kernel whose waves are short (k_fast_cells).
+__device__ __forceinline__ bool frame_item_magic(const Batch& b, unsigned block, unsigned per_frame, unsigned magic, int& frame, int& item) {
+    const unsigned slot = b.xcd_affinity ? block >> 3 : block;
+    unsigned fr = magic ? __umulhi(slot, magic) : slot;
+    if (fr * per_frame > slot) --fr;
+    frame = (int)(b.xcd_affinity ? fr * 8u + (block & 7u) : fr);
+    item = (int)(slot - fr * per_frame);
+    return frame < b.nframes;
+}
 static inline int frame_item_blocks(const Batch& b, int per_frame) {
     return (b.xcd_affinity ? (b.nframes + 7) / 8 * 8 : b.nframes) * per_frame;
 }
@@ -495,7 +507,7 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
         // addresses are dword-aligned only (the band starts at the dword at or left of x0 - 3), which the x4 load accepts.
         {
             const int cpr = nd >> 2, nchunks16 = nrows * cpr;
-            const float inv_cpr = 1.0f / (float)cpr;
+            const float inv_cpr = bg.inv_cpr;
             for (int q0 = 64 * wave; q0 < nchunks16; q0 += 64 * NW) {
                 const int q = q0 + lane;
                 int r, c;
@@ -508,7 +520,7 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     } else {
         // unaligned frames (level 0 only): flattened (row, dword) items assembled from byte loads, 8 in flight per lane
         const int total = nrows * nd;
-        const float inv_nd0 = 1.0f / (float)nd;
+        const float inv_nd0 = bg.inv_nd;
         const uint8_t* src0 = src + (long long)(bg.ey0 - 3) * stride64 + gxb;
         const int xm = L.w - 1 - gxb;   // never read past the row end
         for (int i0 = 0; i0 < total; i0 += NT * 8) {
@@ -536,7 +548,7 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     __syncthreads();
 
     const int tmin = g.tmin;
-    const float inv_nd = 1.0f / (float)nd;
+    const float inv_nd = bg.inv_nd;                // (1 / nd, 1 / S, 1 / cpr come with the band: BandGeom)
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;          // fill of this wave's queues (wave-uniform)
 
     // B: exact FAST score of <= 64 queued pixels (`on` lanes hold one each); scored corners are remembered in q3
@@ -703,19 +715,25 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     __syncthreads();
     // the band's keypoint list in raster order (cv::FAST's order): one lane per 64-byte chunk of the survivor bitmask
     Cand* out = b.cand + (long long)frame * g.frame_cands + L.cand_base + bg.cand_off;
-    const float inv_S = 1.0f / (float)S;
+    const float inv_S = bg.inv_s;
     int run_base = 0;
     for (int c0 = 0; c0 < nchunks; c0 += NT) {
+        // a wave whose 64 chunks lie beyond the band (waves 2 and 3 of a VGA level-0 band: 81 chunks) only keeps the barriers company:
+        // it reports a count of 0 and skips the scan, the count exchange and the output loop (wave 0 is never idle: it carries run_base)
+        const bool busy = c0 + 64 * wave < nchunks;
         unsigned long long m = 0ull;
-        if (c0 + tid < nchunks) m = cmask[c0 + tid];
-        const int cnt = __popcll(m);
-        const int incl = wave_scan_inclusive(cnt);
+        int cnt = 0, incl = 0;
+        if (busy) {
+            if (c0 + tid < nchunks) m = cmask[c0 + tid];
+            cnt = __popcll(m);
+            incl = wave_scan_inclusive(cnt);
+        }
         if (NW > 1) {
             if (lane == 63) hdr->wsum[wave] = incl;
             __syncthreads();
         }
         int run = run_base + incl - cnt, total = NW > 1 ? 0 : __builtin_amdgcn_readlane(incl, 63);
-        if (NW > 1) {
+        if (NW > 1 && busy) {
 #pragma unroll
             for (int wv = 0; wv < NW; wv++) { const int t = hdr->wsum[wv]; if (wv < wave) run += t; total += t; }
         }
@@ -744,7 +762,7 @@ template <bool ALIGNED, int NT, int PPT>
 __global__ __launch_bounds__(NT) void k_fast_cells(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int frame, item;
-    if (!frame_item(b, blockIdx.x, b.g.nbands_total, frame, item)) return;
+    if (!frame_item_magic(b, blockIdx.x, (unsigned)b.g.nbands_total, b.g.nbands_magic, frame, item)) return;
     fast_band_task<ALIGNED, NT, PPT>(b, frame, item, smem);
 }
 
