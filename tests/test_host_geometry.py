@@ -75,3 +75,25 @@ def test_rejections_are_classified():
     with pytest.raises(capi.OrbxError) as e:
         capi.geometry(w=6533, h=4600, nfeatures=20, nlevels=1)
     assert e.value.code == capi.ORBX_ERR_CAPACITY
+
+
+def test_magic_multiply_block_mapping_is_exact():
+    """k_fast_cells maps a block index to (frame, band) with umulhi(n, floor(2^32 / d) + 1) and one correcting compare
+    (orbx_kernels.hip: frame_item_magic; the constant is DevGeom::nbands_magic, made by orbx_geometry.hip).  The arithmetic restated on
+    32-bit integers: exact for every divisor and every block index a launch can have (boundaries of the quotient, powers of two, the
+    largest grids), including the products staying below 2^32 as the device computes them."""
+    rng = np.random.default_rng(3)
+    U32 = 1 << 32
+    ds = list(range(1, 300)) + [511, 512, 513, 1023, 1024, 1025, 4095, 4096, 16383, 16384, 65535, 65536, 262143] + [int(v) for v in rng.integers(2, 1 << 18, 300)]
+    for d in ds:
+        magic = (U32 // d + 1) if d > 1 else 0
+        assert magic < U32
+        ns = {0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 24) - 1, 1 << 24, (1 << 31) - d - 1} | {int(v) for v in rng.integers(0, (1 << 31) - d, 200)}
+        ns |= {k * d + e for k in (1, 7, 1000, ((1 << 31) - d) // d - 1) for e in (-1, 0, 1) if 0 <= k * d + e < (1 << 31) - d}
+        for n in ns:
+            q = (n * magic) >> 32 if magic else n
+            assert q in (n // d, n // d + 1)
+            assert q * d < U32                       # the device's 32-bit product does not wrap
+            if q * d > n:
+                q -= 1
+            assert q == n // d and n - q * d == n % d
