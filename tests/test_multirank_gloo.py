@@ -1,4 +1,4 @@
-"""N>1 path on CPU: two ranks over gloo exercise the same sharding + reduction code bench.py runs over RCCL.
+"""N>1 path on CPU: two and eight ranks over gloo exercise the same sharding + reduction code bench.py runs over RCCL.
 Each rank owns an independent image stream (no data-path collective); only timing / counters are reduced."""
 import os
 import socket
@@ -54,6 +54,27 @@ def test_two_rank_sharding_and_reduction():
     assert tot0 == tot1 and tot0[0] == 8.0                 # whole-job frame count
     assert rows0 == rows1 and rows0[0][2] != rows0[1][2]   # ranks really processed different frames
     assert tot0[1] == rows0[0][1] + rows0[1][1]
+
+
+def test_eight_rank_sharding_and_reduction():
+    """the world size the driver's scaling run ends at: eight disjoint streams, MAX of the elapsed times, whole-job sums"""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [4 * r for r in range(world)]            # rank r owns frames [4 r, 4 r + 4)
+    assert all(r[2] == float(world) for r in res)                          # MAX over ranks = the slowest rank's 1 + 7 s
+    tot, rows = res[0][3], res[0][4]
+    assert all(r[3] == tot and r[4] == rows for r in res)                  # every rank holds the same reduction
+    assert tot[0] == 4.0 * world and tot[1] == sum(row[1] for row in rows)
+    assert len({row[2] for row in rows}) == world                          # eight different streams
 
 
 def test_single_process_path():
