@@ -21,12 +21,15 @@ the timing and gathers the counters.  Run as a plain command it spawns its N ran
 the ranks it is given.  The timed region is `repeats` x K steps, with `repeats` chosen so that it lasts at least
 `--min-seconds` (default 6 s, so that a 5 s device sampler must land inside it; 0 = exactly K steps).  Prints ONE JSON line on rank 0.
 
-After the timed region (never inside it) every rank compares a sample of the LAST timed step's outputs with the CPU oracle —
-every lane border from both sides, the step border, interior frames: keypoints + descriptors byte for byte, top-2 match against
-the previous frame integer for integer — and the line carries `config.parity_checked_frames` / `config.parity_mismatches`; a
-mismatch makes the process exit 1.  The default run (`--config vga`) then also runs BASELINE.json's other GPU configurations,
-`hd1080` (configs[2]; at N > 1 this is configs[3], one 1080p stream per GPU) and `match100k` (configs[4]), for >= 1.5 s each and
-embeds them under `also` (headline keys unchanged; `--no-also` skips them).
+After the timed region (never inside it) every rank compares the LAST timed step's outputs with the CPU oracle — EVERY frame of
+the step (`--parity all`, the default: one oracle instance per host thread; `--parity sample` = lane and step borders + interior
+frames only): keypoints + descriptors byte for byte, top-2 match against the previous frame integer for integer — and the line
+carries `config.parity_checked_frames` / `config.parity_mismatches`; a mismatch makes every rank exit 1.  The default run
+(`--config vga`) then also runs, for >= 1.5 s each with the same parity leg, and embeds under `also` (headline keys unchanged;
+`--no-also` skips them): BASELINE.json's other GPU configurations — `vga_extract` (configs[1]), `hd1080` (configs[2]; at N > 1 this
+is configs[3], one 1080p stream per GPU), `match100k` (configs[4]) — and the headline configuration on the other synthetic
+families, whose corner statistics (and therefore FAST / selection cost) differ: `vga_noise` (SURVEY 8d's worst case), `vga_midtex`
+(textured: several times more corners at threshold 7 than at 20, no fallback cells), `vga_lowtex` (every cell takes the fallback).
 """
 import argparse
 import json
@@ -99,32 +102,76 @@ def effective_cores():
     return aff, quota
 
 
+def host_threads(world=1):
+    """host threads one rank may use for its CPU-side legs (frame synthesis, the parity leg's oracle pool): its share of the cores the
+    cgroup grants (LOCAL_WORLD_SIZE ranks share a node)"""
+    aff, quota = effective_cores()
+    cores = max(1, min(aff, int(math.ceil(quota)) if quota else aff))
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    return max(1, min(32, cores // local_world))
+
+
 def _cpu_worker(args):
-    """One oracle instance (instances are not re-entrant, like the reference's extractor) on its own frames."""
-    idx, w, h, nfeat, seconds, do_match = args
+    """One oracle instance (instances are not re-entrant, like the reference's extractor) on its own frames.
+    kind "port" = oracle/liborb_oracle.so; "reference" = oracle/_ref/libref_orbextractor.so (the reference's own src/ORBextractor.cc
+    compiled where it lies; its OpenCV pixel primitives resolve to the oracle's restatements)."""
+    idx, w, h, nfeat, seconds, do_match, kind = args
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
     from orb_slam_amd import synth
-    o = orc.OracleExtractor(nfeatures=nfeat)
+    o = orc.RefExtractor(nfeat) if kind == "reference" else orc.OracleExtractor(nfeatures=nfeat)
     imgs = synth.frames(w, h, synth.BLOCKS, 6000 + 64 * idx, 8)      # synthesis is outside the timed loop
     prev = o(imgs[0])[1]                                              # warm-up frame (page faults), not timed
-    done, t = 0, time.perf_counter()
+    done, t, per = 0, time.perf_counter(), []
     while time.perf_counter() - t < seconds:
+        t1 = time.perf_counter()
         _, d = o(imgs[(done + 1) % len(imgs)])
         if do_match and len(d) and len(prev):
             orc.match_top2(d, prev)
         prev = d
         done += 1
-    return done, time.perf_counter() - t
+        per.append(time.perf_counter() - t1)
+    return done, time.perf_counter() - t, per
 
 
-def cpu_baseline(w, h, nfeat, do_match, seconds):
-    """Oracle (scalar CPU restatement of the reference algorithm) timed on this host, 1 core, bounded sample.
-    The reference runs its extractor on the single Tracking thread (src/Tracking.cc:199-202), hence cores=1."""
-    done, el = _cpu_worker((0, w, h, nfeat, seconds, do_match))
-    return {"value": round(done / el, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d S-blocks %dx%d frames, oracle extract (nFeatures %d)%s, %.1f s"
-                      % (done, w, h, nfeat, " + scalar top-2 match vs previous frame" if do_match else "", el)}
+def _percentiles_ms(per):
+    import numpy as np
+    a = np.sort(np.asarray(per)) * 1e3
+    return {"median_ms": round(float(np.median(a)), 4), "p10_ms": round(float(a[int(0.1 * (len(a) - 1))]), 4),
+            "p90_ms": round(float(a[int(0.9 * (len(a) - 1))]), 4), "iterations": len(a)}
+
+
+def cpu_baseline(w, h, nfeat, do_match, seconds, kind="port"):
+    """Oracle (scalar CPU restatement of the reference algorithm) timed on this host, 1 core, bounded sample; per-frame median and
+    p10 / p90 besides the mean rate.  The reference runs its extractor on the single Tracking thread
+    (src/Tracking.cc:199-202), hence cores=1."""
+    done, el, per = _cpu_worker((0, w, h, nfeat, seconds, do_match, kind))
+    out = {"value": round(done / el, 2), "unit": "frames/s", "cores": 1, "kind": kind,
+           "sample": "%d S-blocks %dx%d frames, %s extract (nFeatures %d)%s, %.1f s"
+                     % (done, w, h, "oracle" if kind == "port" else "oracle/_ref/libref_orbextractor.so (reference src/ORBextractor.cc)", nfeat,
+                        " + scalar top-2 match vs previous frame" if do_match else "", el)}
+    out.update(_percentiles_ms(per))
+    return out
+
+
+def cpu_match_variants(nq=32, nt=20000, seconds=1.0):
+    """the two scalar matcher baselines of SURVEY.md 8d on one core: the reference's bit-trick popcount (src/ORBmatcher.cc:1794-1810)
+    and a __builtin_popcountll variant, pairs/s"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    from orb_slam_amd import synth
+    Q, T = synth.descriptors(nq, 11), synth.descriptors(nt, 12)
+    out = {}
+    for name, fn in (("bit_trick", orc.match_top2), ("popcountll", orc.match_top2_popcountll)):
+        fn(Q, T)
+        n, t = 0, time.perf_counter()
+        while time.perf_counter() - t < seconds:
+            fn(Q, T)
+            n += 1
+        out[name] = round(n * float(nq) * nt / (time.perf_counter() - t), 1)
+    out["unit"] = "pairs/s"
+    out["sample"] = "%d x %d descriptors per call, 1 core, %.0f s each" % (nq, nt, seconds)
+    return out
 
 
 def cpu_baseline_allcores(w, h, nfeat, do_match, seconds):
@@ -133,7 +180,8 @@ def cpu_baseline_allcores(w, h, nfeat, do_match, seconds):
     aff, quota = effective_cores()
     workers = max(1, min(aff, int(math.ceil(quota)) if quota else aff))
     with mp.get_context("spawn").Pool(workers) as pool:
-        res = pool.map(_cpu_worker, [(i, w, h, nfeat, seconds, do_match) for i in range(workers)])
+        res = pool.map(_cpu_worker, [(i, w, h, nfeat, seconds, do_match, "port") for i in range(workers)])
+    res = [(n, t) for n, t, _ in res]
     fps = sum(n / t for n, t in res)
     return {"value": round(fps, 1), "unit": "frames/s", "cores": workers, "kind": "port", "host_threads": aff,
             "cgroup_cpu_quota_cores": quota,
@@ -175,7 +223,7 @@ def spawn_ranks(n):
     port = free_port()
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -192,7 +240,8 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
     dev = torch.device("cuda", local_rank)
     w, h, B, nfeat, do_match = cfg["width"], cfg["height"], cfg["batch"], cfg["nfeatures"], cfg["match"]
     ring = max(cfg["ring"] // B, 1) * B
-    frames = synth.frames(w, h, a.family, dist_util.stream_first_index(rank, ring), ring)          # one independent image stream per rank
+    # one independent image stream per rank; the ranks of a node share its host cores, so each synthesises on its share of them
+    frames = synth.frames(w, h, a.family, dist_util.stream_first_index(rank, ring), ring, threads=host_threads(world))
     d_img = torch.from_numpy(frames).to(dev)
     del frames
     pipe = LanePipeline(w, h, B, lanes=a.lanes, nfeatures=nfeat, device=local_rank, do_match=do_match)   # orb_slam_amd/pipeline.py
@@ -240,7 +289,8 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
 
     # parity leg (outside the timed region): the outputs the LAST timed step left on the device against the CPU oracle
     parity = {"frames": 0, "mismatches": 0, "detail": []}
-    if not a.no_parity:
+    t_par = time.perf_counter()
+    if a.parity != "none":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import parity_sample
         last = first + nsteps - 1
@@ -249,7 +299,9 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
         def host_frame(j):
             return synth.frame(w, h, a.family, i0 + (last * B + j) % ring)
 
-        parity = parity_sample.check_step(pipe, host_frame, parity_sample.sample_indices(B, G), nfeat)
+        sample = range(B) if a.parity == "all" else parity_sample.sample_indices(B, G)
+        parity = parity_sample.check_step(pipe, host_frame, sample, nfeat, threads=host_threads(world))
+    t_par = time.perf_counter() - t_par
 
     stage = pipe.stage_times()
     pipe.stage_timing(0)
@@ -310,12 +362,12 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
 
     # RCCL: the only collectives of the run (MAX of the timing, all-gather of the counters)
     tmax, counters, rows = dist_util.reduce_run(dist, elapsed, [nsteps * B, kp_mean * nsteps * B, bad_status, elapsed, parity["frames"],
-                                                                parity["mismatches"], host_submit_ms],
+                                                                parity["mismatches"], host_submit_ms, float(torch.cuda.current_device())],
                                                 dev if a.backend == "nccl" else torch.device("cpu"))
     placement = pipe.placement
     if rank != 0:
         pipe.close()
-        return None
+        return {"_mismatches": int(counters[5])}
     total_frames = float(counters[0])
     a_extract, a_match, per_stage = algorithmic_bytes(w, h, nfeat)
     region_ms = {k: (ms / n if n else 0.0) for k, (ms, n) in stage.items()}      # per LAUNCH: one lane's slice of b frames
@@ -333,7 +385,7 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
 
     # counters replayed from profiles/ (PMC passes cannot run inside this process): only when measured on THIS build
     # the two workloads with committed counter passes: VGA / 1000 (profiles/traffic.json) and 1080p / 2000 (profiles/traffic_hd1080.json)
-    wl_tag = {(640, 480, 1000, 1): "vga_640x480_nf1000", (1920, 1080, 2000, 1): "hd_1920x1080_nf2000"}.get((w, h, nfeat, a.family))
+    wl_tag = {(640, 480, 1000, 1): "vga_640x480_nf1000", (1920, 1080, 2000, 1): "hd_1920x1080_nf2000"}.get((w, h, nfeat, a.family)) if do_match else None
     traffic_file = "traffic_hd1080.json" if wl_tag == "hd_1920x1080_nf2000" else "traffic.json"
     rep = load_replayed_counters(capi.build_id(), traffic_file)
     traffic, valu_insts, valu_launch = None, None, None
@@ -387,7 +439,7 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
         "dtype": "u8",
         "data": "synthetic",
         "config": {"workload": "%s: %dx%d grayscale stream, 8 levels, nFeatures %d, %s frames, extract%s (BASELINE.json configs[%d]%s)" % (
-                       a.config, w, h, nfeat, {0: "S-noise", 1: "S-blocks", 3: "S-lowtex"}.get(a.family, str(a.family)),
+                       a.config, w, h, nfeat, synth.FAMILY_NAMES.get(a.family, str(a.family)),
                        " + Hamming top-2 match vs previous frame" if do_match else " only", cfg["baseline_config"],
                        " + the frame-to-frame match of the metric" if a.config == "vga" else ""),
                    "frames_per_step_per_gpu": B, "resident_frames_per_gpu": ring,
@@ -395,8 +447,10 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
                                   "(own extractor handle + HIP stream each), frame-to-frame matches across lane borders via event-ordered hand-off" % (B, G, b),
                    "lanes": G, "lane_placement": placement,
                    "parity_checked_frames": int(counters[4]), "parity_mismatches": int(counters[5]),
-                   "parity_note": "outputs of the LAST timed step vs the CPU oracle, after the timed region, on every rank: first + last frame of every lane, "
-                                  "the step border, interior frames; keypoints + descriptors byte-equal, top-2 match vs the previous frame integer-equal",
+                   "parity_note": "outputs of the LAST timed step vs the CPU oracle, after the timed region, on every rank: %s; keypoints + descriptors "
+                                  "byte-equal, top-2 match vs the previous frame integer-equal (%.1f s on %d host threads)"
+                                  % ("EVERY frame of the step" if a.parity == "all" else "first + last frame of every lane, the step border, interior frames",
+                                     t_par, host_threads(world)),
                    "parity_detail": parity["detail"],
                    "host_submit_ms_per_step": round(float(counters[6]) / world, 4),
                    "mean_keypoints_per_frame": round(float(counters[1]) / total_frames, 2),
@@ -404,7 +458,8 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
                    "accepted_note": "consecutive S-blocks frames are independent images, so few matches pass best <= 50 && best < 0.6 * second; "
                                     "what the match leg computes is checked against the oracle in the parity leg (integer-equal top-2)",
                    "library_build_id": capi.build_id()},
-        "per_rank": [{"rank": r, "frames": int(row[0]), "elapsed_s": round(row[3], 4), "frames_per_s": round(row[0] / row[3], 1)} for r, row in enumerate(rows)],
+        "per_rank": [{"rank": r, "device": int(row[7]), "frames": int(row[0]), "elapsed_s": round(row[3], 4), "frames_per_s": round(row[0] / row[3], 1),
+                      "host_submit_ms": round(row[6], 4), "parity_checked_frames": int(row[4])} for r, row in enumerate(rows)],
         "roofline": roofline,
         "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(pipe_gbs / HBM_PEAK_GBS, 5), "frac_of_achievable": round(pipe_gbs / HBM_ACHIEVABLE_GBS, 5),
@@ -433,6 +488,12 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
     torch.cuda.empty_cache()
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, h, nfeat, do_match, a.cpu_seconds)
+        if do_match:
+            out["cpu_baseline"]["match_variants"] = cpu_match_variants()
+        if a.cpu_reference_seconds > 0 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_orbextractor.so")):
+            # the north_star's literal wording ("next to the reference src/ORBextractor.cc"): the reference's own translation unit, prebuilt
+            # by oracle/Makefile where /root/reference exists and shipped with the tree; same arithmetic as the port
+            out["cpu_baseline_reference_source"] = cpu_baseline(w, h, nfeat, do_match, a.cpu_reference_seconds, kind="reference")
         if a.cpu_allcores_seconds > 0:
             out["cpu_baseline_allcores"] = cpu_baseline_allcores(w, h, nfeat, do_match, a.cpu_allcores_seconds)
     return out
@@ -497,7 +558,7 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
     checksum = int(out3[1, :nq].sum().item()) if nq else 0
     # parity leg (outside the timed region): sampled query rows of the last call against the oracle's sequential scan
     checked, mism = 0, 0
-    if not a.no_parity and nq:
+    if a.parity != "none" and nq:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as orc
         import numpy as np
@@ -510,7 +571,7 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
     tmax, counters, rows = dist_util.reduce_run(dist, elapsed, [float(nq) * n * nsteps, checksum, elapsed, checked, mism],
                                                 dev if a.backend == "nccl" else torch.device("cpu"))
     if rank != 0:
-        return None
+        return {"_mismatches": int(counters[4])}
     pairs = float(counters[0])
     value = pairs / tmax
     a_match = 32 * (nq + n) + 12 * nq
@@ -567,7 +628,7 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--nfeatures", type=int, default=None)
-    ap.add_argument("--family", type=int, default=1, help="0 noise, 1 blocks (default), 3 lowtex")
+    ap.add_argument("--family", type=int, default=1, help="0 noise, 1 blocks (default), 3 lowtex, 4 midtex (orb_slam_amd/csrc/synth_frames.c)")
     ap.add_argument("--no-match", action="store_true", help="extract only (same as --config vga_extract for the VGA stream)")
     ap.add_argument("--lanes", type=int, default=4,
                     help="a step's frames go through this many concurrent lanes (own extractor handle + HIP stream each); 1 = one stream")
@@ -575,8 +636,15 @@ def main():
                     help="also time every kernel inside the timed region (HIP events between the kernels of every lane: costs a few percent)")
     ap.add_argument("--min-seconds", type=float, default=6.0,
                     help="repeat the --steps block until the timed region lasts at least this long (0: exactly --steps steps)")
-    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the last timed step's outputs")
-    ap.add_argument("--no-also", action="store_true", help="headline configuration only (the default run also measures hd1080 and match100k)")
+    ap.add_argument("--parity", default="all", choices=["all", "sample", "none"],
+                    help="oracle comparison of the LAST timed step's outputs: every frame (default), lane / step borders + interior frames, or none")
+    ap.add_argument("--no-parity", action="store_true", help="same as --parity none")
+    ap.add_argument("--cpu-reference-seconds", type=float, default=4.0,
+                    help="CPU sample of oracle/_ref/libref_orbextractor.so (the reference's own ORBextractor.cc), when that file is present; 0 disables")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even at world size 1 (the RCCL communicator, barrier and collectives then run as at N > 1)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="headline configuration only (the default run also measures vga_extract, hd1080, match100k and the other frame families)")
     ap.add_argument("--also-min-seconds", type=float, default=1.5, help="timed region of each embedded configuration")
     ap.add_argument("--also-cpu-seconds", type=float, default=5.0, help="CPU baseline sample of each embedded configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -585,19 +653,26 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo")
     ap.add_argument("--share-device", action="store_true", help="functional smoke of the N>1 path on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     a = ap.parse_args()
+    if a.no_parity:
+        a.parity = "none"
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a.gpus))
 
     import torch
-    from orb_slam_amd import dist_util
+    from orb_slam_amd import dist_util, synth
     world, rank, local_rank = dist_util.env_ranks()
     if world == 1 or a.share_device:
         local_rank = 0
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d wants cuda:%d but this process sees %d device(s) (one process per GPU; --share-device for a 1-GPU functional run)"
+                         % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    dist = dist_util.init(a.backend, world, rank, local_rank)    # "nccl" is RCCL on ROCm
+    numa = dist_util.bind_to_gpu_numa(local_rank) if world > 1 and not a.share_device else None
+    dist = dist_util.init(a.backend, world, rank, local_rank, force=a.force_dist)    # "nccl" is RCCL on ROCm
     if a.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (a.gpus, world))
+
     def run(a_, name):
         cfg = dict(CONFIGS[name])
         for k in ("batch", "ring", "width", "height", "nfeatures"):
@@ -608,29 +683,38 @@ def main():
         return (run_match if name == "match100k" else run_frontend)(a_, cfg, world, rank, local_rank, dist, torch)
 
     out = run(a, a.config)
-    bad = 0
-    if a.config == "vga" and not a.no_also:
-        # BASELINE.json's other GPU configurations in the same line (the driver runs this command once): shorter timed regions and CPU
-        # samples, same definitions.  At N > 1 `hd1080` is configs[3] (one 1080p stream per GPU).
+    bad = int(out.get("_mismatches", 0)) if rank != 0 else int(out["config"].get("parity_mismatches", 0))
+    if rank == 0 and numa:
+        out["config"]["host_numa_binding"] = numa
+    if a.config == "vga" and a.family == synth.BLOCKS and not a.no_also:
+        # BASELINE.json's other GPU configurations and the headline configuration on the other frame families, in the same line (the
+        # driver runs this command once): shorter timed regions and CPU samples, same definitions, same every-frame parity leg.  At
+        # N > 1 `hd1080` is configs[3] (one 1080p stream per GPU).
         also = {}
-        for name in ("hd1080", "match100k"):
+        for key, name, family, cpu in (("vga_extract", "vga_extract", synth.BLOCKS, False), ("hd1080", "hd1080", synth.BLOCKS, True),
+                                       ("match100k", "match100k", synth.BLOCKS, True), ("vga_noise", "vga", synth.NOISE, False),
+                                       ("vga_midtex", "vga", synth.MIDTEX, False), ("vga_lowtex", "vga", synth.LOWTEX, False)):
             a2 = argparse.Namespace(**vars(a))
-            a2.config, a2.min_seconds, a2.cpu_seconds, a2.cpu_allcores_seconds = name, a.also_min_seconds, a.also_cpu_seconds, 0.0
+            a2.config, a2.min_seconds, a2.cpu_seconds, a2.cpu_allcores_seconds, a2.cpu_reference_seconds = name, a.also_min_seconds, a.also_cpu_seconds, 0.0, 0.0
             a2.batch = a2.ring = a2.width = a2.height = a2.nfeatures = None
             a2.region_timing = False
+            a2.family = family
+            a2.no_cpu_baseline = a.no_cpu_baseline or not cpu
             r = run(a2, name)
-            if r is not None:
-                also[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "timed_steps", "timed_seconds", "scaling", "dtype", "config",
-                                                "roofline", "roofline_pipeline", "roofline_valu", "stage_ms_per_step", "cpu_baseline", "per_rank") if k in r}
-        if out is not None:
+            if rank != 0:
+                bad += int(r.get("_mismatches", 0))
+            else:
+                bad += int(r["config"].get("parity_mismatches", 0))
+                also[key] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "timed_steps", "timed_seconds", "scaling", "dtype", "config",
+                                               "roofline", "roofline_pipeline", "roofline_valu", "stage_ms_per_step", "cpu_baseline", "per_rank") if k in r}
+        if rank == 0:
             out["also"] = also
-    if out is not None:
-        bad = int(out["config"].get("parity_mismatches", 0)) + sum(int(v["config"].get("parity_mismatches", 0)) for v in out.get("also", {}).values())
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    if bad:
-        sys.stderr.write("bench.py: %d sampled outputs differ from the oracle (config.parity_detail)\n" % bad)
+    if bad:                 # every rank: the mismatch counters were summed over the ranks
+        sys.stderr.write("bench.py: %d outputs differ from the oracle (config.parity_detail)\n" % bad)
         sys.exit(1)
 
 

@@ -107,13 +107,15 @@ int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int nfra
                               orbx_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, int cap,
                               int32_t* d_status, void* stream);
 
-/* The same call cut into the three parts a host can interleave with other work on other streams (the phased lanes of
- * orb_slam_amd/pipeline.py run the VALU-bound part of one lane next to the memory-bound parts of another):
+/* The same call cut into the three parts a host can interleave with other work on other streams (tools/corun_probe.py times
+ * them alone and in pairs; the bench's lanes queue whole calls — NOTES.md 8.1):
  *   ORBX_PHASE_PYRAMID   ComputePyramid                                              (src/ORBextractor.cc:781-822)
  *   ORBX_PHASE_DETECT    FAST + NMS per cell, quotas, retainBest, GaussianBlur       (:527-707, :760)
  *   ORBX_PHASE_DESCRIBE  IC_Angle, rBRIEF, scaling, outputs                          (:124-194, :709-779)
- * `phases` is a bit mask; the parts of one batch must be queued in this order on ONE stream with identical arguments, and
- * nframes <= max_batch (the handle's scratch holds one launch group).  ORBX_PHASE_ALL == orbx_extract_batch_device. */
+ * `phases` is a bit mask of CONSECUTIVE parts; the parts of one batch must be queued in this order on ONE stream with identical
+ * arguments, and nframes <= max_batch (the handle's scratch holds one launch group).  A call whose parts are not consecutive
+ * (PYRAMID | DESCRIBE) or that queues a part before the parts in front of it were queued for the same batch returns
+ * ORBX_ERR_ARG; repeating a part is allowed.  ORBX_PHASE_ALL == orbx_extract_batch_device. */
 #define ORBX_PHASE_PYRAMID  1
 #define ORBX_PHASE_DETECT   2
 #define ORBX_PHASE_DESCRIBE 4
@@ -131,8 +133,9 @@ int orbm_hamming256(const uint8_t* a, const uint8_t* b);
  *   best[q], second[q] = the two smallest distances WITH multiplicity; best_idx[q] = FIRST index
  *   attaining best (strict '<' update order of the reference loops); nt==0 -> -1, INT_MAX, INT_MAX.
  * Host-pointer form (copies in/out, synchronous) and device-pointer form (async on `stream`: its scratch — the partial
- * results of the train splits — is allocated and freed in stream order (hipMallocAsync), so concurrent calls on different
- * streams, also from one host thread, never share a buffer).  nt < 2^22.
+ * results of the train splits — is allocated and freed in stream order from a memory pool the library creates for itself
+ * (hipMallocFromPoolAsync; the device's default pool is left as the host set it), so concurrent calls on different streams,
+ * also from one host thread, never share a buffer).  nt < 2^22.
  * The kernels compute the distances on the matrix cores (int8 MFMA on +-1 encoded bits, exact); ORBX_MATCH_MFMA=0 in the
  * environment selects the xor + popcount kernels instead as the process default, orbm_debug_set_match_path() at run time
  * (same results; tests/test_gpu_matcher.py runs every case through both).
@@ -195,6 +198,9 @@ int orbm_distinctive_device(const uint8_t* d_desc, const int32_t* d_seg_off, int
 #define ORBX_DBG_BLUR       1   /* blurred level plane, tight w*h bytes */
 #define ORBX_DBG_NMS        2   /* per-pixel FAST score of NMS survivors (0 elsewhere), tight w*h bytes */
 #define ORBX_DBG_LEVEL_KPS  3   /* selected keypoints of a level before orientation: int32 triples (x,y,response bits) */
+#define ORBX_DBG_BANDS      4   /* the FAST work items (row bands of grid cells) of a level: int32[8] each = x0, x1 (the cell's columns), y0, y1
+                                 * (the rows the band owns), survivors listed, of them with score >= fastTh, with score >= 7, and the threshold
+                                 * the band's list was made at (fastTh, or 7 for a band that kept <= 3 survivors at fastTh) */
 /* run the kernel sequence only up to `stage` (0 pyramid, 1 FAST + NMS + cell lists, 2 quotas, 3 per-cell retainBest,
  * 4 per-level cap, 5 blur, 6 describe); <0 = everything (default) */
 int orbx_debug_set_stop_after(orbx_extractor* h, int stage);

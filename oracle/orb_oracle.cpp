@@ -813,6 +813,23 @@ void orc_match_top2(const uint8_t* Q, int nq, const uint8_t* T, int nt, int32_t*
         best_idx[q] = bestIdx; best[q] = bestDist1; second[q] = bestDist2;
     }
 }
+// CPU-baseline variant of the same scan ("a __builtin_popcountll variant"): the descriptor as four 64-bit words, one
+// popcount instruction per word instead of the reference's bit-trick sum (src/ORBmatcher.cc:1794-1810).  Same integers out.
+void orc_match_top2_popcountll(const uint8_t* Q, int nq, const uint8_t* T, int nt, int32_t* best_idx, int32_t* best, int32_t* second) {
+    for (int q = 0; q < nq; q++) {
+        uint64_t a[4];
+        memcpy(a, Q + (size_t)q * 32, 32);
+        int bestDist1 = INT_MAX, bestIdx = -1, bestDist2 = INT_MAX;
+        for (int t = 0; t < nt; t++) {
+            uint64_t b[4];
+            memcpy(b, T + (size_t)t * 32, 32);
+            const int dist = __builtin_popcountll(a[0] ^ b[0]) + __builtin_popcountll(a[1] ^ b[1]) + __builtin_popcountll(a[2] ^ b[2]) + __builtin_popcountll(a[3] ^ b[3]);
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx = t; }
+            else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        best_idx[q] = bestIdx; best[q] = bestDist1; second[q] = bestDist2;
+    }
+}
 // the same scan over a per-query candidate list (e.g. src/ORBmatcher.cc:87-111 over vNearIndices, :201-222 over vIndicesF)
 void orc_match_top2_segments(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int32_t* seg_off, const int32_t* cand,
                              int32_t* best_idx, int32_t* best, int32_t* second) {

@@ -15,7 +15,7 @@ ORBX_OK, ORBX_EMPTY = 0, 1
 ORBX_ERR_ARG, ORBX_ERR_DEVICE, ORBX_ERR_CAPACITY, ORBX_ERR_GEOMETRY = -1, -2, -3, -4
 HARRIS_SCORE, FAST_SCORE = 0, 1
 BLUR_X86_SSE2, BLUR_HALF_UP = 0, 1
-DBG_PLANE, DBG_BLUR, DBG_NMS, DBG_LEVEL_KPS = 0, 1, 2, 3
+DBG_PLANE, DBG_BLUR, DBG_NMS, DBG_LEVEL_KPS, DBG_BANDS = 0, 1, 2, 3, 4
 (ST_PYRAMID, ST_FAST_CELLS, ST_QUOTA, ST_CELL_SELECT, ST_LEVEL_SELECT, ST_BLUR, ST_DESCRIBE) = range(7)
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
@@ -283,6 +283,14 @@ class ORBextractor:
         if rc < 0:
             raise self._err(rc)
         return out
+
+    def fetch_bands(self, level, frame=0):
+        """the FAST work items of a level after a run: int32 rows (x0, x1, y0, y1, n_all, n_hi, n_lo, list threshold)"""
+        out = np.zeros((16384, 8), dtype=np.int32)
+        rc = self.L.orbx_debug_fetch(self.h, DBG_BANDS, frame, level, out.ctypes.data, out.nbytes)
+        if rc < 0:
+            raise self._err(rc)
+        return out[:rc // 32].copy()
 
     def fetch_level_keypoints(self, level, frame=0):
         out = np.zeros((4 * self.max_keypoints + 64, 3), dtype=np.int32)

@@ -43,7 +43,16 @@ public:
     LanePipeline(int width, int height, int batch, int lanes, const orbx_params& params, bool do_match = true, bool autotune = true,
                  int placement = -1)
         : w_(width), h_(height), B_(batch), device_(params.device), do_match_(do_match) {
-        if (placement < 0) { const char* e = std::getenv("ORBX_LANE_PLACEMENT"); if (e && *e) placement = std::atoi(e); }
+        if (placement < 0) {
+            const char* e = std::getenv("ORBX_LANE_PLACEMENT");
+            if (e && *e) {                                  // a candidate index 0..2, parsed as orb_slam_amd/pipeline.py parses it: anything else is an error
+                char* end = nullptr;
+                const long v = std::strtol(e, &end, 10);
+                if (end == e || *end != '\0' || v < 0 || v > 2) throw std::invalid_argument(std::string("ORBX_LANE_PLACEMENT=") + e + ": expected a candidate index 0..2");
+                placement = (int)v;
+            }
+        }
+        if (placement > 2) throw std::invalid_argument("lane placement: expected a candidate index 0..2");
         G_ = lanes < 1 ? 1 : (lanes > batch ? batch : lanes);
         while (B_ % G_) --G_;
         b_ = B_ / G_;

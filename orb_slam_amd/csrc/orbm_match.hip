@@ -15,6 +15,7 @@
 #include <atomic>
 #include <climits>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 
 #include "orb_math.h"
@@ -573,27 +574,45 @@ static int device_cus() {
     return cus;
 }
 
-// Scratch of the split form (partial top-2 per train split): stream-ordered allocation.  The device's default pool keeps what it
-// has handed out once (release threshold raised on first use: with the default of 0 every synchronise returned the memory to the
-// driver and the next large match paid the allocation again); where the runtime has no memory pools the call falls back to
-// hipMalloc + a stream synchronise before the free.
-static bool pool_ready(hipStream_t) {
-    static thread_local int done_for = -1;
-    static thread_local bool ok = false;
+// Scratch of the split form (partial top-2 per train split): stream-ordered allocation from a PRIVATE memory pool per device (round 4;
+// rounds 2-3 raised the release threshold of the device's DEFAULT pool, a process-wide side effect on a pool the host application may
+// share, e.g. with torch's hipMallocAsync backend).  The private pool keeps what it has handed out once (release threshold 256 MiB: with
+// 0 every synchronise returns the memory to the driver and the next large match pays the allocation again).  Where the runtime cannot
+// create a pool the default pool serves, its threshold raised only if it is lower; where it has no memory pools at all the call falls
+// back to hipMalloc + a stream synchronise before the free.
+static hipMemPool_t match_pool() {
+    constexpr int MAX_DEV = 64;
+    static std::mutex mu;
+    static hipMemPool_t pools[MAX_DEV] = {};
+    static int state[MAX_DEV] = {};                 // 0 unknown, 1 pool usable, -1 no pools
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (done_for == dev) return ok;
-    done_for = dev;
-    ok = false;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state[dev] != 0) return state[dev] > 0 ? pools[dev] : nullptr;
+    state[dev] = -1;
     int supported = 0;
-    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, dev) != hipSuccess || !supported) { (void)hipGetLastError(); return false; }
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, dev) != hipSuccess || !supported) { (void)hipGetLastError(); return nullptr; }
     uint64_t keep = 256ull << 20;
-    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    hipMemPoolProps props;
+    memset(&props, 0, sizeof(props));
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    hipMemPool_t pool = nullptr;
+    if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool) {
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    } else {
+        (void)hipGetLastError();
+        if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        uint64_t cur = 0;
+        if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &cur) != hipSuccess || cur < keep)
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
     (void)hipGetLastError();
-    ok = true;
-    return true;
+    pools[dev] = pool;
+    state[dev] = 1;
+    return pool;
 }
 
 int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt, int32_t* d_best_idx, int32_t* d_best,
@@ -630,8 +649,9 @@ int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
     // call stays asynchronous (the free is queued behind the merge kernel).
     const size_t need = (size_t)2 * nsplit * nq * sizeof(uint32_t);
     uint32_t* pk1 = nullptr;
-    const bool pooled = pool_ready(stream);
-    if ((pooled ? hipMallocAsync(reinterpret_cast<void**>(&pk1), need, stream) : hipMalloc(reinterpret_cast<void**>(&pk1), need)) != hipSuccess) {
+    hipMemPool_t pool = match_pool();
+    const bool pooled = pool != nullptr;
+    if ((pooled ? hipMallocFromPoolAsync(reinterpret_cast<void**>(&pk1), need, pool, stream) : hipMalloc(reinterpret_cast<void**>(&pk1), need)) != hipSuccess) {
         (void)hipGetLastError();
         return ORBX_ERR_DEVICE;
     }

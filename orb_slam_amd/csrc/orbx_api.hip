@@ -51,6 +51,17 @@ struct orbx_extractor {
     SideStream side;
     Batch last;
     bool have_last = false;
+    // phased calls (orbx_extract_batch_device_phases): the parts already queued for the batch described by ph_key
+    int ph_done = 0;
+    struct PhaseKey {
+        const void *img, *kps, *desc, *n, *stream;
+        int nframes, w, hgt, cap;
+        ptrdiff_t row_stride, frame_stride;
+        bool operator==(const PhaseKey& o) const {
+            return img == o.img && kps == o.kps && desc == o.desc && n == o.n && stream == o.stream && nframes == o.nframes && w == o.w && hgt == o.hgt &&
+                   cap == o.cap && row_stride == o.row_stride && frame_stride == o.frame_stride;
+        }
+    } ph_key = {};
 };
 
 #define HIPCHK(h, call)                                                                      \
@@ -209,8 +220,24 @@ int orbx_extract_batch_device_phases(orbx_extractor* h, const uint8_t* d_imgs, i
     if (!h) return ORBX_ERR_ARG;
     if (!d_imgs || nframes <= 0 || w <= 0 || hgt <= 0) return ORBX_EMPTY;
     if (!d_kps || !d_desc || !d_n || cap < 1 || row_stride < w) { h->err = "bad argument"; return ORBX_ERR_ARG; }
-    if (phases < 1 || phases > ORBX_PHASE_ALL) { h->err = "bad phase mask"; return ORBX_ERR_ARG; }
+    if (phases < 1 || phases > ORBX_PHASE_ALL || phases == (ORBX_PHASE_PYRAMID | ORBX_PHASE_DESCRIBE)) {
+        h->err = "bad phase mask (the parts of one call must be consecutive)";
+        return ORBX_ERR_ARG;
+    }
     if (phases != ORBX_PHASE_ALL && nframes > h->p.max_batch) { h->err = "a phased call covers one launch group: nframes <= max_batch"; return ORBX_ERR_ARG; }
+    {
+        // a part may only follow the parts in front of it, queued for the SAME batch (same arguments, same stream): the detection reads the
+        // pyramid of this batch from the handle's scratch, the description reads its selections and blurred planes.  Repeating a part is fine.
+        const orbx_extractor::PhaseKey key = {d_imgs, d_kps, d_desc, d_n, stream_, nframes, w, hgt, cap, row_stride, frame_stride};
+        const int first = phases & -phases;                       // lowest part of this call
+        const int before = first - 1;                             // every part in front of it
+        if (!(phases & ORBX_PHASE_PYRAMID) && (!(key == h->ph_key) || (h->ph_done & before) != before)) {
+            h->err = "phase queued out of order: the parts in front of it were not queued for this batch (same arguments, same stream)";
+            return ORBX_ERR_ARG;
+        }
+        if (phases & ORBX_PHASE_PYRAMID) { h->ph_key = key; h->ph_done = 0; }
+        h->ph_done |= phases;
+    }
     HIPCHK(h, hipSetDevice(h->p.device));
     int rc = ensure_geometry(h, w, hgt);
     if (rc != ORBX_OK) return rc;
@@ -364,6 +391,22 @@ long orbx_debug_fetch(orbx_extractor* h, int what, int frame, int level, void* h
             for (int i = 0; i < n; i++) ((uint8_t*)host_out)[(size_t)(tmp[i].pos >> 16) * L.w + (tmp[i].pos & 0xFFFF)] = (uint8_t)tmp[i].resp;
         }
         return need;
+    }
+    if (what == ORBX_DBG_BANDS) {
+        std::vector<CellState> st(g.nbands_total);
+        if (hipMemcpy(st.data(), b.cstate + (size_t)frame * g.nbands_total, g.nbands_total * sizeof(CellState), hipMemcpyDeviceToHost) != hipSuccess)
+            return ORBX_ERR_DEVICE;
+        long n = 0;
+        for (int it = 0; it < g.nbands_total; it++) {
+            const BandGeom& bgm = h->hg.bands[it];
+            if (bgm.level != level) continue;
+            if ((n + 1) * 32 > cap_bytes) return ORBX_ERR_CAPACITY;
+            int32_t* o = (int32_t*)host_out + 8 * n++;
+            o[0] = bgm.x0; o[1] = bgm.x1; o[2] = bgm.y0; o[3] = bgm.y1;
+            o[4] = st[it].n_all; o[5] = st[it].n_hi; o[6] = st[it].n_lo;
+            o[7] = (ORBX_FAST_TWO_PASS && g.fast_th > 7 && st[it].n_hi > 3) ? g.fast_th : std::min(g.fast_th, 7);
+        }
+        return n * 32;
     }
     if (what == ORBX_DBG_PLANE || what == ORBX_DBG_BLUR) {
         const long need = (long)L.w * L.h;

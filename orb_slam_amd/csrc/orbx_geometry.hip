@@ -383,8 +383,8 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
 
 // Shape of k_fast_cells (orbx_internal.h: FAST_SMALL / FAST_LARGE).  VGA-class grids (largest cell view <= 12288 px and at most
 // 500 px wide) take the small shape: 256 threads over 8192-pixel bands.  Everything else takes the large shape: since round 3
-// 256 threads over 7168-pixel bands (rounds 1-2: 512 threads over 10240-pixel bands, kept at 4 work items per CU by the
-// band-shrinking loop below, which only applies to shapes whose bands start above 8192 px).
+// 256 threads over 7168-pixel bands (rounds 1-2: 512 threads over 10240-pixel bands); grids whose widest cell pushes the LDS
+// footprint of a work item above a quarter of the CU's LDS get smaller bands from the loop below (down to 4096 px).
 int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::string& err) {
     constexpr int LDS_FOR_FOUR = (160 * 1024) / 4 - 64;
     const FastShape small = FAST_SMALL, large = FAST_LARGE;
@@ -408,7 +408,7 @@ int build_geometry(const orbx_params& p, int w, int h, HostGeom& out, std::strin
     out.g.fast_threads = large.threads;
     out.g.fast_small = 0;
     if (out.g.fast_lds_bytes <= LDS_FOR_FOUR) return rc;
-    for (int band = large.band_px - 512; band >= 8192; band -= 512) {
+    for (int band = large.band_px - 512; band >= 4096; band -= 512) {      // (re-based in round 4: the large shape's bands start at 7168 px)
         HostGeom trial;
         std::string e2;
         if (build_geometry_band(p, w, h, trial, e2, band, large) == ORBX_OK && trial.g.fast_lds_bytes <= LDS_FOR_FOUR) {

@@ -96,6 +96,10 @@ constexpr FastShape FAST_LARGE = {ORBX_FL};   // 720p / 1080p-class grids (round
 // (round 3: the kernel is latency-bound at the occupancy its LDS allows — 1.06 / 1.15 / 1.30 / 1.56 ms per 1024 VGA frames at
 //  6 / 5 / 4 / 3 workgroups per CU — so the queues are kept as small as their invariants allow: every producer drains as soon as
 //  a slice of 64 is full)
+// 1: k_fast_cells scores a band at fastTh first and again at 7 only when it keeps <= 3 survivors (round 4); 0: one pass at min(fastTh, 7)
+#ifndef ORBX_FAST_TWO_PASS
+#define ORBX_FAST_TWO_PASS 1
+#endif
 constexpr int FAST_Q1CAP = 192, FAST_Q2CAP = 128, FAST_Q3CAP = 192;
 constexpr int fast_q0cap(int) { return 128; }
 constexpr int fast_wave_queue_bytes(int ppt) { return fast_q0cap(ppt) * 4 + FAST_Q1CAP * 2 + FAST_Q2CAP * 2 + FAST_Q3CAP * 2; }

@@ -547,7 +547,13 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     }
     __syncthreads();
 
-    const int tmin = g.tmin;
+    // Threshold of the current pass (round 4).  The band is first scored at fastTh: survivors@fastTh = survivors@7 intersected with
+    // {score >= fastTh} (a neighbour scoring below fastTh can never block a pixel scoring at least fastTh), so a band that keeps
+    // more than 3 of them proves that its cell has more than 3 and never takes the reference's threshold-7 fallback (:609-614): its
+    // list at fastTh is all the later stages read.  Only a band with <= 3 survivors@fastTh is scored again at 7 (below).  On textured
+    // input (corners@7 several times corners@fastTh) the pair test, score, NMS and list phases shrink by that factor; on the S-blocks
+    // stream 3 % of the bands take the second pass.  fastTh <= 7: one pass at fastTh serves both (g.tmin = fastTh).
+    int tmin = ORBX_FAST_TWO_PASS ? g.fast_th : g.tmin;
     const float inv_nd = bg.inv_nd;                // (1 / nd, 1 / S, 1 / cpr come with the band: BandGeom)
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;          // fill of this wave's queues (wave-uniform)
 
@@ -606,7 +612,7 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
 
     // A1: SWAR compass test, 4 pixels per lane and step (see the header of this section)
     const uint32_t M8 = 0x00FF00FFu, HH = 0x80008000u;
-    const uint32_t KD = (uint32_t)(0x8000 - tmin - 1) * 0x00010001u;
+    uint32_t KD = (uint32_t)(0x8000 - tmin - 1) * 0x00010001u;
     auto compass4 = [&](uint32_t C, uint32_t E, uint32_t W, uint32_t Nn, uint32_t Ss) -> uint32_t {
         uint32_t P[2];
 #pragma unroll
@@ -649,6 +655,7 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
             }
         }
     };
+    for (;;) {      // one pass at fastTh; a second one at 7 for a band with <= 3 survivors@fastTh
     {
         int base = i_begin;
         for (; base + RG <= i_end; base += RG) round(std::true_type{}, base);
@@ -713,6 +720,15 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
         }
     }
     __syncthreads();
+    if (tmin <= 7 || __builtin_amdgcn_readfirstlane(hdr->n_hi) > 3) break;          // workgroup-uniform
+    // second pass at the fallback threshold: score plane, survivor masks and counts start over (the staged image stays)
+    __syncthreads();                                 // every wave has read n_hi
+    clear_lds();
+    tmin = 7;
+    KD = (uint32_t)(0x8000 - 7 - 1) * 0x00010001u;
+    n0 = n1 = n2 = n3 = 0;
+    __syncthreads();
+    }
     // the band's keypoint list in raster order (cv::FAST's order): one lane per 64-byte chunk of the survivor bitmask
     Cand* out = b.cand + (long long)frame * g.frame_cands + L.cand_base + bg.cand_off;
     const float inv_S = bg.inv_s;
@@ -1289,6 +1305,15 @@ __global__ __launch_bounds__(SMALL ? FAST_SMALL.threads : FAST_LARGE.threads) vo
 //   Keypoints closer than 19 px to an edge may read the level's UNBLURRED reflect-101 border: their group of lanes
 //     takes its taps from global memory with the reflection in the index math.
 // Waves are formed per level (slots padded to multiples of 4), so the level is wave-uniform and its geometry scalar.
+#ifndef ORBX_EXP_TILED_WIN
+#define ORBX_EXP_TILED_WIN 0
+#endif
+#ifndef ORBX_EXP_TILED_PATCH
+#define ORBX_EXP_TILED_PATCH 0
+#endif
+#ifndef ORBX_EXP_PATCH_FIRST
+#define ORBX_EXP_PATCH_FIRST 0
+#endif
 constexpr int DESC_KPW = 4;
 constexpr int DESC_WIN_PITCH = 40, DESC_WIN_ROWS = 37, DESC_WIN_BYTES = DESC_WIN_PITCH * DESC_WIN_ROWS;   // 37 px + up to 3 px of dword alignment per row
 
@@ -1364,6 +1389,21 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
     // rounded pattern offsets never exceed 18 px (|(-13,-13)| = 18.4): keypoints at least 19 px from every edge — all but the
     // outermost ring of candidates — take the branch-free path with the window in LDS
     const bool interior = x >= 19 && y >= 19 && x < L.w - 19 && y < L.h - 19;
+#if ORBX_EXP_PATCH_FIRST
+    // The 31 x 31 patch of the UNBLURRED level is requested before the windows of the blurred one: vmcnt counts in order, so with the
+    // window DMA in front (round 3) IC_Angle could not start before the last window dword had landed.  The patch loads are inline
+    // assembly (the compiler's own wait-count pass would wait for everything outstanding before the first use of a loaded value);
+    // the wait below names the number of DMA instructions that may still be in flight.
+    uint32_t I[16];
+    const int pc = li & 7, ppar = li >> 3;
+    {
+        const unsigned off0 = (unsigned)(x + 4 * pc - HALF_PATCH) + __umul24((unsigned)(y - HALF_PATCH + ppar), pstride);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(I[i]) : "v"(off0 + (unsigned)(2 * i) * pstride), "s"(plain) : "memory");
+    }
+    int ndma = 0;
+#endif
     {
         // window of keypoint q: rows y-18 .. y+18, 40 bytes from the aligned start at or left of x-18, row after row (pitch 40 = 10
         // dwords), i.e. 370 consecutive LDS dwords: 6 global_load_lds_dword of the whole wave per keypoint (lane i of instruction n
@@ -1384,12 +1424,28 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
             const unsigned posq = (unsigned)__builtin_amdgcn_readlane((int)kp.pos, 16 * q);
             const bool inq = __builtin_amdgcn_readlane((int)interior, 16 * q) != 0;
             if (!inq || (q > 0 && k0 + q >= cnt)) continue;                              // wave-uniform
+#if ORBX_EXP_PATCH_FIRST
+            ndma += 6;
+#endif
             const int xq = posq & 0xFFFF, yq = posq >> 16;
+#if ORBX_EXP_TILED_WIN
+            // TIMING EXPERIMENT (wrong results): the window gathered as if the blurred plane were stored in 16 x 8-px tiles of 128 bytes
+            const int hcl = (L.h & ~7) - 1, tpr = L.stride >> 4;
+#pragma unroll
+            for (int n = 0; n < 6; n++) {
+                const unsigned e = 64u * n + (unsigned)lane, er = (e * 205u) >> 11;
+                const int Y = min(yq - 18 + (int)er, hcl), X = ((xq - 18) & ~3) + 4 * (int)(e - 10u * er);
+                const unsigned off = ((unsigned)((Y >> 3) * tpr + (X >> 4)) << 7) + ((unsigned)(Y & 7) << 4) + (unsigned)(X & 15);
+                if (n < 5 || lane < DESC_WIN_ROWS * 10 - 320)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(blur + off), (lptr_t)(win0 + q * DESC_WIN_BYTES + 256 * n), 4, 0, 0);
+            }
+#else
             const uint8_t* srcq = blur + __umul24((unsigned)(yq - 18), (unsigned)L.stride) + (unsigned)((xq - 18) & ~3);
 #pragma unroll
             for (int n = 0; n < 6; n++)
                 if (n < 5 || lane < DESC_WIN_ROWS * 10 - 320)
                     __builtin_amdgcn_global_load_lds((gptr_t)(srcq + eoff[n]), (lptr_t)(win0 + q * DESC_WIN_BYTES + 256 * n), 4, 0, 0);
+#endif
         }
     }
 
@@ -1400,10 +1456,35 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
         uint32_t uw = 0;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) uw |= (uint32_t)(4 * c + kk) << (8 * kk);          // u + 15 of the dword's four pixels
+#if ORBX_EXP_PATCH_FIRST
+#define ORBX_WAIT_I(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(I[0]), "+v"(I[1]), "+v"(I[2]), "+v"(I[3]), "+v"(I[4]), "+v"(I[5]), "+v"(I[6]), "+v"(I[7]), \
+                                    "+v"(I[8]), "+v"(I[9]), "+v"(I[10]), "+v"(I[11]), "+v"(I[12]), "+v"(I[13]), "+v"(I[14]), "+v"(I[15]) :: "memory")
+        if (ndma == 24) ORBX_WAIT_I(24);
+        else if (ndma == 18) ORBX_WAIT_I(18);
+        else if (ndma == 12) ORBX_WAIT_I(12);
+        else if (ndma == 6) ORBX_WAIT_I(6);
+        else ORBX_WAIT_I(0);
+#undef ORBX_WAIT_I
+#else
         const unsigned off0 = (unsigned)(x + 4 * c - HALF_PATCH) + __umul24((unsigned)(y - HALF_PATCH + par), pstride);
         uint32_t I[16];
+#endif
+#if ORBX_EXP_PATCH_FIRST
+#elif ORBX_EXP_TILED_PATCH
+        // TIMING EXPERIMENT (wrong results): the patch gathered as if the plain plane were stored in 16 x 8-px tiles of 128 bytes
+        {
+            const int hcl = (L.h & ~7) - 1, tpr = (int)(pstride >> 4), X = (x + 4 * c - HALF_PATCH) & ~3;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int Y = min(y - HALF_PATCH + par + 2 * i, hcl);
+                const unsigned off = ((unsigned)((Y >> 3) * tpr + (X >> 4)) << 7) + ((unsigned)(Y & 7) << 4) + (unsigned)(X & 15);
+                I[i] = *reinterpret_cast<const uint32_t*>(plain + off);
+            }
+        }
+#else
 #pragma unroll
         for (int i = 0; i < 16; i++) __builtin_memcpy(&I[i], plain + (off0 + (unsigned)(2 * i) * pstride), 4);   // rows par, par + 2, ...: row 31 (par = 1, i = 15) is masked, still inside the level
+#endif
         uint32_t a_su = 0, a_si = 0, a_i = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -1554,7 +1635,10 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         }
     }
     if (stop_after == ST_PYRAMID) return ORBX_OK;
-    if (!(phases & ORBX_PHASE_DETECT)) goto describe;
+    if (!(phases & ORBX_PHASE_DETECT)) {
+        if (stop_after >= 0 && stop_after < ST_DESCRIBE) return ORBX_OK;      // the diagnostics' early stop lies inside the part this call skips
+        goto describe;
+    }
     {
     auto launch_blur = [&](hipStream_t st) -> int {
         StageScope sc(timer, st, ST_BLUR);

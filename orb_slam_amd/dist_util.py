@@ -10,13 +10,16 @@ def env_ranks():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend, world, rank, local_rank=0):
-    """Returns the torch.distributed module (initialised) or None for a single process."""
-    if world <= 1:
+def init(backend, world, rank, local_rank=0, force=False):
+    """Returns the torch.distributed module (initialised) or None for a single process.  force: initialise at world size 1 too, so that
+    the communicator, the barrier and the collectives below run exactly as at N > 1 (tests/test_gpu_bench.py drives the RCCL path
+    that way on the 1-GPU box)."""
+    if world <= 1 and not force:
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    world = max(world, 1)
     # No device_id here: with it torch builds the RCCL communicator (and RCCL its streams) eagerly, BEFORE the pipeline creates
     # its lane streams, and the runtime's stream -> hardware-queue placement the lanes rely on would shift (NOTES.md §4.5).
     # The communicator is built lazily at the first collective instead: the barrier in front of the timed region.
@@ -59,3 +62,26 @@ def reduce_run(dist, elapsed_s, counters, device):
     dist.all_gather(rows, c)
     total = torch.stack(rows).sum(0)
     return float(t.item()), total.cpu().tolist(), [r.cpu().tolist() for r in rows]
+
+
+def bind_to_gpu_numa(local_rank):
+    """Multi-rank runs: keep this rank's host threads on the NUMA node its GPU hangs off (launch threads, the synthesis and parity
+    pools), intersected with the CPUs the process may already use.  Best effort: returns a short description, or None when the
+    topology is not exposed (numa_node -1, no sysfs, single node) — the rank then stays where the launcher put it."""
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        mine = cpus & os.sched_getaffinity(0)
+        if not mine or mine == os.sched_getaffinity(0):
+            return None
+        os.sched_setaffinity(0, mine)
+        return "cuda:%d (%s) -> NUMA node %d, %d host threads" % (local_rank, bdf, node, len(mine))
+    except Exception:
+        return None

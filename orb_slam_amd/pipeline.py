@@ -53,7 +53,12 @@ class LanePipeline:
         # queues); tune() — an explicit, blocking call — times them and keeps the fastest (`self.placement` reports the timings
         # and the choice).  Raw HIP streams from the C ABI (torch creates its pool streams lazily, in an order of its own).
         if placement is None and os.environ.get("ORBX_LANE_PLACEMENT", "") != "":
-            placement = int(os.environ["ORBX_LANE_PLACEMENT"])
+            try:
+                placement = int(os.environ["ORBX_LANE_PLACEMENT"])
+            except ValueError:
+                raise ValueError("ORBX_LANE_PLACEMENT=%r: expected a candidate index 0..2" % os.environ["ORBX_LANE_PLACEMENT"]) from None
+        if placement is not None and not 0 <= placement <= 2:       # (LanePipeline.h refuses the same values)
+            raise ValueError("lane placement %d: expected a candidate index 0..2" % placement)
         dev = torch.device("cuda", device)
         handles = [capi.ORBextractor(nfeatures=nfeatures, device=device, max_batch=self.b, **extractor_kw) for _ in range(G)]
         self._raw_sets, self._spacers = [], []
@@ -62,15 +67,16 @@ class LanePipeline:
             self._spacers += [capi.stream_create(device) for _ in range(spacer)]
             self._raw_sets.append([capi.stream_create(device) for _ in range(G)])
         self._sets = [[torch.cuda.ExternalStream(p, device=dev) for p in raw] for raw in self._raw_sets]
-        chosen = min(max(placement, 0), ncand - 1) if placement is not None else 0
+        chosen = min(placement, ncand - 1) if placement is not None else 0          # (one lane: a single candidate)
         self.lanes = [_Lane(handles[g], device, self.b, self._sets[chosen][g]) for g in range(G)]
         self.device = device
         self.cap = self.lanes[0].ex.max_keypoints
         self.steps_done = 0
         self.match_events = []
-        self.placement = {"candidates": ncand, "chosen": chosen, "probe_ms_per_step": None, "fixed": placement is not None,
+        self.placement = {"candidates": ncand, "chosen": chosen, "probe_ms_per_step": None, "fixed": placement is not None, "untuned_steps": 0,
                           "note": "candidate k = lane streams created behind k spacer streams (and behind the handles' side streams)"}
         self._fixed = placement is not None or ncand == 1
+        self._tuning = False
         torch.cuda.synchronize(dev)      # the zero-fills above ran on the default stream; the lane streams do not wait for it
 
     def _use_set(self, k):
@@ -102,6 +108,7 @@ class LanePipeline:
         row_stride = row_stride or self.w
         frame_stride = frame_stride or row_stride * self.h
         ms = []
+        self._tuning = True
         for k in range(len(self._sets)):
             self._use_set(k)
             self._reset_handoff()
@@ -117,7 +124,7 @@ class LanePipeline:
         self._use_set(best)
         self._reset_handoff()
         self._sync_lanes()
-        self._fixed = True
+        self._fixed, self._tuning = True, False
         self.placement.update({"chosen": best, "probe_ms_per_step": [round(v, 4) for v in ms]})
         return self.placement
 
@@ -128,6 +135,13 @@ class LanePipeline:
         w, h, b, G, cap = self.w, self.h, self.b, self.G, self.cap
         row_stride = row_stride or w
         frame_stride = frame_stride or row_stride * h
+        if not self._fixed and not self._tuning:
+            # autotune was asked for but tune() has not run: the step goes through candidate 0 (round 3 made the probe an explicit
+            # call; step() never blocks).  Said once, and counted in self.placement.
+            if self.placement["untuned_steps"] == 0:
+                import warnings
+                warnings.warn("LanePipeline.step() before tune(): running on stream candidate 0 (call tune() once, or pass placement=k)", stacklevel=2)
+            self.placement["untuned_steps"] += 1
         i = self.steps_done
         par = i & 1
         for g, ln in enumerate(self.lanes):

@@ -50,6 +50,7 @@ def lib():
         L.orc_nth_element_perm.argtypes = [c_void_p, c_int, c_int, c_void_p]
         L.orc_hamming256.argtypes = [c_void_p, c_void_p]
         L.orc_match_top2.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+        L.orc_match_top2_popcountll.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
         L.orc_count_accepted.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float]
         L.orc_match_top2_segments.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.orc_frame_bounds.argtypes = [c_void_p, c_void_p]
@@ -158,6 +159,16 @@ def match_top2(Q, T):
     nq, nt = len(Q), len(T)
     idx = np.empty(nq, np.int32); best = np.empty(nq, np.int32); sec = np.empty(nq, np.int32)
     lib().orc_match_top2(Q.ctypes.data, nq, T.ctypes.data, nt, idx.ctypes.data, best.ctypes.data, sec.ctypes.data)
+    return idx, best, sec
+
+
+def match_top2_popcountll(Q, T):
+    """the CPU-baseline variant of match_top2 (one popcount instruction per 64-bit word); same integers"""
+    Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 32)
+    T = np.ascontiguousarray(T, dtype=np.uint8).reshape(-1, 32)
+    nq, nt = len(Q), len(T)
+    idx = np.empty(nq, np.int32); best = np.empty(nq, np.int32); sec = np.empty(nq, np.int32)
+    lib().orc_match_top2_popcountll(Q.ctypes.data, nq, T.ctypes.data, nt, idx.ctypes.data, best.ctypes.data, sec.ctypes.data)
     return idx, best, sec
 
 

@@ -1,8 +1,9 @@
-"""Parity at the launch shapes bench.py actually times (missing #3): the throughput numbers are quoted on 640x480 /
+"""Parity at the launch shapes bench.py actually times (missing #3; r03 #4): the throughput numbers are quoted on 640x480 /
 nFeatures 1000 in launch groups of 256 frames (per-level k_resize, frame -> XCD block renumbering on, k_fast_cells<true,256,2>) and
-on 1920x1080 / nFeatures 2000 in groups of 32 (the 512-thread FAST work-item shape).  Here EVERY frame of such a group is compared
-with the oracle byte for byte, and the bench's own pipeline configuration (1024 frames, 4 lanes of 256, match vs the previous
-frame) is checked at every lane border and the step border.  Contract: src/ORBextractor.cc:718-779, src/ORBmatcher.cc:201-222."""
+on 1920x1080 / nFeatures 2000 in launch groups of 64 (the 256-thread FAST work item over 7168-px bands since round 3).  Here EVERY
+frame of such a group is compared with the oracle byte for byte, and the bench's own pipeline configurations (1024 VGA frames as 4
+lanes of 256; 256 1080p frames as 4 lanes of 64; match vs the previous frame) are checked on EVERY frame of their last step.
+Contract: src/ORBextractor.cc:718-779, src/ORBmatcher.cc:201-222."""
 import os
 from concurrent.futures import ThreadPoolExecutor
 
@@ -94,25 +95,28 @@ def test_hd1080_launch_group_of_72_frames_with_xcd_affinity():
     _group_vs_oracle(w, h, 2000, frames, 72)
 
 
-@pytest.mark.parametrize("cfg", ["vga", "hd1080"])
+@pytest.mark.parametrize("cfg", ["vga", "hd1080", "vga_midtex"])
 def test_bench_pipeline_configuration(cfg):
-    """bench.py's own configuration — 1024 VGA frames as 4 lanes of 256 (128 1080p frames as 4 lanes of 32), three steps back to
-    back with the placement probe in front — checked exactly the way bench.py's parity leg checks its last timed step"""
+    """bench.py's own configurations — 1024 VGA frames as 4 lanes of 256, 256 1080p frames as 4 lanes of 64 (launch groups of 64:
+    the shape the 1080p line is timed on), three steps back to back with the placement probe in front — checked exactly the way
+    bench.py's parity leg checks its last timed step: every frame, keypoints + descriptors + top-2 match"""
     torch = pytest.importorskip("torch")
     from orb_slam_amd.pipeline import LanePipeline
-    w, h, nf, B = (640, 480, 1000, 1024) if cfg == "vga" else (1920, 1080, 2000, 128)
+    w, h, nf, B = (1920, 1080, 2000, 256) if cfg == "hd1080" else (640, 480, 1000, 1024)
+    fam = synth.MIDTEX if cfg == "vga_midtex" else synth.BLOCKS
     steps = 3
     ring = B * 2
-    frames = synth.frames(w, h, synth.BLOCKS, 7000, ring)
+    frames = synth.frames(w, h, fam, 7000, ring, threads=_cores())
     d_img = torch.from_numpy(frames).cuda()
     pipe = LanePipeline(w, h, B, lanes=4, nfeatures=nf)
     try:
+        assert pipe.G == 4 and pipe.b == B // 4
         pipe.tune(d_img.data_ptr())
         for i in range(steps):
             pipe.step(d_img.data_ptr() + ((i * B) % ring) * w * h)
         torch.cuda.synchronize()
         last = steps - 1
-        res = parity_sample.check_step(pipe, lambda j: frames[(last * B + j) % ring], parity_sample.sample_indices(B, pipe.G), nf)
-        assert res["frames"] >= 8 and res["mismatches"] == 0, res
+        res = parity_sample.check_step(pipe, lambda j: frames[(last * B + j) % ring], range(B), nf, threads=_cores())
+        assert res["frames"] == B and res["mismatches"] == 0, res
     finally:
         pipe.close()

@@ -8,8 +8,8 @@ from orb_slam_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 
-FAMILIES = [synth.BLOCKS, synth.NOISE, synth.LOWTEX, synth.FLAT]
-FAMNAME = {0: "noise", 1: "blocks", 2: "flat", 3: "lowtex"}
+FAMILIES = [synth.BLOCKS, synth.NOISE, synth.LOWTEX, synth.FLAT, synth.MIDTEX]
+FAMNAME = {0: "noise", 1: "blocks", 2: "flat", 3: "lowtex", 4: "midtex"}
 
 
 def _assert_kps_equal(k_gpu, k_ref):
@@ -58,21 +58,40 @@ def test_stage_parity_vga(gpu_extractor_factory, family):
     # blur (oracle: blur of the unblurred plane; the pipeline blurs every level)
     for l in range(nl):
         np.testing.assert_array_equal(ex.fetch_plane(capi.DBG_BLUR, l), orc.gaussian_blur7(o.level_plane(l, 0)), err_msg="blur level %d" % l)
-    # FAST score + cell-local NMS map at tmin = 7 (survivor lists are permuted by the later stages: stop after FAST)
+    # FAST score + cell-local NMS map (survivor lists are permuted by the later stages: stop after FAST).  A row band of a cell lists
+    # its survivors at fastTh = 20 when it keeps more than 3 of them and at the fallback threshold 7 otherwise (k_fast_cells, round 4):
+    # the reference map is cv::FAST of the cell view at the band's threshold restricted to the band's rows, and the band's counters
+    # must be the numbers of those survivors
     ex.set_stop_after(capi.ST_FAST_CELLS)
     ex(img)
     nms_planes = [ex.fetch_plane(capi.DBG_NMS, l) for l in range(nl)]
+    band_tabs = [ex.fetch_bands(l) for l in range(nl)]
     ex.set_stop_after(-1)
     gk, gd = ex(img)
     for l in range(nl):
         plane = o.level_plane(l, 0)
         ref = np.zeros_like(plane)
+        bands = band_tabs[l]
+        seen = 0
         for info, _ in o.cells():
             if info[0] != l:
                 continue
             ix, iy, cw, ch = info[3], info[4], info[6], info[7]
-            kp = orc.fast(plane[iy:iy + ch, ix:ix + cw], 7)
-            ref[iy + kp["y"].astype(int), ix + kp["x"].astype(int)] = kp["response"].astype(np.uint8)
+            view = plane[iy:iy + ch, ix:ix + cw]
+            by_thr = {t: orc.fast(view, t) for t in (7, 20)}
+            mine = bands[(bands[:, 0] == ix + 3) & (bands[:, 1] == ix + cw - 4) & (bands[:, 2] >= iy + 3) & (bands[:, 3] <= iy + ch - 4)]
+            assert len(mine) and mine[:, 2].min() == iy + 3 and mine[:, 3].max() == iy + ch - 4, (l, info, mine)      # the bands tile the scored rows
+            seen += len(mine)
+            for x0, x1, y0, y1, n_all, n_hi, n_lo, thr in mine:
+                at20 = by_thr[20]
+                in20 = (at20["y"] + iy >= y0) & (at20["y"] + iy <= y1)
+                want_thr = 20 if in20.sum() > 3 else 7
+                assert thr == want_thr, (l, info, (x0, x1, y0, y1), thr, int(in20.sum()))
+                kp = by_thr[thr]
+                kp = kp[(kp["y"] + iy >= y0) & (kp["y"] + iy <= y1)]
+                assert n_all == len(kp) and n_hi == int((kp["response"] >= 20).sum()) and n_lo == int((kp["response"] >= 7).sum()), (l, info, n_all, n_hi, n_lo, len(kp))
+                ref[iy + kp["y"].astype(int), ix + kp["x"].astype(int)] = kp["response"].astype(np.uint8)
+        assert seen == len(bands)
         got = nms_planes[l]
         bad = np.argwhere(got != ref)
         assert bad.size == 0, "nms level %d: %d pixels differ, first %s gpu=%d ref=%d" % (
@@ -104,7 +123,7 @@ def test_stage_parity_vga(gpu_extractor_factory, family):
     dict(w=640, h=480, nfeatures=1000, fastTh=5),             # fastTh below the fallback threshold 7
     dict(w=640, h=480, nfeatures=1000, blur_rounding=capi.BLUR_HALF_UP),
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
-@pytest.mark.parametrize("family", [synth.BLOCKS, synth.NOISE, synth.LOWTEX], ids=lambda f: FAMNAME[f])
+@pytest.mark.parametrize("family", [synth.BLOCKS, synth.NOISE, synth.LOWTEX, synth.MIDTEX], ids=lambda f: FAMNAME[f])
 def test_end_to_end_configs(gpu_extractor_factory, cfg, family):
     cfg = dict(cfg)
     w, h = cfg.pop("w"), cfg.pop("h")
@@ -441,6 +460,22 @@ def test_phased_call_equals_the_whole_call(gpu_extractor_factory):
         assert o[1] == outs[0][1] and o[2] == outs[0][2]
     ok, od = orc.OracleExtractor(nfeatures=nf)(frames[3])
     assert outs[0][0][3] == len(ok)
+    # out of order / not consecutive: description without the detection of THIS batch, detection of other arguments, mask 5
+    fresh = gpu_extractor_factory(nfeatures=nf, max_batch=B)
+    args = (d_img.data_ptr(), B, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, 0, st)
+    for seq in ((capi.PHASE_DESCRIBE,), (capi.PHASE_DETECT,), (capi.PHASE_PYRAMID, capi.PHASE_DESCRIBE), (capi.PHASE_PYRAMID | capi.PHASE_DESCRIBE,)):
+        with pytest.raises(capi.OrbxError) as e:
+            for m in seq:
+                fresh.extract_batch_device(*args, phases=m)
+        assert e.value.code == capi.ORBX_ERR_ARG, seq
+    fresh.extract_batch_device(*args, phases=capi.PHASE_ALL)              # (and the handle is still usable)
+    fresh.extract_batch_device(*args, phases=capi.PHASE_PYRAMID)
+    with pytest.raises(capi.OrbxError):
+        fresh.extract_batch_device(d_img.data_ptr(), B - 8, *args[2:], phases=capi.PHASE_DETECT)      # other arguments than the pyramid's
+    fresh.extract_batch_device(*args, phases=capi.PHASE_DETECT)
+    fresh.extract_batch_device(*args, phases=capi.PHASE_DETECT)              # repeating a part is allowed
+    fresh.extract_batch_device(*args, phases=capi.PHASE_DESCRIBE)
+    torch.cuda.synchronize()
     small = gpu_extractor_factory(nfeatures=nf, max_batch=8)
     for kw in (dict(phases=capi.PHASE_DETECT), dict(phases=0), dict(phases=8)):
         with pytest.raises(capi.OrbxError) as e:
