@@ -87,7 +87,7 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
     // --- per-level geometry
     const float imageRatio = (float)w / h;   // level 0 cols/rows (:526)
     int plane_off = 0, cell_base = 0, cand_base = 0, sel_base = 0, slot_base = 0, quad_base = 0;
-    int btile_base = 0, btile_base_s = 0;
+    int btile_base = 0, btile_base_s = 0, mb_base = 0;
     for (int l = 0; l < nl; l++) {
         LevelGeom& L = g.lv[l];
         const float s = out.inv_scale[l];
@@ -208,6 +208,9 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
         L.btiles_y_s = (L.h + BLUR_ROWS_SMALL - 1) / BLUR_ROWS_SMALL;
         L.btile_base_s = btile_base_s;
         btile_base_s += L.btiles_x * L.btiles_y_s;
+        L.mb_n = (align_up(L.w, 4) + MB_COLS - 1) / MB_COLS;     // (w >= 39: at least two; the last one is shifted left to end at align4(w))
+        L.mb_base = mb_base;
+        mb_base += L.mb_n;
 
         // cv::resize tables level l-1 -> l
         if (l > 0) {
@@ -366,12 +369,14 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
         g.quad_bases[l] = live ? g.lv[l].quad_base : INT_MAX;
         g.btile_bases[l] = live ? g.lv[l].btile_base : INT_MAX;
         g.btile_bases_s[l] = live ? g.lv[l].btile_base_s : INT_MAX;
+        g.mb_bases[l] = live ? g.lv[l].mb_base : INT_MAX;
     }
     g.ncells_total = cell_base;
     g.nbands_total = (int)out.bands.size();
     g.nbands_magic = g.nbands_total > 1 ? (uint32_t)((1ull << 32) / (unsigned)g.nbands_total) + 1u : 0u;
     g.nbtiles_total = btile_base;
     g.nbtiles_total_s = btile_base_s;
+    g.nmb_total = mb_base;
     g.nslots = slot_base;
     g.nquads = quad_base;
     g.frame_plane_bytes = align_up(plane_off, 256);

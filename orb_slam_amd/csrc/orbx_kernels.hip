@@ -1271,6 +1271,167 @@ __global__ __launch_bounds__(BLUR_WAVES * 64) void k_blur(Batch b) {
     if (t < ntiles) blur_strip<ALIGNED, ROWS>(b, frame, t);
 }
 
+// ------------------------------------------------------------------------------------ blur on the matrix cores (round 4)
+// The same filter as two exact int8 matrix products per 32 x 32 tile (v_mfma_i32_32x32x32_i8, i32 accumulate).  k_blur spends
+// 19.7 lane-operations per pixel on the taps (v_dot4 / v_dot2) and is VALU-issue bound at 0.55 ms per 1024 VGA frames while the
+// matrix pipe idles; here the taps are banded 0 / 18 / 34 / 49 / 55 matrices held in registers, the VALU only converts between the
+// passes and rounds (about 7 lane-operations per pixel), and the kernel's floor becomes the HBM time of reading and writing the
+// pyramid once (2 P_total bytes: 0.31 ms per 1024 VGA frames at 6.3 TB/s).  tools/proto/blur_mfma_emulation.py is the integer model
+// of this data flow, checked against the oracle.
+//
+// One wave = one 24-pixel tile column of a level, streamed down in steps of 32 rows; the four waves of a workgroup take
+// neighbouring tile columns, so the 128-byte lines of the rows they read are shared in the L1.  Operand slots (probe:
+// profiles/r02_mfma_layout.txt): lane (i, g) = i + 32 g holds row i of A (column i of B) and 16 of the 32 k-values; the k-value a
+// byte slot stands for is ours to choose as long as A and B agree; lane (n, g) of D holds rows 8 (r / 4) + 4 g + r % 4 in register r.
+//   row pass     D[row][c] = sum_k I[row][k] T[k][c]:  A = the tile's pixels minus 128 (lane = row, slot = column c0 + 16 g + 4 v + b:
+//                one 16-byte load per lane), B = the horizontal taps of output column pi(c) (reflect-101 at the level's edges is
+//                folded into this matrix: a reflected tap adds its weight to the column it lands on).  One slot of an inner
+//                tile is never tapped: it carries the constant 64 with weight 2, so D = S - 32896 + 128 = Z with S the 16-bit
+//                row sum of the reference and Z in [-32768, 32767].
+//   split        Z = 256 hi + lo + 128 with hi = Z >> 8 and lo = (Z & 255) - 128 both in int8: register r of a lane (rows 8 i +
+//                4 g + j of ITS column) becomes byte j of operand dword i — the column pass contracts over rows, and the slots a
+//                lane holds after the row pass are exactly the k-slots its lane group needs: no data moves between lanes.
+//   column pass  D2[c][y] = sum_rho H[rho][c] W[rho][y] over the previous and the current row tile (rows Y0 - 29 .. Y0 + 34 cover
+//                the taps of output rows Y0 .. Y0 + 31): A = hi (then lo) bytes, lane = column index c, B = vertical taps, lane =
+//                output row.  256 HI + LO + 257 * 32896 is the reference's 32-bit column sum; the shifted HI accumulator plus the
+//                rounding constant seeds the LO products, so the epilogue is one v_bfe + v_add (ties-to-even columns) per pixel.
+//   pi           column index 8 i + 4 g + j <-> tile column 12 g + 4 i + j: the 12 valid registers of a lane of D2 are 12
+//                CONTIGUOUS pixels of its row, stored as one 12-byte store (registers 12..15 = column indices 24..31: no taps).
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+
+__device__ __forceinline__ int gauss7_tap(int t) {      // [18, 34, 49, 55, 49, 34, 18][t], 0 outside
+    return (unsigned)t <= 6u ? (int)((0x12223137312212ull >> (8 * t)) & 255ull) : 0;
+}
+
+__global__ __launch_bounds__(MB_WAVES * 64) void k_blur_mfma(Batch b) {
+    const DevGeom& g = b.g;
+    int frame, wgi;
+    if (!frame_item(b, blockIdx.x, (g.nmb_total + MB_WAVES - 1) / MB_WAVES, frame, wgi)) return;
+    const int item = wgi * MB_WAVES + wave_id();
+    if (item >= g.nmb_total) return;
+    const int level = __builtin_amdgcn_readfirstlane(find_level(g.mb_bases, item));
+    const LevelGeom& L = g.lv[level];
+    const int lane = threadIdx.x & 63, m = lane & 31, gg = lane >> 5;
+    const int w = L.w, h = L.h;
+    const int tc = item - L.mb_base, w4 = (w + 3) & ~3;
+    const bool first = tc == 0, last = !first && tc == L.mb_n - 1;
+    const int xs0 = last ? w4 - MB_COLS : MB_COLS * tc;          // first output column of the tile column
+    const int c0 = first ? 0 : (last ? w4 - 32 : xs0 - 4);       // first input column of its 32-column input tiles (a multiple of 4, c0 + 32 <= row pitch)
+    const bool spare = !first;                                   // input column c0 is never tapped: it carries the + 128 of the split
+    long long sstride;
+    const uint8_t* src = plain_plane(b, L, level, frame, sstride);
+    uint8_t* dst = b.blur + (long long)frame * g.frame_plane_bytes + L.plane_off;
+
+    // B operand of the row pass: lane (c, g), slot (v, bb) <-> input column k = 16 g + 4 v + bb
+    v4i Tr = {0, 0, 0, 0};
+    {
+        const int ci = m >> 3, cg = (m >> 2) & 1, cj = m & 3;
+        const int o = 12 * cg + 4 * ci + cj;                     // pi(c)
+        if (ci < 3) {
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+                int x = xs0 + o - 3 + t;                                // one reflection suffices: |offset| <= 3 < w
+                x = x < 0 ? -x : (x >= w ? 2 * w - 2 - x : x);
+                const int k = x - c0;                                   // 0 .. 31 by construction
+                const int wgt = (k >> 4) == gg ? gauss7_tap(t) << (8 * (k & 3)) : 0;
+                const int v = (k >> 2) & 3;
+                Tr.x += v == 0 ? wgt : 0; Tr.y += v == 1 ? wgt : 0; Tr.z += v == 2 ? wgt : 0; Tr.w += v == 3 ? wgt : 0;
+            }
+        }
+        if (spare && gg == 0) Tr.x += 2;                         // x the constant 64 in slot 0 of A
+    }
+    // B operands of the column pass: lane (y, g), slot (v, bb) <-> input row rho = 8 v + 4 g + bb of the current (previous) row tile
+    v4i Wc, Wp;
+    {
+        int wc[4], wp[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            wc[v] = 0; wp[v] = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) {
+                const int rho = 8 * v + 4 * gg + bb;
+                wc[v] |= gauss7_tap(rho - m + 6) << (8 * bb);
+                wp[v] |= gauss7_tap(rho - m - 26) << (8 * bb);
+            }
+        }
+        Wc = (v4i){wc[0], wc[1], wc[2], wc[3]};
+        Wp = (v4i){wp[0], wp[1], wp[2], wp[3]};
+    }
+    const uint32_t amask = (spare && gg == 0) ? 0xFFFFFF00u : 0xFFFFFFFFu, aor = (spare && gg == 0) ? 0x40u : 0u;
+    const int xcol = xs0 + 12 * gg;                              // the lane's 12 output columns
+    int tew[3], kc[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        tew[i] = xcol + 4 * i < L.blur_wvec ? 1 : 0;             // ties-to-even columns (orb_math.h blur_round); blur_wvec is a multiple of 4
+        kc[i] = 257 * 32896 + 0x7FFF + (1 - tew[i]);
+    }
+    auto load_tile = [&](int R) -> u32x4_a4 {                    // rows R .. R + 31 (reflect-101; rows no tap reaches are clamped into the level)
+        int row = R + m;
+        row = row < 0 ? -row : row;
+        row = row >= h ? 2 * h - 2 - row : row;
+        row = min(max(row, 0), h - 1);
+        return *reinterpret_cast<const u32x4_a4*>(src + (__umul24((unsigned)row, (unsigned)sstride) + (unsigned)(c0 + 16 * gg)));    // rows < 2^24 bytes, planes < 2^31 (host-checked)
+    };
+    // row pass + split of one tile: hi / lo operand dwords of the column pass
+    auto row_pass = [&](u32x4_a4 px, v4i& hi, v4i& lo) {
+        v4i a;
+        a.x = (int)(((px.x ^ 0x80808080u) & amask) | aor);
+        a.y = (int)(px.y ^ 0x80808080u); a.z = (int)(px.z ^ 0x80808080u); a.w = (int)(px.w ^ 0x80808080u);
+        v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        z = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Tr, z, 0, 0, 0);
+        if (!spare) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) z[r] += 128;
+        }
+        int h4[4], l4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)z[4 * i + 1], (uint32_t)z[4 * i], 0x05010400u);      // lo0 lo1 hi0 hi1
+            const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)z[4 * i + 3], (uint32_t)z[4 * i + 2], 0x05010400u);
+            l4[i] = (int)(__builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+            h4[i] = (int)__builtin_amdgcn_perm(p23, p01, 0x07060302u);
+        }
+        hi = (v4i){h4[0], h4[1], h4[2], h4[3]};
+        lo = (v4i){l4[0], l4[1], l4[2], l4[3]};
+    };
+    v4i phi, plo;
+    row_pass(load_tile(3 - 32), phi, plo);                       // rows -29 .. 2: the taps above the first output rows
+    u32x4_a4 nxt = load_tile(3);
+    for (int Y0 = 0; Y0 < h; Y0 += 32) {
+        const u32x4_a4 cur = nxt;
+        if (Y0 + 32 < h) nxt = load_tile(Y0 + 32 + 3);           // the next step's rows are requested before this step's arithmetic
+        v4i chi, clo;
+        row_pass(cur, chi, clo);
+        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi, Wp, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(chi, Wc, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 12; r++) acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)kc[r >> 2]);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo, Wp, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(clo, Wc, acc, 0, 0, 0);
+        phi = chi; plo = clo;
+        uint32_t o3[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            uint32_t q[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t t = (uint32_t)acc[4 * i + j];
+                q[j] = t + __builtin_amdgcn_ubfe(t, 16u, (uint32_t)tew[i]);
+            }
+            // (q >> 16) of two pixels per dword, saturated to 255 as packed 16-bit (the taps sum to 257 per pass: 254 and 255 overshoot)
+            const us2v lo2 = __builtin_elementwise_min(as_us2v(__builtin_amdgcn_perm(q[1], q[0], 0x07060302u)), as_us2v(0x00FF00FFu));
+            const us2v hi2 = __builtin_elementwise_min(as_us2v(__builtin_amdgcn_perm(q[3], q[2], 0x07060302u)), as_us2v(0x00FF00FFu));
+            o3[i] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi2), __builtin_bit_cast(uint32_t, lo2), 0x06040200u);
+        }
+        const int oy = Y0 + m;
+        if (oy < h) *reinterpret_cast<u32x3_a4*>(dst + (__umul24((unsigned)oy, (unsigned)L.stride) + (unsigned)xcol)) = (u32x3_a4){o3[0], o3[1], o3[2]};
+    }
+}
+
 // FAST and the blur both depend on the pyramid only.  A launch group that cannot fill the chip (the one-frame drop-in call) runs
 // them side by side in ONE launch: the first blocks of a frame blur short strips (4 waves = 4 strips), the rest are cell bands.
 // (Two streams would do the same for a full batch - launch_extract forks there - but a fork / join across hardware queues costs
@@ -1305,15 +1466,6 @@ __global__ __launch_bounds__(SMALL ? FAST_SMALL.threads : FAST_LARGE.threads) vo
 //   Keypoints closer than 19 px to an edge may read the level's UNBLURRED reflect-101 border: their group of lanes
 //     takes its taps from global memory with the reflection in the index math.
 // Waves are formed per level (slots padded to multiples of 4), so the level is wave-uniform and its geometry scalar.
-#ifndef ORBX_EXP_TILED_WIN
-#define ORBX_EXP_TILED_WIN 0
-#endif
-#ifndef ORBX_EXP_TILED_PATCH
-#define ORBX_EXP_TILED_PATCH 0
-#endif
-#ifndef ORBX_EXP_PATCH_FIRST
-#define ORBX_EXP_PATCH_FIRST 0
-#endif
 constexpr int DESC_KPW = 4;
 constexpr int DESC_WIN_PITCH = 40, DESC_WIN_ROWS = 37, DESC_WIN_BYTES = DESC_WIN_PITCH * DESC_WIN_ROWS;   // 37 px + up to 3 px of dword alignment per row
 
@@ -1343,6 +1495,11 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
         __builtin_amdgcn_readfirstlane(LG.plane_off), __builtin_amdgcn_readfirstlane(LG.sel_base), __builtin_amdgcn_readfirstlane(LG.quad_base),
         __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, LG.scale))),
         __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, LG.kp_size)))};
+    // The group's keypoint is requested before the counts are there (round 4: its address depends on the quad only; the counts decide
+    // whether it is one — the slot index is clamped into the level's list, what lies behind the list's end is never used).  One
+    // dependent memory round trip less in front of the two gathers.
+    const int k0 = (quad - L.quad_base) * DESC_KPW;
+    Cand kp = b.sel[(long long)frame * g.frame_sel + L.sel_base + min(max(k0 + grp, 0), __builtin_amdgcn_readfirstlane(LG.sel_cap) - 1)];
     int out_base = 0, total = 0, cnt = 0;
     for (int l = 0; l < g.nlevels; l++) {
         const int c = __builtin_amdgcn_readlane(cl, l);
@@ -1350,13 +1507,13 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
         if (l == level) cnt = c;
         total += c;
     }
-    const int k0 = (quad - L.quad_base) * DESC_KPW;
     const bool work = live && k0 < cnt && total <= b.cap && __builtin_amdgcn_readfirstlane(st0) == ORBX_OK;
     const bool valid = work && k0 + grp < cnt;
     const int k = valid ? k0 + grp : (work ? k0 : 0);       // idle groups shadow the wave's first keypoint (results dropped)
-    Cand kp;
-    kp.pos = 0; kp.resp = 0.f;
-    if (work) kp = b.sel[(long long)frame * g.frame_sel + L.sel_base + k];
+    if (!valid) {
+        kp.pos = (uint32_t)__builtin_amdgcn_readlane((int)kp.pos, 0);
+        kp.resp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kp.resp), 0));
+    }
     for (int t = tid; t < 256; t += DESC_WAVES * 64) {
         const uint32_t pk = c_pattern[t];
         reinterpret_cast<float4*>(s_pat)[t] = make_float4((float)(int)(int8_t)pk, (float)(int)(int8_t)(pk >> 8), (float)(int)(int8_t)(pk >> 16), (float)(int)(int8_t)(pk >> 24));
@@ -1389,21 +1546,6 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
     // rounded pattern offsets never exceed 18 px (|(-13,-13)| = 18.4): keypoints at least 19 px from every edge — all but the
     // outermost ring of candidates — take the branch-free path with the window in LDS
     const bool interior = x >= 19 && y >= 19 && x < L.w - 19 && y < L.h - 19;
-#if ORBX_EXP_PATCH_FIRST
-    // The 31 x 31 patch of the UNBLURRED level is requested before the windows of the blurred one: vmcnt counts in order, so with the
-    // window DMA in front (round 3) IC_Angle could not start before the last window dword had landed.  The patch loads are inline
-    // assembly (the compiler's own wait-count pass would wait for everything outstanding before the first use of a loaded value);
-    // the wait below names the number of DMA instructions that may still be in flight.
-    uint32_t I[16];
-    const int pc = li & 7, ppar = li >> 3;
-    {
-        const unsigned off0 = (unsigned)(x + 4 * pc - HALF_PATCH) + __umul24((unsigned)(y - HALF_PATCH + ppar), pstride);
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(I[i]) : "v"(off0 + (unsigned)(2 * i) * pstride), "s"(plain) : "memory");
-    }
-    int ndma = 0;
-#endif
     {
         // window of keypoint q: rows y-18 .. y+18, 40 bytes from the aligned start at or left of x-18, row after row (pitch 40 = 10
         // dwords), i.e. 370 consecutive LDS dwords: 6 global_load_lds_dword of the whole wave per keypoint (lane i of instruction n
@@ -1424,28 +1566,12 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
             const unsigned posq = (unsigned)__builtin_amdgcn_readlane((int)kp.pos, 16 * q);
             const bool inq = __builtin_amdgcn_readlane((int)interior, 16 * q) != 0;
             if (!inq || (q > 0 && k0 + q >= cnt)) continue;                              // wave-uniform
-#if ORBX_EXP_PATCH_FIRST
-            ndma += 6;
-#endif
             const int xq = posq & 0xFFFF, yq = posq >> 16;
-#if ORBX_EXP_TILED_WIN
-            // TIMING EXPERIMENT (wrong results): the window gathered as if the blurred plane were stored in 16 x 8-px tiles of 128 bytes
-            const int hcl = (L.h & ~7) - 1, tpr = L.stride >> 4;
-#pragma unroll
-            for (int n = 0; n < 6; n++) {
-                const unsigned e = 64u * n + (unsigned)lane, er = (e * 205u) >> 11;
-                const int Y = min(yq - 18 + (int)er, hcl), X = ((xq - 18) & ~3) + 4 * (int)(e - 10u * er);
-                const unsigned off = ((unsigned)((Y >> 3) * tpr + (X >> 4)) << 7) + ((unsigned)(Y & 7) << 4) + (unsigned)(X & 15);
-                if (n < 5 || lane < DESC_WIN_ROWS * 10 - 320)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(blur + off), (lptr_t)(win0 + q * DESC_WIN_BYTES + 256 * n), 4, 0, 0);
-            }
-#else
             const uint8_t* srcq = blur + __umul24((unsigned)(yq - 18), (unsigned)L.stride) + (unsigned)((xq - 18) & ~3);
 #pragma unroll
             for (int n = 0; n < 6; n++)
                 if (n < 5 || lane < DESC_WIN_ROWS * 10 - 320)
                     __builtin_amdgcn_global_load_lds((gptr_t)(srcq + eoff[n]), (lptr_t)(win0 + q * DESC_WIN_BYTES + 256 * n), 4, 0, 0);
-#endif
         }
     }
 
@@ -1456,35 +1582,10 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
         uint32_t uw = 0;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) uw |= (uint32_t)(4 * c + kk) << (8 * kk);          // u + 15 of the dword's four pixels
-#if ORBX_EXP_PATCH_FIRST
-#define ORBX_WAIT_I(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(I[0]), "+v"(I[1]), "+v"(I[2]), "+v"(I[3]), "+v"(I[4]), "+v"(I[5]), "+v"(I[6]), "+v"(I[7]), \
-                                    "+v"(I[8]), "+v"(I[9]), "+v"(I[10]), "+v"(I[11]), "+v"(I[12]), "+v"(I[13]), "+v"(I[14]), "+v"(I[15]) :: "memory")
-        if (ndma == 24) ORBX_WAIT_I(24);
-        else if (ndma == 18) ORBX_WAIT_I(18);
-        else if (ndma == 12) ORBX_WAIT_I(12);
-        else if (ndma == 6) ORBX_WAIT_I(6);
-        else ORBX_WAIT_I(0);
-#undef ORBX_WAIT_I
-#else
         const unsigned off0 = (unsigned)(x + 4 * c - HALF_PATCH) + __umul24((unsigned)(y - HALF_PATCH + par), pstride);
         uint32_t I[16];
-#endif
-#if ORBX_EXP_PATCH_FIRST
-#elif ORBX_EXP_TILED_PATCH
-        // TIMING EXPERIMENT (wrong results): the patch gathered as if the plain plane were stored in 16 x 8-px tiles of 128 bytes
-        {
-            const int hcl = (L.h & ~7) - 1, tpr = (int)(pstride >> 4), X = (x + 4 * c - HALF_PATCH) & ~3;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int Y = min(y - HALF_PATCH + par + 2 * i, hcl);
-                const unsigned off = ((unsigned)((Y >> 3) * tpr + (X >> 4)) << 7) + ((unsigned)(Y & 7) << 4) + (unsigned)(X & 15);
-                I[i] = *reinterpret_cast<const uint32_t*>(plain + off);
-            }
-        }
-#else
 #pragma unroll
         for (int i = 0; i < 16; i++) __builtin_memcpy(&I[i], plain + (off0 + (unsigned)(2 * i) * pstride), 4);   // rows par, par + 2, ...: row 31 (par = 1, i = 15) is masked, still inside the level
-#endif
         uint32_t a_su = 0, a_si = 0, a_i = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -1647,6 +1748,8 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
             const int nblk = frame_item_blocks(b, (g.nbtiles_total_s + BLUR_WAVES - 1) / BLUR_WAVES);
             if (aligned) hipLaunchKernelGGL((k_blur<true, BLUR_ROWS_SMALL>), dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);
             else hipLaunchKernelGGL((k_blur<false, BLUR_ROWS_SMALL>), dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);
+        } else if (ORBX_BLUR_MFMA && aligned) {      // full launch groups of dword-aligned frames: the filter as int8 matrix products
+            hipLaunchKernelGGL(k_blur_mfma, dim3(frame_item_blocks(b, (g.nmb_total + MB_WAVES - 1) / MB_WAVES)), dim3(MB_WAVES * 64), 0, st, b);
         } else {
             const int nblk = frame_item_blocks(b, (g.nbtiles_total + BLUR_WAVES - 1) / BLUR_WAVES);
             if (aligned) hipLaunchKernelGGL((k_blur<true, BLUR_ROWS>), dim3(nblk), dim3(BLUR_WAVES * 64), 0, st, b);

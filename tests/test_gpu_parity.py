@@ -496,3 +496,44 @@ def test_beyond_the_round2_limits(gpu_extractor_factory, w, h, nf, nl, family):
     assert len(ok) > 0.5 * nf
     _assert_kps_equal(gk, ok)
     np.testing.assert_array_equal(gd, od)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(w=640, h=480), dict(w=752, h=480), dict(w=322, h=246, nlevels=6), dict(w=98, h=86, nlevels=4, nfeatures=60), dict(w=1280, h=720),
+    dict(w=200, h=600, nlevels=4, nfeatures=400), dict(w=640, h=480, blur_rounding=capi.BLUR_HALF_UP), dict(w=644, h=300, nlevels=5, stride=704),
+], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_blur_planes_of_a_full_launch_group(gpu_extractor_factory, cfg):
+    """GaussianBlur (src/ORBextractor.cc:760) as the throughput path runs it: launch groups of >= 32 dword-aligned frames take
+    k_blur_mfma (the filter as int8 matrix products, round 4).  Every level of every frame byte for byte against the oracle's blur of
+    the same unblurred level: saturated / black / checkerboard frames (255 * 257 * 257 >> 16 = 256 must clamp; the + 128 of the
+    16-bit split at both ends of its range), all families, level widths that are not multiples of 4 or 24, a row stride wider than
+    the image, both rounding modes."""
+    torch = pytest.importorskip("torch")
+    cfg = dict(cfg)
+    w, h, stride = cfg.pop("w"), cfg.pop("h"), cfg.pop("stride", None)
+    nl = cfg.get("nlevels", 8)
+    B = 33
+    fr = [synth.frame(w, h, f, 40 + i) for i, f in enumerate([synth.BLOCKS] * 12 + [synth.NOISE] * 8 + [synth.LOWTEX] * 4 + [synth.MIDTEX] * 4)]
+    yy, xx = np.mgrid[0:h, 0:w]
+    fr += [np.full((h, w), 255, np.uint8), np.zeros((h, w), np.uint8), (((yy // 5 + xx // 7) & 1) * 255).astype(np.uint8),
+           np.where(xx < w // 2, 254, 255).astype(np.uint8), (((yy + xx) & 1) * 255).astype(np.uint8)]
+    frames = np.stack(fr)
+    assert len(frames) == B
+    rs = stride or w
+    buf = np.full((B, h, rs), 0x5A, np.uint8)
+    buf[:, :, :w] = frames
+    d_img = torch.from_numpy(buf).cuda()
+    ex = gpu_extractor_factory(max_batch=B, **cfg)
+    cap = ex.max_keypoints
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d_img.data_ptr(), B, w, h, rs, rs * h, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    mode = cfg.get("blur_rounding", capi.BLUR_X86_SSE2)
+    for f in list(range(0, B, 5)) + [B - 5, B - 4, B - 3, B - 2, B - 1]:
+        for l in range(nl):
+            plain = ex.fetch_plane(capi.DBG_PLANE, l, frame=f)
+            got = ex.fetch_plane(capi.DBG_BLUR, l, frame=f)
+            bad = np.argwhere(got != orc.gaussian_blur7(plain, mode))
+            assert bad.size == 0, "frame %d level %d (%dx%d): %d pixels differ, first %s" % (f, l, plain.shape[1], plain.shape[0], len(bad), bad[0])
