@@ -208,7 +208,13 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
         L.btiles_y_s = (L.h + BLUR_ROWS_SMALL - 1) / BLUR_ROWS_SMALL;
         L.btile_base_s = btile_base_s;
         btile_base_s += L.btiles_x * L.btiles_y_s;
-        L.mb_n = (align_up(L.w, 4) + MB_COLS - 1) / MB_COLS;     // (w >= 39: at least two; the last one is shifted left to end at align4(w))
+        {
+            const int nsteps = (L.h + 31) / 32;
+            L.mb_strips = (L.w + 32 * MB_TILES - 1) / (32 * MB_TILES);
+            L.mb_bands = (nsteps + MB_BAND_STEPS - 1) / MB_BAND_STEPS;
+            L.mb_band_steps = (nsteps + L.mb_bands - 1) / L.mb_bands;
+            L.mb_n = L.mb_strips * L.mb_bands;
+        }
         L.mb_base = mb_base;
         mb_base += L.mb_n;
 

@@ -43,7 +43,8 @@ struct LevelGeom {
     int rz_pitch, rz_rows; // k_resize: LDS source tile of one 256x16 output tile (bytes per row, rows), maxima over the level's tiles
     int btile_base, btiles_x, btiles_y;// blur wave tasks: 248-px strips x 32-row bands of the whole plane
     int btile_base_s, btiles_y_s;      // the same with BLUR_ROWS_SMALL-row bands (launch groups too small to fill the chip: shorter waves)
-    int mb_base, mb_n;     // k_blur_mfma work items: 24-px tile columns of the level (one wave each streams down all rows)
+    int mb_base, mb_n;     // k_blur_mfma work items of the level: mb_strips 64-px strips x mb_bands row bands of mb_band_steps 32-row steps, band-major
+    int mb_strips, mb_bands, mb_band_steps;
     int blur_wvec;         // columns x < blur_wvec round ties-to-even (SSE2 emulation), others half-up
     int blur_sel_last, blur_sel_halo;   // v_perm selectors building the reflect-101 bytes of the last / right-halo dword of a row
     float scale;           // mvScaleFactor[level]
@@ -75,13 +76,19 @@ constexpr int DESC_WAVES = ORBX_DESC_WAVES;   // k_describe: keypoints (waves) p
 #define ORBX_RZ_ROWS 48
 #endif
 #ifndef ORBX_BLUR_MFMA
-#define ORBX_BLUR_MFMA 1                    // 1: full launch groups of aligned frames take k_blur_mfma (round 4); 0: k_blur everywhere
+#define ORBX_BLUR_MFMA 1                    // 1: full launch groups of aligned VGA-class frames take k_blur_mfma (round 4); 0: k_blur everywhere; 2: k_blur_mfma at every width
 #endif
-constexpr int MB_COLS = 24;                 // k_blur_mfma: output columns per tile column (32 input columns feed 25 outputs; 24 = six dwords)
+#ifndef ORBX_MB_BAND_STEPS
+#define ORBX_MB_BAND_STEPS 8
+#endif
+constexpr int MB_BAND_STEPS = ORBX_MB_BAND_STEPS;   // k_blur_mfma: a wave streams at most this many 32-row steps (taller levels are cut into row bands: the
+                                                    // launch ends with its longest waves, and a VGA level 0 is 15 steps against 5 on level 7)
+constexpr int MB_MAX_WIDTH = 1024;           // ... and only levels-0 up to this width (see launch_extract)
+constexpr int MB_TILES = 2;                 // k_blur_mfma: 32-column tiles per strip (one wave streams a 64-pixel strip down all rows)
 #ifndef ORBX_MB_WAVES
 #define ORBX_MB_WAVES 4
 #endif
-constexpr int MB_WAVES = ORBX_MB_WAVES;                 // ... tile columns (waves) per workgroup: neighbours share the 128-byte lines of their rows in the L1
+constexpr int MB_WAVES = ORBX_MB_WAVES;     // ... strips (waves) per workgroup
 constexpr int BLUR_ROWS = ORBX_BLUR_ROWS;   // k_blur: output rows per wave strip
 constexpr int BLUR_ROWS_SMALL = 8;          // ... when the launch group cannot fill the chip anyway (a wave's strip is a serial chain of rows)
 constexpr int RZ_ROWS = ORBX_RZ_ROWS;       // k_resize: output rows per workgroup (a tall tile amortises the table -> source -> LDS latency chain)
@@ -160,7 +167,7 @@ struct DevGeom {
     int nbands_total;        // k_fast_cells work items per frame (>= ncells_total)
     uint32_t nbands_magic;   // floor(2^32 / nbands_total) + 1 (0 for one band): block -> (frame, band) with a scalar multiply instead of a division
     int nbtiles_total, nbtiles_total_s;
-    int nmb_total;           // k_blur_mfma: tile columns per frame (all levels)
+    int nmb_total;           // k_blur_mfma: work items (strip x band) per frame (all levels)
     int nslots;              // sum of ndesired (max keypoints per frame)
     int nquads;              // sum of ceil(ndesired / 4): k_describe waves per frame
     int quota_cells;         // cells of the level with the most cells, rounded up to 64 (k_quota LDS arrays)
