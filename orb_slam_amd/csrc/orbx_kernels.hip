@@ -1319,7 +1319,7 @@ __device__ __forceinline__ int gauss7_taps4(int t0) {   // the bytes tap(t0), ta
     return (int)(uint32_t)(t0 >= 0 ? taps >> sh : taps << -sh);
 }
 
-__global__ __launch_bounds__(MB_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_blur_mfma(Batch b) {      // 128 VGPRs: what its 34 KB of LDS per workgroup admit anyway
+__global__ __launch_bounds__(MB_WAVES * 64) void k_blur_mfma(Batch b) {      // (134 VGPRs: three waves per SIMD, each with two independent chains)
     // three LDS objects on purpose: hipcc orders a ds_read behind an outstanding LDS-DMA (s_waitcnt vmcnt(0)) unless it can prove that
     // the two do not alias, which it can for distinct objects only — with one array the rows requested for the NEXT step were drained
     // in front of the first operand read of THIS step
@@ -1481,9 +1481,77 @@ __global__ __launch_bounds__(MB_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
             asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:32\n\tds_read_b128 %2, %3 offset:64\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(pre[0]), "=&v"(pre[1]), "=&v"(pre[2]) : "v"(ra) : "memory");
         }
+        if (tile1) {
+            // both tiles stage by stage: the two chains (row pass -> split -> HI products -> shift -> LO products -> rounding) are independent, and
+            // a wave that walks them one after the other leaves the matrix pipe and the VALU waiting on each other's results — 0.52 -> 0.48 ms
+            // per 1024 VGA frames although the 32 accumulator registers of two chains cost the fourth wave per SIMD (NOTES.md 9.2)
+            auto centre = [&](v4i pv, bool first) -> v4i {
+                v4i a;
+                a.x = (int)((uint32_t)pv.x ^ 0x80808080u);
+                if (first) a.x = gg == 0 ? (int)(((uint32_t)a.x & 0xFFFFFF00u) | 0x40u) : a.x;      // the constant slot
+                a.y = (int)((uint32_t)pv.y ^ 0x80808080u); a.z = (int)((uint32_t)pv.z ^ 0x80808080u); a.w = (int)((uint32_t)pv.w ^ 0x80808080u);
+                return a;
+            };
+            auto split = [&](const v16i& z, v4i& hi, v4i& lo) {
+                int h4[4], l4[4];
 #pragma unroll
-        for (int j = 0; j < MB_TILES; j++) {
-            if (j == 1 && !tile1) break;
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)z[4 * i + 1], (uint32_t)z[4 * i], 0x05010400u);
+                    const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)z[4 * i + 3], (uint32_t)z[4 * i + 2], 0x05010400u);
+                    l4[i] = (int)(__builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+                    h4[i] = (int)__builtin_amdgcn_perm(p23, p01, 0x07060302u);
+                }
+                hi = (v4i){h4[0], h4[1], h4[2], h4[3]};
+                lo = (v4i){l4[0], l4[1], l4[2], l4[3]};
+            };
+            auto finish = [&](const v16i& acc, int j) {
+                uint32_t o4[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t tw = (tm >> (4 * j + i)) & 1u;
+                    uint32_t q[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const uint32_t t = (uint32_t)acc[4 * i + jj];
+                        q[jj] = t + __builtin_amdgcn_ubfe(t, 16u, tw) + (tw ^ 1u);
+                    }
+                    const us2v lo2 = __builtin_elementwise_min(as_us2v(__builtin_amdgcn_perm(q[1], q[0], 0x07060302u)), as_us2v(0x00FF00FFu));
+                    const us2v hi2 = __builtin_elementwise_min(as_us2v(__builtin_amdgcn_perm(q[3], q[2], 0x07060302u)), as_us2v(0x00FF00FFu));
+                    o4[i] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi2), __builtin_bit_cast(uint32_t, lo2), 0x06040200u);
+                }
+                const unsigned wa = (unsigned)(uintptr_t)(lptr_t)(obuf + m * MB_OUT_PITCH + 32 * j + 16 * gg);
+                const v4i ov = {(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]};
+                asm volatile("ds_write_b128 %0, %1" :: "v"(wa), "v"(ov) : "memory");
+            };
+            const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const v4i a10 = centre(pre[0], true), a20 = centre(pre[1], false), a11 = centre(pre[1], true), a21 = centre(pre[2], false);
+            v16i z0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a10, Ta[0], zero, 0, 0, 0);
+            v16i z1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a11, Ta[1], zero, 0, 0, 0);
+            z0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a20, Tb[0], z0, 0, 0, 0);
+            z1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a21, Tb[1], z1, 0, 0, 0);
+            v16i acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi[0], Wp, zero, 0, 0, 0);      // (the previous tiles' halves of the HI products need nothing of this step)
+            v16i acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi[1], Wp, zero, 0, 0, 0);
+            v4i chi0, clo0, chi1, clo1;
+            split(z0, chi0, clo0);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(chi0, Wc, acc0, 0, 0, 0);
+            split(z1, chi1, clo1);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(chi1, Wc, acc1, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc0[r] = (int)(((uint32_t)acc0[r] << 8) + (uint32_t)(257 * 32896 + 0x7FFF));
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo[0], Wp, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(clo0, Wc, acc0, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc1[r] = (int)(((uint32_t)acc1[r] << 8) + (uint32_t)(257 * 32896 + 0x7FFF));
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo[1], Wp, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(clo1, Wc, acc1, 0, 0, 0);
+            phi[0] = chi0; plo[0] = clo0; phi[1] = chi1; plo[1] = clo1;
+            finish(acc0, 0);
+            finish(acc1, 1);
+            return;
+        }
+        // a strip whose second tile lies beyond the level: one chain
+#pragma unroll
+        for (int j = 0; j < 1; j++) {
             v4i chi, clo;
             row_pass(cur, j, chi, clo, pre + j);
             v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
