@@ -499,12 +499,14 @@ def test_beyond_the_round2_limits(gpu_extractor_factory, w, h, nf, nl, family):
 
 
 @pytest.mark.parametrize("cfg", [
-    dict(w=640, h=480), dict(w=752, h=480), dict(w=322, h=246, nlevels=6), dict(w=98, h=86, nlevels=4, nfeatures=60), dict(w=1280, h=720),
-    dict(w=200, h=600, nlevels=4, nfeatures=400), dict(w=640, h=480, blur_rounding=capi.BLUR_HALF_UP), dict(w=644, h=300, nlevels=5, stride=704),
+    dict(w=640, h=480), dict(w=752, h=480), dict(w=322, h=246, nlevels=6, stride=336), dict(w=98, h=86, nlevels=4, nfeatures=60, stride=112),
+    dict(w=1024, h=200, nlevels=5), dict(w=200, h=600, nlevels=4, nfeatures=400, stride=208), dict(w=640, h=480, blur_rounding=capi.BLUR_HALF_UP),
+    dict(w=644, h=300, nlevels=5, stride=704), dict(w=65, h=70, nlevels=2, nfeatures=60, stride=80),
+    dict(w=1280, h=720), dict(w=322, h=246, nlevels=6),          # levels wider than 1024 px / rows that are not whole 16-byte chunks: k_blur (the VALU form)
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
 def test_blur_planes_of_a_full_launch_group(gpu_extractor_factory, cfg):
-    """GaussianBlur (src/ORBextractor.cc:760) as the throughput path runs it: launch groups of >= 32 dword-aligned frames take
-    k_blur_mfma (the filter as int8 matrix products, round 4).  Every level of every frame byte for byte against the oracle's blur of
+    """GaussianBlur (src/ORBextractor.cc:760) as the throughput path runs it: launch groups of >= 32 frames whose rows are whole 16-byte
+    chunks and whose level 0 is at most 1024 px wide take k_blur_mfma (the filter as int8 matrix products, round 4), the others k_blur.  Every level of every frame byte for byte against the oracle's blur of
     the same unblurred level: saturated / black / checkerboard frames (255 * 257 * 257 >> 16 = 256 must clamp; the + 128 of the
     16-bit split at both ends of its range), all families, level widths that are not multiples of 4 or 24, a row stride wider than
     the image, both rounding modes."""

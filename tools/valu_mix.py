@@ -21,7 +21,7 @@ SLOW = {"v_and_or_b32", "v_min_u32", "v_max_u32", "v_min_i32", "v_max_i32", "v_l
         "v_pk_add_u16", "v_pk_sub_i16", "v_pk_min_u16", "v_pk_max_u16", "v_pk_lshrrev_b16", "v_lerp_u8", "v_min_f32", "v_max_f32", "v_mbcnt_lo_u32_b32",
         "v_mbcnt_hi_u32_b32", "v_add_co_u32", "v_bfi_b32", "v_alignbit_b32", "v_cvt_pk_u8_f32", "v_xnor_b32", "v_dot4_i32_i8", "v_dot8_i32_i4"}   # round 2 measurements
 STAGE = {"k_resize<true, true>": "pyramid", "k_fast_cells<true, 256, 2>": "fast_cells",
-         "k_quota": "quota", "k_cell_select": "cell_select", "k_level_select": "level_select", "k_blur<true, 32>": "blur", "k_describe": "describe",
+         "k_quota": "quota", "k_cell_select": "cell_select", "k_level_select": "level_select", "k_blur_mfma": "blur", "k_blur<true, 32>": "blur_valu", "k_describe": "describe",
          "k_match_batch_mfma<4>": "match"}
 hist = {}
 with tempfile.TemporaryDirectory() as td:
@@ -40,7 +40,7 @@ with tempfile.TemporaryDirectory() as td:
             if line.startswith(".Lfunc_end"):
                 cur = None
             m = re.match(r"^\s+(v_[a-z0-9_]+)", line)
-            if m and cur:
+            if m and cur and not m.group(1).startswith("v_mfma"):          # (matrix-core instructions are not VALU work: SQ_INSTS_MFMA counts them)
                 op = re.sub(r"_(e32|e64)$", "", m.group(1))
                 if op.endswith("_sdwa") or op.endswith("_dpp"):
                     op = "sdwa/dpp form"            # measured: 4 cycles whatever the base opcode (v_mov_b32_dpp, v_and_b32_sdwa, v_add_u32_sdwa ...)
