@@ -101,7 +101,11 @@ int orbx_extract(orbx_extractor* h, const uint8_t* img, int w, int hgt, ptrdiff_
 /* Throughput form.  d_imgs: DEVICE pointer to nframes frames, frame f at d_imgs + f*frame_stride,
  * rows `row_stride` bytes apart.  d_kps[nframes*cap], d_desc[nframes*cap*32], d_n[nframes]: DEVICE
  * buffers.  Work is enqueued on `stream` (a hipStream_t, may be NULL) and NOT synchronised.
- * d_status[nframes] (optional DEVICE int32 buffer) receives ORBX_OK / ORBX_ERR_CAPACITY per frame. */
+ * d_status[nframes] (optional DEVICE int32 buffer) receives ORBX_OK / ORBX_ERR_CAPACITY per frame.
+ * Pitched frames (row_stride > w): every row, the last row of the last frame included, must be readable up to
+ * min(row_stride, w rounded up to 16) bytes — the kernels stage rows in whole 16-byte chunks (as a hipMallocPitch-style
+ * buffer of row_stride x hgt bytes per frame guarantees).  Fastest when d_imgs, row_stride and frame_stride are multiples of
+ * 16 (any alignment is accepted: bytes are then assembled on the fly). */
 int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int nframes, int w, int hgt,
                               ptrdiff_t row_stride, ptrdiff_t frame_stride,
                               orbx_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, int cap,

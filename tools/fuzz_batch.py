@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential test of the THROUGHPUT path (orbx_extract_batch_device: per-level k_resize, full-batch k_fast_cells /
-k_blur / k_describe, frame -> XCD block renumbering from 64 frames): random image sizes, constructor arguments, families and launch
+k_blur / k_blur_mfma / k_describe, frame -> XCD block renumbering from 64 frames): random image sizes, constructor arguments, families and launch
 group sizes (32 .. 96 frames, max_batch sometimes smaller than the batch so that a call spans several launch groups); every frame
 of every case against the CPU oracle, byte for byte.  tools/fuzz_parity.py does the same for the one-frame call (orbx_extract).
 usage: fuzz_batch.py [cases] [seed]   — prints one JSON line."""
@@ -38,7 +38,9 @@ for c in range(cases):
     B = int(rng.integers(32, 97)) if w * h <= 1280 * 720 else int(rng.integers(32, 41))
     max_batch = B if rng.random() < 0.7 else int(rng.integers(32, B + 1))
     pad = int(rng.choice([0, 0, 4, 8]))                      # row stride beyond the width (multiple of 4: the aligned kernels)
-    fams = rng.choice([0, 1, 1, 1, 3], size=B)
+    if rng.random() < 0.5:
+        pad = (-w) % 16 + 16 * int(rng.integers(0, 3))       # rows of whole 16-byte chunks: what k_blur_mfma (levels up to 1024 px wide) takes
+    fams = rng.choice([0, 1, 1, 1, 3, 4], size=B)
     try:
         capi.geometry(w, h, nfeatures=nf, scaleFactor=sf, nlevels=nl, scoreType=st, fastTh=th)
     except capi.OrbxError as e:
