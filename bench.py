@@ -415,6 +415,8 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
     mix = rep["mix"]
     if mix and wl_tag == "hd_1920x1080_nf2000" and "blur_valu" in mix:
         mix = dict(mix, blur=mix["blur_valu"])         # levels wider than 1024 px keep the VALU form of the blur (k_blur), VGA-class ones run k_blur_mfma
+        if "fast_cells_large" in mix:
+            mix["fast_cells"] = mix["fast_cells_large"]    # ... and the large launch shape of k_fast_cells (two dwords per lane and round)
     if valu_launch and mix and dom in mix:
         cpi = mix[dom]["cycles_per_inst_lo"]
         ach = valu_launch / (stage_ms[dom] * 1e-3)

@@ -98,12 +98,13 @@ constexpr int RZ_ROWS = ORBX_RZ_ROWS;       // k_resize: output rows per workgro
 // of a remainder < 64) and of scored corners (the NMS work list; a band that overflows it takes a dense sweep instead).
 struct FastShape { int threads, ppt, band_px, max_cw; };
 #ifndef ORBX_FS
-#define ORBX_FS 256, 2, 8192, 500
+#define ORBX_FS 256, 1, 8192, 500
 #endif
 #ifndef ORBX_FL
 #define ORBX_FL 256, 2, 7168, 6500
 #endif
-constexpr FastShape FAST_SMALL = {ORBX_FS};   // VGA-class grids
+constexpr FastShape FAST_SMALL = {ORBX_FS};   // VGA-class grids (round 4: ONE dword per lane and round — with the bands scored at fastTh first the sparse phases shrank and the
+                                              // shorter dense rounds win: 0.883 -> 0.833 ms per 1024 VGA frames, S-midtex 1.02 -> 0.95; rounds 2-3 ran two, then a wash)
 constexpr FastShape FAST_LARGE = {ORBX_FL};   // 720p / 1080p-class grids (round 3: 256 threads over 7168-px bands — per 256 1080p frames 1.84 ms
                                               // against 2.06 for the 512 threads over 10240-px bands of rounds 1-2; 256 threads at 5120 / 6144 / 8192 /
                                               // 12288 px: 1.91 / 1.91 / 1.90 / 1.95).  max_cw 6500: two own rows + 2 halo rows + the 6 ring rows of a staged band
