@@ -22,7 +22,7 @@ fi
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_overlap -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --min-seconds 0 --no-also --no-parity > $D/stats_overlap.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_match -- python $R/bench.py --config match100k --steps 40 --warmup 5 --no-cpu-baseline --min-seconds 0 --no-parity > $D/stats_match.log 2>&1
 cd $R
-timeout 900 python bench.py > $D/bench.json 2> $D/bench.err          # the driver's command: headline + also{hd1080, match100k}, parity legs, CPU baselines
+( time timeout 900 python bench.py > $D/bench.json 2> $D/bench.err ) 2> $D/bench_wall.txt          # the driver's command: headline + also{hd1080, match100k}, parity legs, CPU baselines
 Q="--no-cpu-baseline --no-also --min-seconds 2"
 timeout 300 python bench.py --lanes 1 $Q > $D/bench_one_lane.json 2>/dev/null
 timeout 300 python bench.py --region-timing $Q > $D/bench_region_timing.json 2>/dev/null
