@@ -173,7 +173,7 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
                     if (k > 0 && bg.y0 > c.y1) break;                 // (rounding left no rows for this band)
                     bg.ey0 = (int16_t)std::max<int>(c.y0, bg.y0 - 1);
                     bg.ey1 = (int16_t)std::min<int>(c.y1, bg.y1 + 1);
-                    bg.level = (int16_t)l;
+                    bg.level = l;
                     const int bh = std::max(0, bg.y1 - bg.y0 + 1);
                     bg.cand_off = cand_off;
                     bg.cand_cap = ((cw + 1) / 2) * ((bh + 1) / 2);    // strict 3x3 maxima cannot be adjacent

@@ -64,6 +64,9 @@ struct CellGeom {
 #ifndef ORBX_BLUR_WAVES
 #define ORBX_BLUR_WAVES 2
 #endif
+#ifndef ORBX_DESC_PACKED_PATTERN
+#define ORBX_DESC_PACKED_PATTERN 1      // k_describe: the BRIEF pattern in LDS as packed int8 (1 KB) instead of floats (4 KB)
+#endif
 #ifndef ORBX_DESC_WAVES
 #define ORBX_DESC_WAVES 4
 #endif
@@ -117,6 +120,9 @@ constexpr FastShape FAST_LARGE = {ORBX_FL};   // 720p / 1080p-class grids (round
 #ifndef ORBX_FAST_TWO_PASS
 #define ORBX_FAST_TWO_PASS 1
 #endif
+#ifndef ORBX_FAST_ROTATE
+#define ORBX_FAST_ROTATE 1      // k_fast_cells: wave roles rotate with the band index (see fast_band_task)
+#endif
 constexpr int FAST_Q1CAP = 192, FAST_Q2CAP = 128, FAST_Q3CAP = 192;
 constexpr int fast_q0cap(int) { return 128; }
 constexpr int fast_wave_queue_bytes(int ppt) { return fast_q0cap(ppt) * 4 + FAST_Q1CAP * 2 + FAST_Q2CAP * 2 + FAST_Q3CAP * 2; }
@@ -127,7 +133,7 @@ struct BandGeom {
     int16_t x0, x1;           // the cell's column range (inclusive)
     int16_t y0, y1;           // rows this band owns (inclusive)
     int16_t ey0, ey1;         // rows it scores: own rows + 1 halo row towards neighbouring bands of the same cell
-    int16_t level, pad;
+    int32_t level;            // (a whole dword: as int16 the compiler fetched it with a VECTOR load — a memory round trip in front of every k_fast_cells workgroup)
     int32_t cand_off;         // first Cand slot of its sub-list relative to the level's cand_base
     int32_t cand_cap;
     // 1 / (dwords, bytes, 16-byte chunks per row of the staged band): the divisors of k_fast_cells' p -> (row, column) splits.  Computed

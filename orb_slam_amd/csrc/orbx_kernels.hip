@@ -453,13 +453,17 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {   // number of 
 template <bool ALIGNED, int NT, int PPT>
 __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int item, uint8_t* smem) {
     constexpr int NW = NT / 64;
+    static_assert((NW & (NW - 1)) == 0, "wave roles rotate modulo NW");
     constexpr int Q0CAP = fast_q0cap(PPT), Q1CAP = FAST_Q1CAP, Q2CAP = FAST_Q2CAP, Q3CAP = FAST_Q3CAP;
     constexpr int WQ_BYTES = fast_wave_queue_bytes(PPT);
     const DevGeom& g = b.g;
     const BandGeom bg = b.bands[item];
     const int level = bg.level;
     const LevelGeom& L = g.lv[level];
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    // Wave roles rotate with the band index.  The tails of the task are wave-0 heavy (a VGA cell's survivor list is <= 70 chunks: wave 0
+    // writes all of it; tid 0 closes the band), and the waves of a 4-wave workgroup land on the CU's four SIMDs in order, so without
+    // the rotation one SIMD of every CU carried all of that.  Every use of wave / tid below is work assignment only.
+    const int lane = threadIdx.x & 63, wave = ORBX_FAST_ROTATE ? (wave_id() + item) & (NW - 1) : wave_id(), tid = wave * 64 + lane;
     const int cw = bg.x1 - bg.x0 + 1, ch = bg.ey1 - bg.ey0 + 1;      // scored rectangle: own rows + halo rows towards sibling bands
     CellState* cst = b.cstate + (long long)frame * g.nbands_total + item;
     if (cw <= 0 || ch <= 0) {
@@ -1630,7 +1634,11 @@ constexpr int DESC_KPW = 4;
 constexpr int DESC_WIN_PITCH = 40, DESC_WIN_ROWS = 37, DESC_WIN_BYTES = DESC_WIN_PITCH * DESC_WIN_ROWS;   // 37 px + up to 3 px of dword alignment per row
 
 __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
+#if ORBX_DESC_PACKED_PATTERN
+    __shared__ uint32_t s_pat[256];                                    // test t: x0, y0, x1, y1 as the four int8 of c_pattern[t] (1 KB: six workgroups per CU; as floats, 4 KB: five)
+#else
     __shared__ __attribute__((aligned(16))) float s_pat[256 * 4];     // test t: x0, y0, x1, y1
+#endif
     __shared__ __attribute__((aligned(16))) uint32_t s_mask[256];       // circle byte masks of the 31 x 8 patch dwords (slots 248.. = 0)
     __shared__ __attribute__((aligned(16))) uint8_t s_win[DESC_WAVES * DESC_KPW * DESC_WIN_BYTES];   // per keypoint: 37 rows x 40 bytes of the blurred level
     const DevGeom& g = b.g;
@@ -1676,7 +1684,11 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
     }
     for (int t = tid; t < 256; t += DESC_WAVES * 64) {
         const uint32_t pk = c_pattern[t];
+#if ORBX_DESC_PACKED_PATTERN
+        s_pat[t] = pk;
+#else
         reinterpret_cast<float4*>(s_pat)[t] = make_float4((float)(int)(int8_t)pk, (float)(int)(int8_t)(pk >> 8), (float)(int)(int8_t)(pk >> 16), (float)(int)(int8_t)(pk >> 24));
+#endif
         // umax[] (reference :495-510) depends only on HALF_PATCH_SIZE = 15: nibble v of UMAX_NIBBLES (the host checks it against the computed table)
         const int r = t >> 3, c = t & 7;
         const int v = r - HALF_PATCH, av = v < 0 ? -v : v;
@@ -1775,7 +1787,17 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float sn, cs;
     sincosf_orb(angle * factorPI, &sn, &cs);
+#if ORBX_DESC_PACKED_PATTERN
+    struct PatRow {          // one ds_read_b32 and four v_cvt_f32_i32 with a sign-extending byte select (SDWA) per test
+        const uint32_t* p;
+        __device__ __forceinline__ float4 operator[](int i) const {
+            const uint32_t pk = p[i];
+            return make_float4((float)(int)(int8_t)pk, (float)(int)(int8_t)(pk >> 8), (float)(int)(int8_t)(pk >> 16), (float)(int)(int8_t)(pk >> 24));
+        }
+    } pat{s_pat + li};
+#else
     const float4* pat = reinterpret_cast<const float4*>(s_pat) + li;
+#endif
     uint32_t mybits = 0;                                        // bit j: test li + 16 j
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the wave's window DMA has landed (issued before IC_Angle)
     wave_lds_fence();                                           // the windows are private to this wave: no workgroup barrier

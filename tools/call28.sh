@@ -1,0 +1,5 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+tools/exp_ab.sh ab28 head:1 tree:1 head:4 tree:4 head:1:hd1080 tree:1:hd1080 head:1 tree:1
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
+timeout 100 python tools/corun_probe.py 2>&1 | tail -5

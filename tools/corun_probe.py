@@ -28,6 +28,7 @@ def main():
     class Lane:
         def __init__(self, first):
             self.ex = capi.ORBextractor(nfeatures=a.nfeatures, device=0, max_batch=b)
+            self.ex_next = capi.ORBextractor(nfeatures=a.nfeatures, device=0, max_batch=b)      # the pyramid of step i + 1 (the library refuses parts queued out of order on one handle)
             self.stream = torch.cuda.ExternalStream(capi.stream_create(0), device=dev)
             self.img = torch.from_numpy(synth.frames(w, h, synth.BLOCKS, first, b)).to(dev)
             cap = self.cap = self.ex.max_keypoints
@@ -36,8 +37,8 @@ def main():
             self.n = torch.zeros(b + 1, dtype=torch.int32, device=dev)
             self.match = torch.zeros((3, b, cap), dtype=torch.int32, device=dev)
 
-        def run(self, phases):
-            self.ex.extract_batch_device(self.img.data_ptr(), b, w, h, w, w * h, self.kps.data_ptr(), self.desc[1].data_ptr(), self.n[1:].data_ptr(),
+        def run(self, phases, ex=None):
+            (ex or self.ex).extract_batch_device(self.img.data_ptr(), b, w, h, w, w * h, self.kps.data_ptr(), self.desc[1].data_ptr(), self.n[1:].data_ptr(),
                                          self.cap, 0, self.stream.cuda_stream, phases=phases)
 
         def do_match(self):
@@ -56,7 +57,7 @@ def main():
     def f_pyr(ln): ln.run(P)
     def f_desc(ln): ln.run(S)
     def f_match(ln): ln.do_match()
-    def f_mem(ln): ln.run(S); ln.do_match(); ln.run(P)          # describe + match of step i, pyramid of step i + 1
+    def f_mem(ln): ln.run(S); ln.do_match(); ln.run(P, ln.ex_next)          # describe + match of step i, pyramid of step i + 1
     def f_all(ln): ln.run(capi.PHASE_ALL); ln.do_match()
 
     def timeit(jobs):
