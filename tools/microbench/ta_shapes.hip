@@ -70,11 +70,35 @@ __global__ __launch_bounds__(256) void k_store(uint8_t* __restrict__ buf, uint32
     if (iters < 0) out[threadIdx.x] = 0;
 }
 
+// the 37 x 40-byte window of k_describe out of a STRIP-MAJOR plane (column strips of SW bytes, the rows of a strip back to back):
+// dword lane e of instruction n -> (row e / 10, column e % 10); byte x = xa + 4 col; address = (x / SW) * strip_bytes + row * SW + x % SW
+__global__ __launch_bounds__(256) void k_window_strips(const uint8_t* __restrict__ buf, uint32_t* out, int iters, int SW, int xa, unsigned region_mask) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 1024 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned strip_bytes = 480u * (unsigned)SW;
+    unsigned lane_off[6];
+    for (int n = 0; n < 6; n++) {
+        const int e = 64 * n + lane, r = e / 10, c = e - 10 * r, x = xa + 4 * c;
+        lane_off[n] = SW ? (unsigned)(x / SW) * strip_bytes + (unsigned)(r * SW + x % SW) : (unsigned)(r * 640 + x);
+    }
+    unsigned base = (blockIdx.x * 4 + wave) * 9973u * 64u;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const unsigned a = ((base + (unsigned)(k / 6) * 40960u) & region_mask) + lane_off[k % 6];
+            if (k % 6 < 5 || lane < 50) __builtin_amdgcn_global_load_lds((gptr_t)(buf + a), (lptr_t)(lds + wave * 4096 + (k & 3) * 1024), 4, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        base += 7919u * 64u;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = lds[threadIdx.x];
+}
+
 int main() {
     const size_t region = 4u << 20;
     uint8_t* buf; uint32_t* out;
-    if (hipMalloc(&buf, region + (1 << 20)) != hipSuccess || hipMalloc(&out, 4096 * 256 * 4) != hipSuccess) return 1;
-    hipMemset(buf, 1, region + (1 << 20));
+    if (hipMalloc(&buf, region + (4 << 20)) != hipSuccess || hipMalloc(&out, 4096 * 256 * 4) != hipSuccess) return 1;
+    hipMemset(buf, 1, region + (4 << 20));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const Shape shapes[] = {
         {"dword, 256 B contiguous per wave", 4, 256, 256, 0, 0},
@@ -127,5 +151,19 @@ int main() {
             }
         }
     }
+    for (int SW : {0, 32, 64, 128})
+        for (int xa : {0, 12, 28, 44, 60}) {
+            const unsigned mask = (unsigned)(region - 1) & ~63u;
+            float ms = 0;
+            for (int rep = 0; rep < 2; rep++) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(k_window_strips, blocks, 256, 0, 0, buf, out, rep ? iters : 5, SW, xa, mask);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+            }
+            const double windows = (double)blocks * 4 * iters * 2;
+            printf("window 37 x 40 B by six dword DMA instructions, %s, x0 %% 64 = %2d: %8.3f ms  %6.1f cycles per window per CU\n",
+                   SW == 0 ? "row-major pitch 640      " : SW == 32 ? "strip-major, 32-B strips " : SW == 64 ? "strip-major, 64-B strips " : "strip-major, 128-B strips", xa, ms, ms * 1e-3 * 2.4e9 * 256 / windows);
+        }
     return 0;
 }
