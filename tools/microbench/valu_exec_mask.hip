@@ -28,7 +28,10 @@
 #define OP_MIN3(x) "v_min3_u32 " #x ", " #x ", %8, %9\n"
 #define OP_ADD(x) "v_add_u32 " #x ", " #x ", %8\n"
 #define OP_FMA(x) "v_fma_f32 " #x ", " #x ", %8, %9\n"
-KERNEL(k_min3, OP_MIN3) KERNEL(k_add, OP_ADD) KERNEL(k_fma, OP_FMA)
+#define OP_CND(x) "v_cndmask_b32 " #x ", " #x ", %8, vcc\n"
+#define OP_MULLO(x) "v_mul_lo_u32 " #x ", " #x ", %8\n"
+#define OP_LSHLADD(x) "v_lshl_add_u32 " #x ", " #x ", 1, %8\n"
+KERNEL(k_min3, OP_MIN3) KERNEL(k_add, OP_ADD) KERNEL(k_fma, OP_FMA) KERNEL(k_cnd, OP_CND) KERNEL(k_mullo, OP_MULLO) KERNEL(k_lshladd, OP_LSHLADD)
 typedef void (*kern_t)(unsigned*, int, unsigned long long);
 
 int main() {
@@ -37,9 +40,9 @@ int main() {
     if (hipMalloc(&out, (size_t)blocks * 256 * 4) != hipSuccess) return 1;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    struct { const char* name; kern_t k; } ks[] = {{"v_min3_u32", k_min3}, {"v_add_u32", k_add}, {"v_fma_f32", k_fma}};
+    struct { const char* name; kern_t k; } ks[] = {{"v_min3_u32", k_min3}, {"v_add_u32", k_add}, {"v_fma_f32", k_fma}, {"v_cndmask_b32", k_cnd}, {"v_mul_lo_u32", k_mullo}, {"v_lshl_add_u32", k_lshladd}};
     struct { const char* name; unsigned long long m; } ms[] = {
-        {"all 64 lanes", ~0ull}, {"lanes 0..31", 0xFFFFFFFFull}, {"lanes 0..15", 0xFFFFull}, {"lanes 0..7", 0xFFull}, {"lane 0", 1ull},
+        {"all 64 lanes", ~0ull}, {"lanes 0..31", 0xFFFFFFFFull}, {"lanes 0..15", 0xFFFFull}, {"lanes 0..13", 0x3FFFull}, {"lanes 0..11", 0xFFFull}, {"lanes 0..9", 0x3FFull}, {"lanes 0..8", 0x1FFull}, {"lanes 0..7", 0xFFull}, {"lane 0", 1ull},
         {"lanes 16..31", 0xFFFF0000ull}, {"lanes 48..63", 0xFFFF000000000000ull}, {"lanes 0 and 32", 0x100000001ull}, {"every 16th lane", 0x0001000100010001ull}, {"every 4th lane", 0x1111111111111111ull}};
     for (auto& k : ks)
         for (auto& m : ms) {
