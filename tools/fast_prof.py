@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a k_fast_cells wave spends its life: per-phase s_memtime deltas summed over all waves, read from an INSTRUMENTED build of the
-library (build_variants/prof: the PROF() marks of the experiment described in NOTES.md; not part of the product).
+library (tools/build_prof_variant.py -> build_variants/prof | profd; NOTES.md 9.6; not part of the product).
 usage: ORBX_LIB=build_variants/prof/liborbx.so python tools/fast_prof.py [family] [w h] [nframes]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
