@@ -30,3 +30,13 @@ def test_experiment_index_lists_every_call_script():
             elif part:
                 listed.add(int(part))
     assert set(calls) <= listed, sorted(set(calls) - listed)
+
+
+def test_band_hint_patch_still_applies():
+    """tools/experiments/band_hint_frame0.patch (NOTES.md 9.6: measured, waiting for a round with GPU budget to collect counters) must keep applying"""
+    import subprocess
+    r = subprocess.run(["git", "apply", "--check", "-p0", "tools/experiments/band_hint_frame0.patch"], cwd=ROOT, capture_output=True, text=True)
+    if "not a git repository" in (r.stderr or "").lower():
+        import pytest
+        pytest.skip("no git metadata here")
+    assert r.returncode == 0, r.stderr
