@@ -218,9 +218,23 @@ def free_port():
     return p
 
 
-def spawn_ranks(n):
+def visible_gpus():
+    """GPUs this process would see, without creating a HIP context in the parent (the ranks are exec'ed, not forked)"""
+    import torch
+    return torch.cuda.device_count()
+
+
+def spawn_ranks(n, share_device=False, timeout=1500.0):
     """`python bench.py --gpus N` as a plain command: start the N ranks (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
-    torch.distributed.run would set them); rank 0 inherits stdout and prints the JSON line."""
+    torch.distributed.run would set them); rank 0 inherits stdout and prints the JSON line.  Refuses to start when the node shows
+    fewer than N devices (unless every rank is told to share cuda:0).  A rank that dies takes the others with it after a grace
+    period, and the whole run is bounded by `timeout`: a hung rank must not hang the command (rank 0's line, if it was printed,
+    is already on stdout)."""
+    if not share_device:
+        have = visible_gpus()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but this node shows %d device(s) (HIP_VISIBLE_DEVICES=%s)\n" % (n, have, os.environ.get("HIP_VISIBLE_DEVICES")))
+            return 2
     port = free_port()
     procs = []
     for r in range(n):
@@ -228,9 +242,26 @@ def spawn_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    t0, rc, failed_at = time.monotonic(), 0, None
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            c = p.poll()
+            if c is not None:
+                alive.remove(p)
+                rc = max(rc, abs(c))
+                if c != 0 and failed_at is None:
+                    failed_at = time.monotonic()
+        now = time.monotonic()
+        if alive and ((failed_at is not None and now - failed_at > 30.0) or now - t0 > timeout):
+            sys.stderr.write("bench.py: %s; killing %d remaining rank(s)\n"
+                             % ("a rank failed" if failed_at is not None else "no result after %.0f s" % timeout, len(alive)))
+            for p in alive:
+                p.kill()
+            for p in alive:
+                p.wait()
+            return max(rc, 124 if failed_at is None else rc)
     return rc
 
 
@@ -249,7 +280,13 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
     G, b, cap = pipe.G, pipe.b, pipe.cap
     if a.warmup < 1:
         raise SystemExit("--warmup must be >= 1 (first-call costs would land in the timed region)")
-    pipe.tune(d_img.data_ptr())          # explicit, blocking stream-placement probe (ORBX_LANE_PLACEMENT=k skips it); outside every timed loop
+    # explicit, blocking stream-placement probe (ORBX_LANE_PLACEMENT=k skips it), outside every timed loop; the ranks of a node probe one
+    # after the other (they share host cores, and with --share-device the GPU): a probe timed beside another rank's probe measures the neighbour
+    for r in range(world):
+        if r == rank:
+            pipe.tune(d_img.data_ptr())
+        if world > 1:
+            dist_util.barrier(dist, a.backend, local_rank)
 
     def step(i, timed):
         pipe.step(d_img.data_ptr() + ((i * B) % ring) * w * h, timed=timed)
@@ -632,6 +669,68 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ the line the driver parses
+DETAIL_PREFIX = "#detail "      # full reports: one stdout line each, in front of the final line, never starting with "{"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full, also=None):
+    """The LAST stdout line: the contract's headline keys + roofline + cpu_baseline, and one short row per other configuration
+    (`also_summary`).  Everything else (notes, per-call timings, parity detail, the full `also` reports) is printed in front of it as
+    `#detail <name> <json>` lines.  Bounded: <= 4 KB at one rank, <= 6 KB at eight (the 23 KB line of round 4 did not
+    parse in the driver's record); tests/test_bench_line.py asserts it on CPU, tests/test_gpu_bench.py on the GPU."""
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "repeats", "timed_steps", "timed_seconds", "ms_per_step",
+                       "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = full.get("config", {})
+    c = _pick(cfg, ("workload", "frames_per_step_per_gpu", "resident_frames_per_gpu", "lanes", "queries_per_gpu", "train_descriptors",
+                    "parity_checked_frames", "parity_checked_rows", "parity_mismatches", "mean_keypoints_per_frame", "frames_with_error_status",
+                    "host_submit_ms_per_step", "best_distance_checksum", "library_build_id"))
+    if isinstance(cfg.get("lane_placement"), dict):
+        c["lane_placement"] = cfg["lane_placement"].get("chosen")
+    out["config"] = c
+    r = full.get("roofline") or {}
+    ro = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
+                   "frames_per_launch", "pairs_per_launch", "frac_of_achievable"))
+    ro.setdefault("traffic", None)
+    if isinstance(r.get("valu_issue"), dict):
+        ro["valu_issue"] = _pick(r["valu_issue"], ("achieved", "peak", "unit", "frac", "clock_ghz"))
+    if isinstance(r.get("hbm"), dict):
+        ro["hbm"] = _pick(r["hbm"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch"))
+    out["roofline"] = ro
+    if isinstance(full.get("roofline_pipeline"), dict):
+        out["roofline_pipeline"] = _pick(full["roofline_pipeline"], ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step_serial"))
+    if isinstance(full.get("roofline_valu"), dict):
+        out["roofline_valu"] = _pick(full["roofline_valu"], ("bound", "achieved", "peak", "unit", "frac", "clock_ghz"))
+    if "stage_ms_per_step" in full:
+        out["stage_ms_per_step"] = full["stage_ms_per_step"]
+    for k in ("cpu_baseline", "cpu_baseline_reference_source", "cpu_baseline_allcores"):
+        if isinstance(full.get(k), dict):
+            out[k] = _pick(full[k], ("value", "unit", "cores", "kind", "sample", "median_ms") if k == "cpu_baseline" else ("value", "unit", "cores", "kind"))
+    if full.get("per_rank"):
+        keys = [k for k in ("rank", "device", "frames", "pairs", "elapsed_s", "parity_checked_frames") if k in full["per_rank"][0]]
+        out["per_rank"] = {"columns": keys, "rows": [[row.get(k) for k in keys] for row in full["per_rank"]]}
+    if also:
+        summ = {}
+        for name, rpt in also.items():
+            row = _pick(rpt, ("value", "unit", "ms_per_step", "timed_seconds"))
+            row["parity_mismatches"] = rpt.get("config", {}).get("parity_mismatches")
+            rr = rpt.get("roofline") or {}
+            row["roofline_frac"], row["roofline_bound"] = rr.get("frac"), rr.get("bound")
+            if isinstance(rpt.get("cpu_baseline"), dict):
+                row["cpu_baseline"] = rpt["cpu_baseline"].get("value")
+            summ[name] = row
+        out["also_summary"] = summ
+    out["detail"] = "full reports: the '%s<name> <json>' stdout lines in front of this line" % DETAIL_PREFIX
+    return out
+
+
+def print_detail(name, report):
+    print(DETAIL_PREFIX + name + " " + json.dumps(report), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -651,8 +750,9 @@ def main():
                     help="also time every kernel inside the timed region (HIP events between the kernels of every lane: costs a few percent)")
     ap.add_argument("--min-seconds", type=float, default=6.0,
                     help="repeat the --steps block until the timed region lasts at least this long (0: exactly --steps steps)")
-    ap.add_argument("--parity", default="all", choices=["all", "sample", "none"],
-                    help="oracle comparison of the LAST timed step's outputs: every frame (default), lane / step borders + interior frames, or none")
+    ap.add_argument("--parity", default=None, choices=["all", "sample", "none"],
+                    help="oracle comparison of the LAST timed step's outputs: every frame (default at one rank), lane / step borders + interior "
+                         "frames (default at N > 1: the ranks of a node share its host cores), or none")
     ap.add_argument("--no-parity", action="store_true", help="same as --parity none")
     ap.add_argument("--cpu-reference-seconds", type=float, default=4.0,
                     help="CPU sample of oracle/_ref/libref_orbextractor.so (the reference's own ORBextractor.cc), when that file is present; 0 disables")
@@ -660,7 +760,11 @@ def main():
                     help="initialise torch.distributed even at world size 1 (the RCCL communicator, barrier and collectives then run as at N > 1)")
     ap.add_argument("--no-also", action="store_true",
                     help="headline configuration only (the default run also measures vga_extract, hd1080, match100k and the other frame families)")
-    ap.add_argument("--also-min-seconds", type=float, default=1.5, help="timed region of each embedded configuration")
+    ap.add_argument("--also-min-seconds", type=float, default=6.0,
+                    help="timed region of each other frame configuration (as long as the headline's: sustained clocks)")
+    ap.add_argument("--also-match-min-seconds", type=float, default=2.0, help="timed region of the 100k x 100k configurations")
+    ap.add_argument("--detail-file", default=None, help="also write the full reports (headline + also + the compact line) to this JSON file")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0, help="bare --gpus N command: kill the ranks when the run exceeds this many seconds")
     ap.add_argument("--also-cpu-seconds", type=float, default=5.0, help="CPU baseline sample of each embedded configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -670,9 +774,11 @@ def main():
     a = ap.parse_args()
     if a.no_parity:
         a.parity = "none"
+    if a.parity is None:
+        a.parity = "all" if max(a.gpus, int(os.environ.get("WORLD_SIZE", "1"))) == 1 else "sample"
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(a.gpus))
+        sys.exit(spawn_ranks(a.gpus, a.share_device, a.rank_timeout))
 
     import torch
     from orb_slam_amd import dist_util, synth
@@ -701,18 +807,22 @@ def main():
     bad = int(out.get("_mismatches", 0)) if rank != 0 else int(out["config"].get("parity_mismatches", 0))
     if rank == 0 and numa:
         out["config"]["host_numa_binding"] = numa
+    also = {}
     if a.config == "vga" and a.family == synth.BLOCKS and not a.no_also:
-        # BASELINE.json's other GPU configurations and the headline configuration on the other frame families, in the same line (the
-        # driver runs this command once): shorter timed regions and CPU samples, same definitions, same every-frame parity leg.  At
-        # N > 1 `hd1080` is configs[3] (one 1080p stream per GPU).
-        also = {}
-        for key, name, family, cpu in (("vga_extract", "vga_extract", synth.BLOCKS, False), ("hd1080", "hd1080", synth.BLOCKS, True),
-                                       ("match100k", "match100k", synth.BLOCKS, True), ("match100k_popcount", "match100k", synth.BLOCKS, False),
-                                       ("vga_noise", "vga", synth.NOISE, False), ("vga_midtex", "vga", synth.MIDTEX, False),
-                                       ("vga_lowtex", "vga", synth.LOWTEX, False)):
+        # BASELINE.json's other GPU configurations and the headline configuration on the other frame families, in the same run (the
+        # driver runs this command once): same definitions, same parity leg, a timed region as long as the headline's for the frame
+        # configurations (--also-min-seconds, 6 s: the chip clocks down over the first seconds of a region).  At
+        # N > 1 `hd1080` is configs[3] (one 1080p stream per GPU); the frame families add nothing to a scaling run and are skipped there.
+        entries = [("vga_extract", "vga_extract", synth.BLOCKS, False), ("hd1080", "hd1080", synth.BLOCKS, True),
+                   ("match100k", "match100k", synth.BLOCKS, True), ("match100k_popcount", "match100k", synth.BLOCKS, False),
+                   ("vga_noise", "vga", synth.NOISE, False), ("vga_midtex", "vga", synth.MIDTEX, False), ("vga_lowtex", "vga", synth.LOWTEX, False)]
+        if world > 1:
+            entries = [e for e in entries if e[0] in ("hd1080", "match100k")]
+        for key, name, family, cpu in entries:
             a2 = argparse.Namespace(**vars(a))
             a2.match_path = 0 if key == "match100k_popcount" else -1      # the uint64 x 4 xor + popcount kernels north_star names, beside the MFMA form
-            a2.config, a2.min_seconds, a2.cpu_seconds, a2.cpu_allcores_seconds, a2.cpu_reference_seconds = name, a.also_min_seconds, a.also_cpu_seconds, 0.0, 0.0
+            a2.config, a2.cpu_seconds, a2.cpu_allcores_seconds, a2.cpu_reference_seconds = name, a.also_cpu_seconds, 0.0, 0.0
+            a2.min_seconds = a.also_match_min_seconds if name == "match100k" else a.also_min_seconds
             a2.batch = a2.ring = a2.width = a2.height = a2.nfeatures = None
             a2.region_timing = False
             a2.family = family
@@ -722,12 +832,17 @@ def main():
                 bad += int(r.get("_mismatches", 0))
             else:
                 bad += int(r["config"].get("parity_mismatches", 0))
-                also[key] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "timed_steps", "timed_seconds", "scaling", "dtype", "config",
-                                               "roofline", "roofline_pipeline", "roofline_valu", "stage_ms_per_step", "cpu_baseline", "per_rank") if k in r}
-        if rank == 0:
-            out["also"] = also
+                also[key] = r
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # full reports first (lines that do not start with "{"), the compact line LAST: it is the one JSON line of this run
+        print_detail("headline", out)
+        for key, r in also.items():
+            print_detail("also." + key, r)
+        line = json.dumps(compact_line(out, also))
+        if a.detail_file:
+            with open(a.detail_file, "w") as f:
+                json.dump(dict(out, also=also, line=json.loads(line)), f)
+        print(line, flush=True)
     if dist is not None:
         dist.destroy_process_group()
     if bad:                 # every rank: the mismatch counters were summed over the ranks

@@ -1,0 +1,58 @@
+"""The line the driver parses (bench.py's LAST stdout line) stays small: round 4's 23 KB line did not parse in the driver's record
+(VERDICT r04 #1).  Fed with a full report of the round-4 shape (profiles/r04_bench.json: headline + seven `also` reports) and with
+the same at eight ranks."""
+import copy
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _full():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    also = d.pop("also")
+    return d, also
+
+
+def test_compact_line_one_rank():
+    full, also = _full()
+    line = bench.compact_line(full, also)
+    text = json.dumps(line)
+    assert len(text) <= 4096, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "timed_steps", "timed_seconds", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "also_summary"):
+        assert k in line, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    for k in ("workload", "frames_per_step_per_gpu", "lanes", "parity_checked_frames", "parity_mismatches", "library_build_id"):
+        assert k in line["config"], k
+    assert line["value"] == full["value"] and line["roofline"]["frac"] == full["roofline"]["frac"]
+    assert set(line["also_summary"]) == set(also)
+    for k, v in also.items():
+        assert line["also_summary"][k]["value"] == v["value"]
+    assert not text.startswith(bench.DETAIL_PREFIX) and text.startswith("{")
+
+
+def test_compact_line_eight_ranks():
+    full, also = _full()
+    full["n_gpus"] = 8
+    full["per_rank"] = [dict(copy.deepcopy(full["per_rank"][0]), rank=r, device=r) for r in range(8)]
+    for v in also.values():
+        if v.get("per_rank"):
+            v["per_rank"] = [dict(v["per_rank"][0], rank=r) for r in range(8)]
+    text = json.dumps(bench.compact_line(full, also))
+    assert len(text) <= 6144, len(text)
+    line = json.loads(text)
+    assert len(line["per_rank"]["rows"]) == 8 and line["per_rank"]["columns"][0] == "rank"
+
+
+def test_match_report_compacts():
+    _, also = _full()
+    line = bench.compact_line(also["match100k"])
+    assert line["roofline"]["bound"] == "mfma" and "hbm" in line["roofline"] and line["roofline"]["traffic"] is None
+    assert len(json.dumps(line)) <= 4096

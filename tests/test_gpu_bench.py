@@ -16,9 +16,30 @@ def _bench(*args, timeout=600):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout
-    return json.loads(lines[0])
+    out = res.stdout.splitlines()
+    lines = [ln for ln in out if ln.startswith("{")]
+    assert len(lines) == 1 and out[-1] == lines[0], res.stdout[-3000:]           # ONE JSON line, and it is the last line of stdout
+    line = json.loads(lines[0])
+    # the driver's record keeps a bounded tail of stdout: the line must stay small (23 KB did not parse)
+    assert len(lines[0]) <= (4096 if line["n_gpus"] == 1 else 6144), len(lines[0])
+    for k in ("roofline", "config", "timed_steps", "timed_seconds"):
+        assert k in line, k
+    # the full reports travel in front of it as "#detail <name> <json>" lines; the tests read the headline's and hang the others under `also`
+    detail = {}
+    for ln in out:
+        if ln.startswith("#detail "):
+            _, name, body = ln.split(" ", 2)
+            detail[name] = json.loads(body)
+    d = detail["headline"]
+    assert d["value"] == line["value"] and d["ms_per_step"] == line["ms_per_step"] and d["config"]["workload"] == line["config"]["workload"]
+    assert line["roofline"]["frac"] == d["roofline"]["frac"] and line["roofline"]["bound"] == d["roofline"]["bound"]
+    d["also"] = {k[5:]: v for k, v in detail.items() if k.startswith("also.")}
+    d["line"] = line
+    if d["also"]:
+        assert set(line["also_summary"]) == set(d["also"])
+        for k, v in d["also"].items():
+            assert line["also_summary"][k]["value"] == v["value"] and line["also_summary"][k]["parity_mismatches"] == v["config"]["parity_mismatches"]
+    return d
 
 
 def _contract(d):
@@ -35,9 +56,13 @@ def _contract(d):
 def test_two_ranks_bare_command():
     """the N > 1 path of all three configurations of the default line: VGA stream per rank, 1080p stream per rank (BASELINE configs[3]),
     100k x 100k with the queries sharded by rank"""
+    import time
+    t0 = time.monotonic()
     d = _bench("--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "2", "--warmup", "1", "--batch", "64", "--ring", "128", "--min-seconds", "0",
-               "--also-min-seconds", "0", "--no-cpu-baseline", "--parity", "sample")
+               "--also-min-seconds", "0", "--also-match-min-seconds", "0", "--no-cpu-baseline")
+    assert time.monotonic() - t0 < 120.0                 # VERDICT r04 #7: the N > 1 default run is a short one (sampled parity, no family entries)
     _contract(d)
+    assert set(d["also"]) == {"hd1080", "match100k"} and "EVERY" not in d["config"]["parity_note"]      # sampled parity by default at N > 1
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and len(d["per_rank"]) == 2
     assert d["per_rank"][0]["frames"] == d["per_rank"][1]["frames"] == 2 * 64
     assert d["config"]["frames_with_error_status"] == 0 and d["config"]["mean_keypoints_per_frame"] > 900
@@ -53,9 +78,12 @@ def test_two_ranks_bare_command():
 def test_default_line_carries_every_baseline_config():
     """the command the driver runs, shortened: headline VGA keys unchanged, `also` holds hd1080 (BASELINE configs[2]) and match100k
     (configs[4]) with their own roofline and cpu_baseline; the parity leg ran on the timed shapes"""
-    d = _bench("--steps", "2", "--warmup", "1", "--min-seconds", "0.3", "--also-min-seconds", "0.2", "--cpu-seconds", "1", "--cpu-allcores-seconds", "0",
-               "--also-cpu-seconds", "1", "--cpu-reference-seconds", "1")
+    d = _bench("--steps", "2", "--warmup", "1", "--min-seconds", "0.3", "--also-min-seconds", "0.2", "--also-match-min-seconds", "0.2", "--cpu-seconds", "1",
+               "--cpu-allcores-seconds", "0", "--also-cpu-seconds", "1", "--cpu-reference-seconds", "1")
     _contract(d)
+    _contract(d["line"])
+    assert d["line"]["cpu_baseline"]["value"] == d["cpu_baseline"]["value"] and d["line"]["cpu_baseline"]["cores"] == 1
+    assert d["line"]["config"]["parity_checked_frames"] == 1024 and d["line"]["config"]["library_build_id"]
     assert "640x480" in d["metric"] and d["roofline"]["bound"] == "hbm" and d["roofline"]["kernel"] and "cpu_baseline" in d
     assert d["config"]["frames_per_step_per_gpu"] == 1024 and d["config"]["lanes"] == 4
     assert d["config"]["parity_mismatches"] == 0

@@ -11,11 +11,11 @@ tail -2 $D/pytest_quick.txt
 grep -q " passed" $D/pytest_quick.txt && ! grep -q "failed\|error" $D/pytest_quick.txt || { echo "GATE: parity tests failed"; exit 1; }
 S="--lanes 1 --steps 20 --warmup 3 --no-cpu-baseline --region-timing --min-seconds 0 --no-also --no-parity"
 for rep in 1 2; do
-  ORBX_LIB=$R/build_variants/base/liborbx.so timeout 200 python bench.py $S > $D/base_vga_$rep.json 2>/dev/null
-  timeout 200 python bench.py $S > $D/new_vga_$rep.json 2>/dev/null
+  ORBX_LIB=$R/build_variants/base/liborbx.so timeout 200 python bench.py $S --detail-file $D/base_vga_$rep.json > $D/base_vga_$rep.line.json 2>/dev/null
+  timeout 200 python bench.py $S --detail-file $D/new_vga_$rep.json > $D/new_vga_$rep.line.json 2>/dev/null
 done
-ORBX_LIB=$R/build_variants/base/liborbx.so timeout 200 python bench.py $S --config hd1080 > $D/base_hd.json 2>/dev/null
-timeout 200 python bench.py $S --config hd1080 > $D/new_hd.json 2>/dev/null
+ORBX_LIB=$R/build_variants/base/liborbx.so timeout 200 python bench.py $S --config hd1080 --detail-file $D/base_hd.json > $D/base_hd.line.json 2>/dev/null
+timeout 200 python bench.py $S --config hd1080 --detail-file $D/new_hd.json > $D/new_hd.line.json 2>/dev/null
 python - <<PY
 import json, sys
 def fast(n):
@@ -48,6 +48,6 @@ cp $R/profiles/traffic_hd1080.json $O/traffic_hd1080.json
 unset ORBX_OVERLAP
 (cd $R && python tools/valu_mix.py > $D/valu_mix.log 2>&1; cp profiles/valu_mix.json $D/valu_mix.json)
 cd $R
-timeout 400 python bench.py > $D/bench.json 2> $D/bench.err
+timeout 400 python bench.py --detail-file $D/bench.json > $D/bench.line.json 2> $D/bench.err
 python -c "import json; d=json.load(open('$D/bench.json')); print(d['value'], d['ms_per_step'], d['roofline'], d.get('roofline_valu')); print({k: (v['value'], v['roofline'].get('frac'), v['roofline'].get('traffic')) for k, v in d['also'].items()})"
 (time timeout 600 python -m pytest tests -m gpu -q) > $D/pytest_gpu.txt 2>&1; tail -4 $D/pytest_gpu.txt | head -2

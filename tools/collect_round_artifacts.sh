@@ -22,14 +22,14 @@ fi
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_overlap -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --min-seconds 0 --no-also --no-parity > $D/stats_overlap.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o stats_match -- python $R/bench.py --config match100k --steps 40 --warmup 5 --no-cpu-baseline --min-seconds 0 --no-parity > $D/stats_match.log 2>&1
 cd $R
-( time timeout 900 python bench.py > $D/bench.json 2> $D/bench.err ) 2> $D/bench_wall.txt          # the driver's command: headline + also{hd1080, match100k}, parity legs, CPU baselines
+( time timeout 900 python bench.py --detail-file $D/bench.json > $D/bench.line.json 2> $D/bench.err ) 2> $D/bench_wall.txt          # the driver's command: headline + also{hd1080, match100k}, parity legs, CPU baselines
 Q="--no-cpu-baseline --no-also --min-seconds 2"
-timeout 300 python bench.py --lanes 1 $Q > $D/bench_one_lane.json 2>/dev/null
-timeout 300 python bench.py --region-timing $Q > $D/bench_region_timing.json 2>/dev/null
-timeout 300 python bench.py --config vga_extract $Q > $D/bench_extract_only.json 2>/dev/null
-timeout 300 python bench.py --family 0 $Q > $D/bench_noise.json 2>/dev/null
-ORBX_MATCH_MFMA=0 timeout 300 python bench.py --config match100k --no-cpu-baseline --min-seconds 2 > $D/bench_match100k_popcount.json 2>/dev/null
-timeout 600 python bench.py --gpus 2 --backend gloo --share-device --no-cpu-baseline --batch 512 --min-seconds 2 --also-min-seconds 1 > $D/bench_two_ranks_one_gpu_gloo.json 2>/dev/null
+timeout 300 python bench.py --lanes 1 $Q --detail-file $D/bench_one_lane.json > $D/bench_one_lane.line.json 2>/dev/null
+timeout 300 python bench.py --region-timing $Q --detail-file $D/bench_region_timing.json > $D/bench_region_timing.line.json 2>/dev/null
+timeout 300 python bench.py --config vga_extract $Q --detail-file $D/bench_extract_only.json > $D/bench_extract_only.line.json 2>/dev/null
+timeout 300 python bench.py --family 0 $Q --detail-file $D/bench_noise.json > $D/bench_noise.line.json 2>/dev/null
+ORBX_MATCH_MFMA=0 timeout 300 python bench.py --config match100k --no-cpu-baseline --min-seconds 2 --detail-file $D/bench_match100k_popcount.json > $D/bench_match100k_popcount.line.json 2>/dev/null
+timeout 600 python bench.py --gpus 2 --backend gloo --share-device --no-cpu-baseline --batch 512 --min-seconds 2 --also-min-seconds 1 --detail-file $D/bench_two_ranks_one_gpu_gloo.json > $D/bench_two_ranks_one_gpu_gloo.line.json 2>/dev/null
 timeout 200 python tools/corun_probe.py > $D/corun_probe.json 2>/dev/null
 (timeout 100 python tools/bench_single_frame.py; timeout 100 python tools/bench_single_frame.py 1920 1080 2000; timeout 100 orb_slam_amd/cpp/bench_single_frame; timeout 100 orb_slam_amd/cpp/bench_single_frame 1920 1080 2000) > $D/single_frame.txt 2>/dev/null
 timeout 100 tools/microbench/valu_rate2 > $D/valu_issue_rates2.txt 2>&1

@@ -7,7 +7,7 @@ S="--lanes 1 --steps 10 --warmup 2 --no-cpu-baseline --region-timing --min-secon
 for item in $*; do
   v=${item%%:*}; rest=${item#*:}; f=${rest%%:*}; c=vga; [ "$rest" != "$f" ] && c=${rest#*:}
   lib=$R/build_variants/$v/liborbx.so; [ "$v" = tree ] && lib=$R/orb_slam_amd/liborbx.so
-  ORBX_LIB=$lib timeout 300 python bench.py $S --family $f --config $c > $D/${v}_f${f}_$c.json 2> $D/${v}_f${f}_$c.err
+  ORBX_LIB=$lib timeout 300 python bench.py $S --family $f --config $c --detail-file $D/${v}_f${f}_$c.json > $D/${v}_f${f}_$c.line.json 2> $D/${v}_f${f}_$c.err
   python - <<PY
 import json
 try:

@@ -16,5 +16,5 @@ synth.frames(640, 480, synth.BLOCKS, 0, 2048).tofile("/tmp/frames.raw")
 PY
 (orb_slam_amd/cpp/example_lanes 640 480 1024 2 4 /tmp/frames.raw "" 200; orb_slam_amd/cpp/example_lanes 640 480 1024 2 1 /tmp/frames.raw "" 200) > gpurun_out/$N/cpp_example_lanes.txt 2>&1; grep "frames/s\|IDENT" gpurun_out/$N/cpp_example_lanes.txt
 timeout 600 python tools/fuzz_batch.py 300 4102 > gpurun_out/$N/fuzz_batch_300.json 2>/dev/null; tail -c 200 gpurun_out/$N/fuzz_batch_300.json; timeout 600 python tools/fuzz_parity.py 3000 4101 > gpurun_out/$N/fuzz_parity_3000.json 2>/dev/null; tail -c 200 gpurun_out/$N/fuzz_parity_3000.json; timeout 600 python tools/fuzz_frontend.py 3000 1004 > gpurun_out/$N/fuzz_frontend_3000.json 2>/dev/null; tail -c 200 gpurun_out/$N/fuzz_frontend_3000.json
-timeout 900 python bench.py > gpurun_out/$N/bench_final.json 2> gpurun_out/$N/bench_final.err || tail -5 gpurun_out/$N/bench_final.err; python -c "
+timeout 900 python bench.py --detail-file gpurun_out/$N/bench_final.json > gpurun_out/$N/bench_final.stdout 2> gpurun_out/$N/bench_final.err || tail -5 gpurun_out/$N/bench_final.err; python -c "
 import json; d=json.load(open('gpurun_out/$N/bench_final.json')); print(d['value'], d['roofline']['frac'], d['roofline']['traffic'], d['config']['parity_mismatches'], {k:(v['value'], v['roofline'].get('frac'), v['roofline'].get('traffic'), v['config']['parity_mismatches']) for k,v in d['also'].items()})"

@@ -10,5 +10,5 @@ timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INS
 python $R/tools/pmc_traffic.py $O/fetch_counter_collection.csv $O/write_counter_collection.csv $R/profiles/traffic_hd1080.json 256 $O 32 hd_1920x1080_nf2000 > $O/traffic.log 2>&1
 cp $R/profiles/traffic_hd1080.json $O/traffic_hd1080.json
 (cd $R && python tools/valu_mix.py > $O/valu_mix.log 2>&1; cp profiles/valu_mix.json $O/valu_mix.json)
-cd $R; timeout 400 python bench.py --config hd1080 --cpu-allcores-seconds 0 > $O/bench_hd.json 2> $O/bench_hd.err
+cd $R; timeout 400 python bench.py --config hd1080 --cpu-allcores-seconds 0 --detail-file $O/bench_hd.json > $O/bench_hd.line.json 2> $O/bench_hd.err
 python -c "import json; d=json.loads(open('$O/bench_hd.json').read().strip().splitlines()[-1]); print(d['value'], d['roofline'])"

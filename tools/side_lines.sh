@@ -4,11 +4,11 @@
 # usage: tools/side_lines.sh <name>   (-> gpurun_out/<name>/)
 N=${1:?name}; R=${GRAFT_REPO_ROOT:-/root/repo}; D=$R/gpurun_out/$N; mkdir -p $D; cd $R
 Q="--no-cpu-baseline --no-also --min-seconds 2"
-timeout 200 python bench.py --config hd1080 --cpu-allcores-seconds 0 --cpu-seconds 5 > $D/bench_hd1080.json 2>/dev/null
-timeout 100 python bench.py --lanes 1 $Q > $D/bench_one_lane.json 2>/dev/null
-timeout 100 python bench.py --config vga_extract $Q > $D/bench_extract_only.json 2>/dev/null
-timeout 100 python bench.py --region-timing $Q > $D/bench_region_timing.json 2>/dev/null
-timeout 100 python bench.py --family 0 $Q > $D/bench_noise.json 2>/dev/null
+timeout 200 python bench.py --config hd1080 --cpu-allcores-seconds 0 --cpu-seconds 5 --detail-file $D/bench_hd1080.json > $D/bench_hd1080.line.json 2>/dev/null
+timeout 100 python bench.py --lanes 1 $Q --detail-file $D/bench_one_lane.json > $D/bench_one_lane.line.json 2>/dev/null
+timeout 100 python bench.py --config vga_extract $Q --detail-file $D/bench_extract_only.json > $D/bench_extract_only.line.json 2>/dev/null
+timeout 100 python bench.py --region-timing $Q --detail-file $D/bench_region_timing.json > $D/bench_region_timing.line.json 2>/dev/null
+timeout 100 python bench.py --family 0 $Q --detail-file $D/bench_noise.json > $D/bench_noise.line.json 2>/dev/null
 tools/run_pmc_clock.sh ${N}_clock > /dev/null 2>&1; cp gpurun_out/${N}_clock/pmc_clock.txt $D/pmc_clock.txt
 tools/run_pmc_match.sh ${N}_mfma > /dev/null 2>&1; cp gpurun_out/${N}_mfma/pmc_mfma.txt $D/pmc_mfma.txt
 (cd /tmp; export TMPDIR=/tmp
@@ -27,7 +27,7 @@ PY
 timeout 100 python tools/bench_pcie.py --steps 30 > $D/pcie_inclusive.json 2>/dev/null
 timeout 200 python tools/bench_frontend.py --window 15 2>/dev/null | tail -1 > $D/frontend_w15.json
 timeout 200 python tools/bench_frontend.py 2>/dev/null | tail -1 > $D/frontend_w100.json
-ORBX_MATCH_MFMA=0 timeout 100 python bench.py --config match100k --no-cpu-baseline --min-seconds 2 > $D/bench_match100k_popcount.json 2>/dev/null
+ORBX_MATCH_MFMA=0 timeout 100 python bench.py --config match100k --no-cpu-baseline --min-seconds 2 --detail-file $D/bench_match100k_popcount.json > $D/bench_match100k_popcount.line.json 2>/dev/null
 timeout 100 python tools/corun_probe.py > $D/corun_probe.json 2>/dev/null
 timeout 100 python tools/bench_kf_search.py 2>/dev/null | tail -1 > $D/kf_search.json
 ls $D | wc -l
