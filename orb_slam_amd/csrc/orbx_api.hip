@@ -29,6 +29,8 @@ struct orbx_extractor {
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;
     Cand *d_cand = nullptr, *d_sel = nullptr;
     CellState* d_cstate = nullptr;
+    int32_t* d_band_hint[2] = {nullptr, nullptr};
+    int hint_parity = 0;
     CellSel* d_csel = nullptr;
     int32_t *d_level_total = nullptr, *d_level_count = nullptr, *d_status = nullptr, *d_long_cells = nullptr;
     // single-frame staging for orbx_extract
@@ -82,7 +84,7 @@ static void dev_free(T*& p) {
 static void free_geometry(orbx_extractor* h) {
     dev_free(h->d_cells); dev_free(h->d_bands); dev_free(h->d_tabx); dev_free(h->d_taby); dev_free(h->d_pyr_tab);
     dev_free(h->d_pyr); dev_free(h->d_blur);
-    dev_free(h->d_cand); dev_free(h->d_sel); dev_free(h->d_cstate); dev_free(h->d_csel);
+    dev_free(h->d_cand); dev_free(h->d_sel); dev_free(h->d_cstate); dev_free(h->d_band_hint[0]); dev_free(h->d_band_hint[1]); dev_free(h->d_csel);
     dev_free(h->d_level_total); dev_free(h->d_level_count); dev_free(h->d_status); dev_free(h->d_long_cells);
     h->gw = h->gh = 0;
     h->have_last = false;
@@ -116,6 +118,10 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
     HIPCHK(h, hipMalloc(&h->d_cand, B * std::max(g.frame_cands, 1) * sizeof(Cand)));
     HIPCHK(h, hipMalloc(&h->d_sel, B * std::max(g.frame_sel, 1) * sizeof(Cand)));
     HIPCHK(h, hipMalloc(&h->d_cstate, B * g.nbands_total * sizeof(CellState)));
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(h, hipMalloc(&h->d_band_hint[k], (size_t)(g.nbands_total + 16) * sizeof(int32_t)));
+        HIPCHK(h, hipMemset(h->d_band_hint[k], 0, (size_t)(g.nbands_total + 16) * sizeof(int32_t)));
+    }
     HIPCHK(h, hipMalloc(&h->d_csel, B * g.ncells_total * sizeof(CellSel)));
     HIPCHK(h, hipMalloc(&h->d_level_total, B * MAX_LEVELS * sizeof(int32_t)));
     HIPCHK(h, hipMalloc(&h->d_level_count, B * MAX_LEVELS * sizeof(int32_t)));
@@ -225,19 +231,19 @@ int orbx_extract_batch_device_phases(orbx_extractor* h, const uint8_t* d_imgs, i
         return ORBX_ERR_ARG;
     }
     if (phases != ORBX_PHASE_ALL && nframes > h->p.max_batch) { h->err = "a phased call covers one launch group: nframes <= max_batch"; return ORBX_ERR_ARG; }
+    // a part may only follow the parts in front of it, queued for the SAME batch (same arguments, same stream): the detection reads the
+    // pyramid of this batch from the handle's scratch, the description reads its selections and blurred planes.  Repeating a part is fine.
+    // The bookkeeping is committed only when the call has queued its launches (a failed PYRAMID call must not let a DETECT pass the check).
+    const orbx_extractor::PhaseKey key = {d_imgs, d_kps, d_desc, d_n, stream_, nframes, w, hgt, cap, row_stride, frame_stride};
     {
-        // a part may only follow the parts in front of it, queued for the SAME batch (same arguments, same stream): the detection reads the
-        // pyramid of this batch from the handle's scratch, the description reads its selections and blurred planes.  Repeating a part is fine.
-        const orbx_extractor::PhaseKey key = {d_imgs, d_kps, d_desc, d_n, stream_, nframes, w, hgt, cap, row_stride, frame_stride};
         const int first = phases & -phases;                       // lowest part of this call
         const int before = first - 1;                             // every part in front of it
         if (!(phases & ORBX_PHASE_PYRAMID) && (!(key == h->ph_key) || (h->ph_done & before) != before)) {
             h->err = "phase queued out of order: the parts in front of it were not queued for this batch (same arguments, same stream)";
             return ORBX_ERR_ARG;
         }
-        if (phases & ORBX_PHASE_PYRAMID) { h->ph_key = key; h->ph_done = 0; }
-        h->ph_done |= phases;
     }
+    if (phases & ORBX_PHASE_PYRAMID) h->ph_done = 0;              // a new batch starts: whatever was queued before no longer counts
     HIPCHK(h, hipSetDevice(h->p.device));
     int rc = ensure_geometry(h, w, hgt);
     if (rc != ORBX_OK) return rc;
@@ -247,6 +253,9 @@ int orbx_extract_batch_device_phases(orbx_extractor* h, const uint8_t* d_imgs, i
         Batch b;
         memset(&b, 0, sizeof(b));
         fill_batch(h, b);
+        b.band_hint_in = h->d_band_hint[h->hint_parity];
+        b.band_hint_out = h->d_band_hint[h->hint_parity ^ 1];
+        if (phases & ORBX_PHASE_DETECT) h->hint_parity ^= 1;
         b.nframes = std::min(h->p.max_batch, nframes - f0);
         b.xcd_affinity = (b.nframes >= XCD_AFFINITY_MIN_FRAMES && !h->no_xcd_affinity) ? 1 : 0;
         b.img = d_imgs + (ptrdiff_t)f0 * frame_stride;
@@ -262,6 +271,8 @@ int orbx_extract_batch_device_phases(orbx_extractor* h, const uint8_t* d_imgs, i
         h->last = b;
         h->have_last = true;
     }
+    if (phases & ORBX_PHASE_PYRAMID) h->ph_key = key;
+    h->ph_done |= phases;
     return ORBX_OK;
 }
 
@@ -404,7 +415,7 @@ long orbx_debug_fetch(orbx_extractor* h, int what, int frame, int level, void* h
             int32_t* o = (int32_t*)host_out + 8 * n++;
             o[0] = bgm.x0; o[1] = bgm.x1; o[2] = bgm.y0; o[3] = bgm.y1;
             o[4] = st[it].n_all; o[5] = st[it].n_hi; o[6] = st[it].n_lo;
-            o[7] = (ORBX_FAST_TWO_PASS && g.fast_th > 7 && st[it].n_hi > 3) ? g.fast_th : std::min(g.fast_th, 7);
+            o[7] = st[it].thr;          // the threshold the band's list was made at (fastTh; 7 after the second pass or on the fallback hint)
         }
         return n * 32;
     }

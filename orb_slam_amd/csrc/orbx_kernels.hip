@@ -458,6 +458,7 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     constexpr int WQ_BYTES = fast_wave_queue_bytes(PPT);
     const DevGeom& g = b.g;
     const BandGeom bg = b.bands[item];
+    const int hint = b.band_hint_in[item];
     const int level = bg.level;
     const LevelGeom& L = g.lv[level];
     // Wave roles rotate with the band index.  The tails of the task are wave-0 heavy (a VGA cell's survivor list is <= 70 chunks: wave 0
@@ -467,7 +468,7 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     const int cw = bg.x1 - bg.x0 + 1, ch = bg.ey1 - bg.ey0 + 1;      // scored rectangle: own rows + halo rows towards sibling bands
     CellState* cst = b.cstate + (long long)frame * g.nbands_total + item;
     if (cw <= 0 || ch <= 0) {
-        if (tid == 0) { CellState st; st.n_all = 0; st.n_hi = 0; st.n_lo = 0; *cst = st; }
+        if (tid == 0) { CellState st; st.n_all = 0; st.n_hi = 0; st.n_lo = 0; st.thr = g.tmin; *cst = st; if (frame == 0) b.band_hint_out[item] = 0; }
         return;
     }
     const int own_lo = bg.y0 - bg.ey0, own_hi = bg.y1 - bg.ey0;
@@ -557,7 +558,11 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     // list at fastTh is all the later stages read.  Only a band with <= 3 survivors@fastTh is scored again at 7 (below).  On textured
     // input (corners@7 several times corners@fastTh) the pair test, score, NMS and list phases shrink by that factor; on the S-blocks
     // stream 3 % of the bands take the second pass.  fastTh <= 7: one pass at fastTh serves both (g.tmin = fastTh).
-    int tmin = ORBX_FAST_TWO_PASS ? g.fast_th : g.tmin;
+    // Fallback hint (round 5; Batch::band_hint_in): a band that needed the second pass in FAST_HINT_RUN launch groups in a row starts at 7
+    // (low-texture streams: every band would otherwise run twice, S-lowtex +35 % on this kernel).  A wrong hint costs one pass at 7
+    // instead of one at fastTh, never a wrong result: CellState::thr tells the later stages what the list was made at.
+    constexpr int FAST_HINT_RUN = 6;
+    int tmin = ORBX_FAST_TWO_PASS ? (hint >= FAST_HINT_RUN && g.fast_th > 7 ? 7 : g.fast_th) : g.tmin;
     const float inv_nd = bg.inv_nd;                // (1 / nd, 1 / S, 1 / cpr come with the band: BandGeom)
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;          // fill of this wave's queues (wave-uniform)
 
@@ -773,8 +778,9 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     }
     if (tid == 0) {
         CellState st;
-        st.n_all = run_base; st.n_hi = hdr->n_hi; st.n_lo = hdr->n_lo;
+        st.n_all = run_base; st.n_hi = hdr->n_hi; st.n_lo = hdr->n_lo; st.thr = tmin;
         *cst = st;
+        if (frame == 0) b.band_hint_out[item] = st.n_hi <= 3 && g.fast_th > 7 ? imin(hint + 1, FAST_HINT_RUN) : 0;
     }
 }
 
@@ -1066,26 +1072,59 @@ __global__ __launch_bounds__(256) void k_cell_select(Batch b, int lds_entries) {
     if (lane == 0) b.long_cells[id] = done ? 0 : 1;          // a flag per cell: no list, no atomics (one counter for ~150 k long cells of a
 }                                                            // noise-like batch serialised for 1.3 ms, 64 sharded ones still for 0.5)
 
-// the cells k_cell_select left over (lists beyond its staging area): a wave looks at the flags of SEL_LONG_CHUNK consecutive cells
-// and takes the flagged ones with the full staging area.  Normally none is flagged and the launch is ~10 k workgroups that exit.
+// The cells k_cell_select left over (lists beyond its staging area).  A workgroup of four waves looks at the flags of SEL_LONG_CHUNK
+// consecutive cells and shares ONE full staging area (sel_lds_entries entries) by list length: lists that fit a quarter of it are taken
+// four at a time (one wave each), lists that fit half of it two at a time, the rest one at a time with all of it.  A wave's selection
+// is latency-bound (~20 us per cell whatever its length: ten partition passes of a few dependent LDS round trips each), so what counts
+// is the number of cells in flight per CU, and that is set by the LDS a cell holds.  (Rounds 2-4: one-wave workgroups with the full area
+// each, six cells per CU.  S-lowtex lists 440-480 corners per level-0 cell, S-noise 910 / 570 / 520 on levels 0 / 1 / 2: 0.42 and 1.1 ms
+// per 1024 frames.  Round 5 first tried the opposite, four waves on ONE list — block-wide stopper scans, three barriers per pass — and
+// lost: 1.37 -> 1.67 ms on S-noise, the passes over short ranges dominate and stay serial.)  Normally no cell is flagged and the launch
+// is a few thousand workgroups that exit.
 #ifndef ORBX_SEL_LONG_CHUNK
 #define ORBX_SEL_LONG_CHUNK 8
 #endif
-constexpr int SEL_LONG_CHUNK = ORBX_SEL_LONG_CHUNK;
-__global__ __launch_bounds__(64) void k_cell_select_long(Batch b) {
+constexpr int SEL_LONG_CHUNK = ORBX_SEL_LONG_CHUNK, SEL_LONG_WAVES = 4;
+__host__ __device__ constexpr int sel_long_bytes(int entries) {      // the shared area: four quarter areas, two half areas or one full one
+    const int a = 4 * sel_wave_bytes((entries + 3) / 4), c = 2 * sel_wave_bytes((entries + 1) / 2), d = sel_wave_bytes(entries);
+    return a > c ? (a > d ? a : d) : (c > d ? c : d);
+}
+__global__ __launch_bounds__(SEL_LONG_WAVES * 64) void k_cell_select_long(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const DevGeom& g = b.g;
-    const int lane = (int)threadIdx.x, total = b.nframes * g.ncells_total;
+    const int lane = (int)threadIdx.x & 63, wave = wave_id(), total = b.nframes * g.ncells_total;
     const int id0 = (int)blockIdx.x * SEL_LONG_CHUNK;
+    static_assert(SEL_LONG_CHUNK <= 64, "one flag per lane");
+    const int quarter = (g.sel_lds_entries + 3) / 4, half = (g.sel_lds_entries + 1) / 2;
+    // every wave reads the same flags and list lengths (lane i: cell id0 + i)
+    int n_all = 0;
     const bool mine = lane < SEL_LONG_CHUNK && id0 + lane < total && b.long_cells[id0 + lane] != 0;
-    unsigned long long m = __ballot(mine);
-    while (m) {
-        const int id = id0 + __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int frame = id / g.ncells_total, cell = id - frame * g.ncells_total;
-        (void)cell_select_body(b, frame, cell, find_level(g.cell_bases, cell), smem, g.sel_lds_entries, 0, lane);
-        wave_lds_fence();
+    if (mine) {
+        const int id = id0 + lane, frame = id / g.ncells_total, cell = id - frame * g.ncells_total;
+        const CellGeom cgeo = b.cells[cell];
+        const CellState* bst = b.cstate + (long long)frame * g.nbands_total + cgeo.band0;
+        for (int k = 0; k < cgeo.nbands; k++) n_all += bst[k].n_all;
     }
+    const unsigned long long mQ = __ballot(mine && n_all <= quarter), mH = __ballot(mine && n_all > quarter && n_all <= half),
+                             mF = __ballot(mine && n_all > half);
+    if (!(mQ | mH | mF)) return;
+    auto run = [&](unsigned long long m, int share, int entries) {       // class m: wave w takes the cells of rank w, w + share, ... in its own part of the area
+        if (wave >= share) return;
+        uint8_t* area = smem + wave * sel_wave_bytes(entries);
+        for (int r = 0; m; r++) {
+            const int id = id0 + __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (r % share != wave) continue;
+            const int frame = id / g.ncells_total, cell = id - frame * g.ncells_total;
+            (void)cell_select_body(b, frame, cell, find_level(g.cell_bases, cell), area, entries, 0, lane);
+            wave_lds_fence();
+        }
+    };
+    run(mQ, 4, quarter);
+    if (mH | mF) __syncthreads();             // the parts change owners
+    run(mH, 2, half);
+    if (mF) __syncthreads();
+    run(mF, 1, g.sel_lds_entries);
 }
 
 // reference :697-701 (per-level cap), same scheme; one wave
@@ -1412,7 +1451,9 @@ __global__ __launch_bounds__(MB_WAVES * 64) void k_blur_mfma(Batch b) {      // 
     for (int n = 0; n < 3; n++) {
         const int q = 64 * n + lane, r = (q * 171) >> 10;        // q / 6 for q < 192
         const int ca = (X0 >> 4) - 1 + (q - 6 * r);              // absolute chunk of the row; chunks outside it are clamped (no tap reaches them)
-        dma_c[n] = 16 * min(max(ca, 0), (int)(sstride >> 4) - 1);
+        // level 0 is the caller's frame: only min(row_stride, w rounded up to 16) bytes of a row are promised readable (include/orbx.h), so the
+        // clamp stops there (with the clamp at row_stride an ROI at the right edge of a wider image was read past its last row)
+        dma_c[n] = 16 * min(max(ca, 0), min((int)(sstride >> 4), (w + 15) >> 4) - 1);
     }
     auto dma_tile = [&](int R, uint8_t* ibuf) {                  // rows R .. R + 31 (reflect-101; rows no tap reaches are clamped into the level)
 #pragma unroll
@@ -2009,9 +2050,9 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
         hipLaunchKernelGGL(k_cell_select, dim3((F * g.ncells_total + 3) / 4), dim3(256), lds, stream, b, small);
         ORBX_LAUNCH_CHECK();
         if (small < g.sel_lds_entries) {
-            const size_t ldsl = (size_t)sel_wave_bytes(g.sel_lds_entries);
+            const size_t ldsl = (size_t)sel_long_bytes(g.sel_lds_entries);
             if (ldsl > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cell_select_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsl) != hipSuccess) return ORBX_ERR_DEVICE;
-            hipLaunchKernelGGL(k_cell_select_long, dim3((F * g.ncells_total + SEL_LONG_CHUNK - 1) / SEL_LONG_CHUNK), dim3(64), ldsl, stream, b);
+            hipLaunchKernelGGL(k_cell_select_long, dim3((F * g.ncells_total + SEL_LONG_CHUNK - 1) / SEL_LONG_CHUNK), dim3(SEL_LONG_WAVES * 64), ldsl, stream, b);
             ORBX_LAUNCH_CHECK();
         }
     }

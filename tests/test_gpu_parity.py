@@ -43,6 +43,45 @@ def test_device_math_matches_host(gpu_extractor_factory):
         assert np.float32(rc.value).view(np.uint32) == c[i].view(np.uint32), (i, ang[i])
 
 
+def _check_band_lists(o, nl, band_tabs, nms_planes, hinted=False):
+    """every FAST work item (row band of a grid cell) against cv::FAST of its cell view at the threshold the band reports: survivors of
+    its rows, counters, and the rebuilt NMS map.  hinted=False: the threshold must be fastTh = 20 when the band keeps more than 3
+    survivors@20, else 7; hinted=True (a handle whose fallback hint is set): 7 is also legal for a band with more than 3."""
+    seen_hinted = 0
+    for l in range(nl):
+        plane = o.level_plane(l, 0)
+        ref = np.zeros_like(plane)
+        bands = band_tabs[l]
+        seen = 0
+        for info, _ in o.cells():
+            if info[0] != l:
+                continue
+            ix, iy, cw, ch = info[3], info[4], info[6], info[7]
+            view = plane[iy:iy + ch, ix:ix + cw]
+            by_thr = {t: orc.fast(view, t) for t in (7, 20)}
+            mine = bands[(bands[:, 0] == ix + 3) & (bands[:, 1] == ix + cw - 4) & (bands[:, 2] >= iy + 3) & (bands[:, 3] <= iy + ch - 4)]
+            assert len(mine) and mine[:, 2].min() == iy + 3 and mine[:, 3].max() == iy + ch - 4, (l, info, mine)      # the bands tile the scored rows
+            seen += len(mine)
+            for x0, x1, y0, y1, n_all, n_hi, n_lo, thr in mine:
+                at20 = by_thr[20]
+                in20 = (at20["y"] + iy >= y0) & (at20["y"] + iy <= y1)
+                want_thr = 20 if in20.sum() > 3 else 7
+                if hinted and thr == 7 and want_thr == 20:
+                    seen_hinted += 1
+                else:
+                    assert thr == want_thr, (l, info, (x0, x1, y0, y1), thr, int(in20.sum()))
+                kp = by_thr[thr]
+                kp = kp[(kp["y"] + iy >= y0) & (kp["y"] + iy <= y1)]
+                assert n_all == len(kp) and n_hi == int((kp["response"] >= 20).sum()) and n_lo == int((kp["response"] >= 7).sum()), (l, info, n_all, n_hi, n_lo, len(kp))
+                ref[iy + kp["y"].astype(int), ix + kp["x"].astype(int)] = kp["response"].astype(np.uint8)
+        assert seen == len(bands)
+        got = nms_planes[l]
+        bad = np.argwhere(got != ref)
+        assert bad.size == 0, "nms level %d: %d pixels differ, first %s gpu=%d ref=%d" % (
+            l, len(bad), bad[0], got[tuple(bad[0])], ref[tuple(bad[0])])
+    return seen_hinted
+
+
 @pytest.mark.parametrize("family", FAMILIES, ids=lambda f: FAMNAME[f])
 def test_stage_parity_vga(gpu_extractor_factory, family):
     img = synth.frame(640, 480, family, 3)
@@ -68,34 +107,7 @@ def test_stage_parity_vga(gpu_extractor_factory, family):
     band_tabs = [ex.fetch_bands(l) for l in range(nl)]
     ex.set_stop_after(-1)
     gk, gd = ex(img)
-    for l in range(nl):
-        plane = o.level_plane(l, 0)
-        ref = np.zeros_like(plane)
-        bands = band_tabs[l]
-        seen = 0
-        for info, _ in o.cells():
-            if info[0] != l:
-                continue
-            ix, iy, cw, ch = info[3], info[4], info[6], info[7]
-            view = plane[iy:iy + ch, ix:ix + cw]
-            by_thr = {t: orc.fast(view, t) for t in (7, 20)}
-            mine = bands[(bands[:, 0] == ix + 3) & (bands[:, 1] == ix + cw - 4) & (bands[:, 2] >= iy + 3) & (bands[:, 3] <= iy + ch - 4)]
-            assert len(mine) and mine[:, 2].min() == iy + 3 and mine[:, 3].max() == iy + ch - 4, (l, info, mine)      # the bands tile the scored rows
-            seen += len(mine)
-            for x0, x1, y0, y1, n_all, n_hi, n_lo, thr in mine:
-                at20 = by_thr[20]
-                in20 = (at20["y"] + iy >= y0) & (at20["y"] + iy <= y1)
-                want_thr = 20 if in20.sum() > 3 else 7
-                assert thr == want_thr, (l, info, (x0, x1, y0, y1), thr, int(in20.sum()))
-                kp = by_thr[thr]
-                kp = kp[(kp["y"] + iy >= y0) & (kp["y"] + iy <= y1)]
-                assert n_all == len(kp) and n_hi == int((kp["response"] >= 20).sum()) and n_lo == int((kp["response"] >= 7).sum()), (l, info, n_all, n_hi, n_lo, len(kp))
-                ref[iy + kp["y"].astype(int), ix + kp["x"].astype(int)] = kp["response"].astype(np.uint8)
-        assert seen == len(bands)
-        got = nms_planes[l]
-        bad = np.argwhere(got != ref)
-        assert bad.size == 0, "nms level %d: %d pixels differ, first %s gpu=%d ref=%d" % (
-            l, len(bad), bad[0], got[tuple(bad[0])], ref[tuple(bad[0])])
+    _check_band_lists(o, nl, band_tabs, nms_planes)
     # per-level selection (order matters)
     for l in range(nl):
         xy, resp = ex.fetch_level_keypoints(l)
@@ -106,6 +118,42 @@ def test_stage_parity_vga(gpu_extractor_factory, family):
         np.testing.assert_array_equal(resp.view(np.uint32), ref["response"].view(np.uint32), err_msg="level %d response" % l)
     _assert_kps_equal(gk, ok)
     np.testing.assert_array_equal(gd, od)
+
+
+def test_fallback_hint_changes_the_pass_not_the_result(gpu_extractor_factory):
+    """Round 5: a band that ended with <= 3 survivors@fastTh in 6 launch groups in a row starts at threshold 7 (Batch::band_hint_in) instead
+    of scoring at fastTh first and again at 7 (src/ORBextractor.cc:609-614 decides per cell either way).  The hint may be wrong — a
+    textured frame arriving on a handle that saw low-texture frames — and then the band's list is made at 7 although it holds more
+    than 3 survivors@20: the band reports thr = 7, its list and counters are cv::FAST's at 7, and the outputs do not change."""
+    low, blk = synth.frame(640, 480, synth.LOWTEX, 5), synth.frame(640, 480, synth.BLOCKS, 6)
+    o_low, o_blk = orc.OracleExtractor(dumps=True), orc.OracleExtractor(dumps=True)
+    (lk, ld), (bk, bd) = o_low(low), o_blk(blk)
+    ex = gpu_extractor_factory()
+    for _ in range(8):                                   # every band of the low-texture frame falls back: the hint saturates
+        gk, gd = ex(low)
+        _assert_kps_equal(gk, lk)
+        np.testing.assert_array_equal(gd, ld)
+    gk, gd = ex(blk)                                     # the hinted pass on a textured frame
+    _assert_kps_equal(gk, bk)
+    np.testing.assert_array_equal(gd, bd)
+    gk, gd = ex(blk)                                     # ... which reset the hint of the bands that kept more than 3
+    _assert_kps_equal(gk, bk)
+    np.testing.assert_array_equal(gd, bd)
+    for _ in range(8):
+        ex(low)
+    ex.set_stop_after(capi.ST_FAST_CELLS)
+    ex(low)
+    tabs = [ex.fetch_bands(l) for l in range(8)]
+    assert all((t[:, 7] == 7).all() for t in tabs)       # one pass at 7 everywhere
+    _check_band_lists(o_low, 8, tabs, [ex.fetch_plane(capi.DBG_NMS, l) for l in range(8)], hinted=True)
+    ex(blk)
+    tabs = [ex.fetch_bands(l) for l in range(8)]
+    hinted = _check_band_lists(o_blk, 8, tabs, [ex.fetch_plane(capi.DBG_NMS, l) for l in range(8)], hinted=True)
+    assert hinted > 100                                  # most bands of the textured frame were listed at 7 with more than 3 survivors@20
+    ex(blk)
+    tabs = [ex.fetch_bands(l) for l in range(8)]
+    assert _check_band_lists(o_blk, 8, tabs, [ex.fetch_plane(capi.DBG_NMS, l) for l in range(8)], hinted=True) == 0      # and the hint is gone
+    ex.set_stop_after(-1)
 
 
 @pytest.mark.parametrize("cfg", [
