@@ -895,11 +895,109 @@ struct RespGreater {   // KeypointResponseGreater (OpenCV keypoint.cpp)
 
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
-__device__ void wave_nth_element(Cand* a, int first, int nth, int last, uint16_t* lpos, uint16_t* rpos, int lane) {
+__device__ __forceinline__ int mask_rank(unsigned long long m) {     // number of set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+__device__ __forceinline__ float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
+// Ranges of at most 64 entries are finished IN REGISTERS (round 5): lane i holds entry first + i, and a partition pass is a few ballots
+// and two hops through the LDS crossbar instead of ~25 dependent LDS round trips (most passes of any list, and every pass of the 20- to
+// 40-entry lists of an ordinary cell, are over such ranges; a wave's selection is a chain of latencies, ~1 us per LDS pass).
+//   pivot      __move_median_to_first reads three entries (v_readlane at wave-uniform lanes) and swaps two lanes;
+//   stoppers   the ballots mL (entry <= pivot) and mR (entry >= pivot) over the lanes (f, l).  Swap k of the Hoare partition exchanges the
+//              k-th left stopper from below with the k-th right stopper from above while the former lies below the latter: a left
+//              stopper with kL left stoppers below it and aR right stoppers above it is swapped iff aR > kL, a right stopper (rank kR
+//              = aR from the top) iff more than kR left stoppers lie below it — no lists, two mbcnt per lane; S = popcount of either;
+//   swaps      left swappers push (pos, resp, lane) to lane kL, right ones to lane 32 + kR (ds_permute; S <= 31), partners look at each
+//              other's origin (ds_bpermute lane ^ 32) and push the entries on to it;
+//   cut        position of the left stopper of rank S / the right stopper of rank S - 1 (ballot + ffs), as in the LDS form;
+//   <= 3 left  __insertion_sort of at most three entries = their stable descending order: ranks from three readlanes.
+// The depth-limit fallback writes the window back and calls libstdc++'s heap select on lane 0 like the LDS form.
+__device__ __forceinline__ void wave_nth_small(Cand* a, int first, int nth, int last, int depth, int lane) {
+    const int n = last - first;                        // 4 .. 64
+    uint32_t pos = 0;
+    float resp = 0.f;
+    if (lane < n) { const Cand e = a[first + lane]; pos = e.pos; resp = e.resp; }
+    int f = 0, l = n;
+    const int k = nth - first;
+    bool heap = false;
+    while (l - f > 3) {
+        if (depth == 0) { heap = true; break; }
+        --depth;
+        const int mid = f + (l - f) / 2;
+        const float ra = readlane_f(resp, f + 1), rb = readlane_f(resp, mid), rc = readlane_f(resp, l - 1);
+        // std::__move_median_to_first(result = f, a = f + 1, b = mid, c = l - 1) with comp = greater
+        int sl;
+        if (ra > rb) sl = rb > rc ? mid : (ra > rc ? l - 1 : f + 1);
+        else sl = ra > rc ? f + 1 : (rb > rc ? l - 1 : mid);
+        {
+            const uint32_t pf = (uint32_t)__builtin_amdgcn_readlane((int)pos, f), ps = (uint32_t)__builtin_amdgcn_readlane((int)pos, sl);
+            const float rf = readlane_f(resp, f), rs = readlane_f(resp, sl);
+            if (lane == f) { pos = ps; resp = rs; }
+            if (lane == sl) { pos = pf; resp = rf; }
+        }
+        const float P = readlane_f(resp, f);
+        const bool inr = lane > f && lane < l;
+        const bool stL = inr && !(resp > P), stR = inr && !(P > resp);
+        const unsigned long long mL = __ballot(stL), mR = __ballot(stR);
+        const int nL = __popcll(mL), nR = __popcll(mR);
+        const int kL = mask_rank(mL);                                  // left stoppers below this lane
+        const int aR = nR - mask_rank(mR) - (stR ? 1 : 0);             // right stoppers above this lane
+        const bool doL = stL && aR > kL, doR = stR && kL > aR;
+        const int S = __popcll(__ballot(doL));
+        int cut;
+        {
+            const unsigned long long cl = __ballot(stL && kL == S), cr = __ballot(stR && aR == S - 1);
+            if (S < nL) { cut = __ffsll((long long)cl) - 1; if (S > 0) { const int r = __ffsll((long long)cr) - 1; if (r < cut) cut = r; } }
+            else cut = __ffsll((long long)cr) - 1;
+        }
+        if (S > 0) {
+            const int d1 = 4 * (doL ? kL : (doR ? 32 + aR : 63));      // (lane 63 is no rank lane: S <= 31)
+            const uint32_t h_pos = (uint32_t)__builtin_amdgcn_ds_permute(d1, (int)pos);
+            const float h_resp = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(d1, __builtin_bit_cast(int, resp)));
+            const int h_src = __builtin_amdgcn_ds_permute(d1, lane);
+            const int partner = __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), h_src);
+            const bool holder = (lane & 31) < S;
+            const int d2 = 4 * (holder ? partner : f);                 // (lane f holds the pivot: never a swap position)
+            const uint32_t n_pos = (uint32_t)__builtin_amdgcn_ds_permute(d2, (int)h_pos);
+            const float n_resp = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(d2, __builtin_bit_cast(int, h_resp)));
+            if (doL || doR) { pos = n_pos; resp = n_resp; }
+        }
+        if (cut <= k) f = cut; else l = cut;
+    }
+    if (!heap && l - f >= 2) {
+        // std::__insertion_sort of the 2 or 3 entries left = their stable order by descending response
+        const int m = l - f;
+        const float r0 = readlane_f(resp, f), r1 = readlane_f(resp, f + 1), r2 = readlane_f(resp, m == 3 ? f + 2 : f);
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)pos, f), p1 = (uint32_t)__builtin_amdgcn_readlane((int)pos, f + 1),
+                       p2 = (uint32_t)__builtin_amdgcn_readlane((int)pos, m == 3 ? f + 2 : f);
+        const bool three = m == 3;
+        const int k0 = (r1 > r0 ? 1 : 0) + (three && r2 > r0 ? 1 : 0);                       // entries that end up in front of entry 0
+        const int k1 = (r0 >= r1 ? 1 : 0) + (three && r2 > r1 ? 1 : 0);
+        const int k2 = (r0 >= r2 ? 1 : 0) + (r1 >= r2 ? 1 : 0);
+        const int t = lane - f;
+        if (t >= 0 && t < m) {
+            if (k0 == t) { pos = p0; resp = r0; }
+            else if (k1 == t) { pos = p1; resp = r1; }
+            else if (three && k2 == t) { pos = p2; resp = r2; }
+        }
+    }
+    if (lane < n) { Cand e; e.pos = pos; e.resp = resp; a[first + lane] = e; }
+    wave_lds_fence();
+    if (heap) {
+        if (lane == 0) std::__introselect(a + first + f, a + first + k, a + first + l, 0, __gnu_cxx::__ops::__iter_comp_iter(RespGreater()));
+        wave_lds_fence();
+    }
+}
+
+// (inlined on purpose: as a called function its arguments are VGPRs — every branch an EXEC mask, every LDS access a FLAT instruction,
+//  and a FLAT access past a small workgroup's LDS allocation is an aperture violation where a ds_read is not)
+__device__ __forceinline__ void wave_nth_element(Cand* a, int first, int nth, int last, uint16_t* lpos, uint16_t* rpos, int lane) {
     if (first == last || nth == last) return;
     int depth = 2 * (31 - __clz(last - first));   // std::__lg(n) * 2
     const unsigned long long lt = (1ull << lane) - 1ull;
     while (last - first > 3) {
+        if (last - first <= 64) { wave_nth_small(a, first, nth, last, depth, lane); return; }
         if (depth == 0) {
             if (lane == 0) std::__introselect(a + first, a + nth, a + last, 0, __gnu_cxx::__ops::__iter_comp_iter(RespGreater()));
             wave_lds_fence();
@@ -911,23 +1009,24 @@ __device__ void wave_nth_element(Cand* a, int first, int nth, int last, uint16_t
         wave_lds_fence();
         const float P = a[first].resp;
         const int f = first + 1, l = last;
-        // left stoppers (ascending positions): !(value > P)
-        int nL = 0;
-        for (int base = f; base < l; base += 64) {
-            const int p = base + lane;
-            const bool st = p < l && !(a[p].resp > P);
-            const unsigned long long m = __ballot(st);
-            if (st) lpos[nL + __popcll(m & lt)] = (uint16_t)p;
-            nL += __popcll(m);
-        }
-        // right stoppers (descending positions): !(P > value)
-        int nR = 0;
-        for (int top = l; top > f; top -= 64) {
-            const int p = top - 1 - lane;
-            const bool st = p >= f && !(P > a[p].resp);
-            const unsigned long long m = __ballot(st);
-            if (st) rpos[nR + __popcll(m & lt)] = (uint16_t)p;
-            nR += __popcll(m);
+        // left stoppers !(value > P) and right stoppers !(P > value), both in ASCENDING positions, in one sweep that reads every entry once,
+        // four independent reads in flight (the k-th right stopper from the top is rpos[nR - 1 - k])
+        int nL = 0, nR = 0;
+        for (int base = f; base < l; base += 256) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int p = base + 64 * j + lane; v[j] = p < l ? a[p].resp : 0.f; }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int p = base + 64 * j + lane;
+                const bool in = p < l;
+                const bool sL = in && !(v[j] > P), sR = in && !(P > v[j]);
+                const unsigned long long mL = __ballot(sL), mR = __ballot(sR);
+                if (sL) lpos[nL + __popcll(mL & lt)] = (uint16_t)p;
+                if (sR) rpos[nR + __popcll(mR & lt)] = (uint16_t)p;
+                nL += __popcll(mL);
+                nR += __popcll(mR);
+            }
         }
         wave_lds_fence();
         // S = number of leading k with L[k] < R[k]  (L ascending, R descending: a prefix)
@@ -935,7 +1034,7 @@ __device__ void wave_nth_element(Cand* a, int first, int nth, int last, uint16_t
         int S = 0;
         for (int kb = 0; kb < nmin; kb += 64) {
             const int k = kb + lane;
-            const bool ok = k < nmin && lpos[k] < rpos[k];
+            const bool ok = k < nmin && lpos[k] < rpos[nR - 1 - k];
             const unsigned long long m = __ballot(ok);
             const int c = __popcll(m);
             S += c;
@@ -944,15 +1043,15 @@ __device__ void wave_nth_element(Cand* a, int first, int nth, int last, uint16_t
         for (int kb = 0; kb < S; kb += 64) {
             const int k = kb + lane;
             if (k < S) {
-                const int pl = lpos[k], pr = rpos[k];
+                const int pl = lpos[k], pr = rpos[nR - 1 - k];
                 const Cand t = a[pl];
                 a[pl] = a[pr];
                 a[pr] = t;
             }
         }
         int cut;
-        if (S < nL) { cut = lpos[S]; if (S > 0 && (int)rpos[S - 1] < cut) cut = rpos[S - 1]; }
-        else cut = rpos[S - 1];
+        if (S < nL) { cut = lpos[S]; if (S > 0 && (int)rpos[nR - S] < cut) cut = rpos[nR - S]; }
+        else cut = rpos[nR - S];
         wave_lds_fence();
         if (cut <= nth) first = cut; else last = cut;
     }
@@ -1108,23 +1207,27 @@ __global__ __launch_bounds__(SEL_LONG_WAVES * 64) void k_cell_select_long(Batch 
     const unsigned long long mQ = __ballot(mine && n_all <= quarter), mH = __ballot(mine && n_all > quarter && n_all <= half),
                              mF = __ballot(mine && n_all > half);
     if (!(mQ | mH | mF)) return;
-    auto run = [&](unsigned long long m, int share, int entries) {       // class m: wave w takes the cells of rank w, w + share, ... in its own part of the area
-        if (wave >= share) return;
-        uint8_t* area = smem + wave * sel_wave_bytes(entries);
-        for (int r = 0; m; r++) {
-            const int id = id0 + __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (r % share != wave) continue;
-            const int frame = id / g.ncells_total, cell = id - frame * g.ncells_total;
-            (void)cell_select_body(b, frame, cell, find_level(g.cell_bases, cell), area, entries, 0, lane);
-            wave_lds_fence();
+    // class c: `share` waves work side by side, wave w on the class's cells of rank w, w + share, ... in its own part of the area
+    const unsigned long long cls_m[3] = {mQ, mH, mF};
+    const int cls_share[3] = {4, 2, 1}, cls_entries[3] = {quarter, half, g.sel_lds_entries};
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+        unsigned long long m = cls_m[c];
+        const int share = cls_share[c], entries = cls_entries[c];
+        if (!m) continue;                                      // (workgroup-uniform)
+        if (wave < share) {
+            uint8_t* area = smem + wave * sel_wave_bytes(entries);
+            for (int r = 0; m; r++) {
+                const int id = id0 + __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (r % share != wave) continue;
+                const int frame = id / g.ncells_total, cell = id - frame * g.ncells_total;
+                (void)cell_select_body(b, frame, cell, find_level(g.cell_bases, cell), area, entries, 0, lane);
+                wave_lds_fence();
+            }
         }
-    };
-    run(mQ, 4, quarter);
-    if (mH | mF) __syncthreads();             // the parts change owners
-    run(mH, 2, half);
-    if (mF) __syncthreads();
-    run(mF, 1, g.sel_lds_entries);
+        __syncthreads();                                       // the parts change owners
+    }
 }
 
 // reference :697-701 (per-level cap), same scheme; one wave

@@ -15,5 +15,49 @@ timeout 300 python tools/fuzz_batch.py 40 501 > gpurun_out/c2/fuzz_batch.json 2>
 export ORBX_OVERLAP=0
 tools/exp_ab.sh c2ab r04:0 tree:0 chunk8:0 chunk32:0 r04:3 tree:3 chunk8:3 chunk32:3 r04:1 tree:1 2>&1 | tail -12
 ;;
+3)  # register-resident selection passes (ranges <= 64) + the fused stopper sweep against the build before them (head1) and round 4
+mkdir -p gpurun_out/c3
+(timeout 600 python -m pytest tests/test_gpu_select.py tests/test_gpu_bench_shapes.py tests/test_gpu_parity.py tests/test_golden.py -x -q 2>&1 | tail -5) > gpurun_out/c3/pytest.txt 2>&1; tail -2 gpurun_out/c3/pytest.txt
+timeout 300 python tools/fuzz_batch.py 40 502 > gpurun_out/c3/fuzz_batch.json 2>/dev/null; tail -c 300 gpurun_out/c3/fuzz_batch.json; echo
+timeout 300 python tools/fuzz_parity.py 400 503 > gpurun_out/c3/fuzz_parity.json 2>/dev/null; tail -c 300 gpurun_out/c3/fuzz_parity.json; echo
+export ORBX_OVERLAP=0
+tools/exp_ab.sh c3ab head1:1 tree:1 head1:0 tree:0 head1:3 tree:3 head1:4 tree:4 head1:1:hd1080 tree:1:hd1080 2>&1 | tail -12
+;;
+4)  # what crashed in call 3's test run
+mkdir -p gpurun_out/c4
+for t in tests/test_gpu_select.py tests/test_gpu_bench_shapes.py tests/test_gpu_parity.py tests/test_golden.py; do
+  timeout 300 python -X faulthandler -m pytest $t -x -q -v > gpurun_out/c4/$(basename $t).txt 2>&1; echo "$t rc=$?"; grep -n "PASSED\|FAILED\|Fatal\|fault\|Memory access" gpurun_out/c4/$(basename $t).txt | tail -4
+done
+;;
+5)  # which list aborts k_debug_nth (call 4: test_structured_lists)
+mkdir -p gpurun_out/c5
+timeout 200 python - > gpurun_out/c5/nth.txt 2>&1 <<'PY'
+import sys, os
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np, oracle_lib as orc
+from orb_slam_amd import capi
+for n in [2, 3, 4, 5, 7, 63, 64, 65, 128, 1000, 2049, 5000]:
+    base = np.arange(n, dtype=np.float32)
+    pats = [base, base[::-1].copy(), np.full(n, 20, np.float32), np.minimum(base, base[::-1]),
+            np.where(np.arange(n) % 2 == 0, 50, 10).astype(np.float32), np.concatenate([base[: n // 2], base[: n - n // 2]]),
+            (np.arange(n) % 3).astype(np.float32)]
+    for pi, r in enumerate(pats):
+        for nth in sorted({1, n // 3, n // 2, n - 1}):
+            if 0 < nth < n:
+                print("n", n, "pat", pi, "nth", nth, flush=True)
+                got = capi.nth_element_perm(r, nth); ref = orc.nth_element_perm(r, nth)
+                if not np.array_equal(got, ref): print("  MISMATCH first at", int(np.argmax(got != ref)), flush=True)
+print("done")
+PY
+tail -5 gpurun_out/c5/nth.txt
+;;
+6)  # the selection inlined again (call 3's build called wave_nth_element as a function: FLAT accesses, aperture violation in k_debug_nth)
+mkdir -p gpurun_out/c6
+(timeout 600 python -m pytest tests/test_gpu_select.py tests/test_gpu_bench_shapes.py tests/test_gpu_parity.py tests/test_golden.py -x -q 2>&1 | tail -5) > gpurun_out/c6/pytest.txt 2>&1; tail -2 gpurun_out/c6/pytest.txt
+timeout 300 python tools/fuzz_batch.py 60 602 > gpurun_out/c6/fuzz_batch.json 2>/dev/null; tail -c 300 gpurun_out/c6/fuzz_batch.json; echo
+timeout 300 python tools/fuzz_parity.py 600 603 > gpurun_out/c6/fuzz_parity.json 2>/dev/null; tail -c 300 gpurun_out/c6/fuzz_parity.json; echo
+export ORBX_OVERLAP=0
+tools/exp_ab.sh c6ab head1:1 tree:1 head1:0 tree:0 head1:3 tree:3 head1:4 tree:4 head1:1:hd1080 tree:1:hd1080 2>&1 | tail -12
+;;
 *) echo "usage: $0 <call number>"; exit 2 ;;
 esac
