@@ -56,3 +56,14 @@ def test_match_report_compacts():
     line = bench.compact_line(also["match100k"])
     assert line["roofline"]["bound"] == "mfma" and "hbm" in line["roofline"] and line["roofline"]["traffic"] is None
     assert len(json.dumps(line)) <= 4096
+
+
+def test_bare_multi_gpu_command_refuses_missing_devices():
+    """`python bench.py --gpus N` starts its own ranks only when the node shows N devices: on a box with fewer it says so
+    and exits 2 instead of spawning ranks that die one by one (this container has no GPU at all)."""
+    import subprocess
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(n, 2))], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 2 and "device(s)" in r.stderr and r.stdout.strip() == "", (r.returncode, r.stderr[-300:])

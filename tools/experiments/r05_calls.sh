@@ -59,5 +59,12 @@ timeout 300 python tools/fuzz_parity.py 600 603 > gpurun_out/c6/fuzz_parity.json
 export ORBX_OVERLAP=0
 tools/exp_ab.sh c6ab head1:1 tree:1 head1:0 tree:0 head1:3 tree:3 head1:4 tree:4 head1:1:hd1080 tree:1:hd1080 2>&1 | tail -12
 ;;
+7)  # k_blur_mfma with the waves of a workgroup staging together (2 / 4 adjacent strips), also on 1920-px rows (ORBX_BLUR_MFMA=2)
+mkdir -p gpurun_out/c7
+(timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bench_shapes.py tests/test_golden.py -x -q 2>&1 | tail -5) > gpurun_out/c7/pytest.txt 2>&1; tail -2 gpurun_out/c7/pytest.txt
+for v in mb4 hdg2 hdg4; do ORBX_LIB=$R/build_variants/$v/liborbx.so timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "blur_planes or large_batch" 2>&1 | tail -1; done
+export ORBX_OVERLAP=0
+tools/exp_ab.sh c7ab head2:1 tree:1 mb4:1 head2:1:hd1080 hdg2:1:hd1080 hdg4:1:hd1080 2>&1 | tail -12
+;;
 *) echo "usage: $0 <call number>"; exit 2 ;;
 esac
