@@ -13,7 +13,7 @@
  *   orbx_get_scale_factor           <- ORBextractor::GetScaleFactor()                      include/ORBextractor.h:50-51
  *   orbx_extract_batch_device       <- the same operator(), throughput form (device-resident frames, many per call)
  *   orbm_hamming256                 <- ORBmatcher::DescriptorDistance(const Mat&,const Mat&) include/ORBmatcher.h:44, src/ORBmatcher.cc:1794-1810
- *   orbm_match_top2[_device|_batch_device]
+ *   orbm_match_top2[_masked][_device|_batch_device]
  *                                   <- the best / second-best scan shared by every ORBmatcher search
  *                                      (src/ORBmatcher.cc:87-111, :201-222, :454-474, :629-650, ...)
  *   orbm_match_top2_segments[_device]
@@ -149,6 +149,13 @@ int orbm_match_top2(const uint8_t* Q, int nq, const uint8_t* T, int nt,
                     int32_t* best_idx, int32_t* best, int32_t* second, int device);
 int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
                            int32_t* d_best_idx, int32_t* d_best, int32_t* d_second, void* stream);
+/* The same scan over the train descriptors with t_valid[t] != 0 only (one byte per train descriptor; NULL = all): the
+ * `if(vpMapPointMatches[realIdxF]) continue;` of the reference's scans (src/ORBmatcher.cc:205-206).  best_idx is an index into the
+ * ORIGINAL train array; no valid descriptor -> -1, INT_MAX, INT_MAX.  nq, nt < 2^22. */
+int orbm_match_top2_masked(const uint8_t* Q, int nq, const uint8_t* T, int nt, const uint8_t* t_valid,
+                           int32_t* best_idx, int32_t* best, int32_t* second, int device);
+int orbm_match_top2_masked_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt, const uint8_t* d_t_valid,
+                                  int32_t* d_best_idx, int32_t* d_best, int32_t* d_second, void* stream);
 /* nbatch independent problems with per-problem sizes read on the device:
  * problem i: queries dQ + i*cap*32 (d_nq[i] of them), train dT + i*cap*32 (d_nt[i]); outputs at i*cap. */
 int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const uint8_t* dT, const int32_t* d_nt,

@@ -25,7 +25,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 EXPORTS = [
     "orbx_default_params", "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_scale_factor",
     "orbx_max_keypoints", "orbx_last_error", "orbx_build_id", "orbx_extract", "orbx_extract_batch_device", "orbx_extract_batch_device_phases",
-    "orbm_hamming256", "orbm_match_top2", "orbm_match_top2_device", "orbm_match_top2_batch_device",
+    "orbm_hamming256", "orbm_match_top2", "orbm_match_top2_device", "orbm_match_top2_batch_device", "orbm_match_top2_masked", "orbm_match_top2_masked_device",
     "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbm_distinctive", "orbm_distinctive_device",
     "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_device_download",
     "orbx_stream_create", "orbx_stream_create_priority", "orbx_stream_destroy", "orbx_stream_synchronize", "orbx_event_create", "orbx_event_destroy", "orbx_event_record",
@@ -134,6 +134,8 @@ def lib():
         L.orbm_match_top2.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci]
         L.orbm_match_top2_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp]
         L.orbm_match_top2_batch_device.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, vp]
+        L.orbm_match_top2_masked.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, ci]
+        L.orbm_match_top2_masked_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp]
         L.orbm_count_accepted.argtypes = [vp, vp, ci, ci, cf]
         L.orbm_debug_set_match_path.argtypes = [ci]
         L.orbs_debug_set_buckets.argtypes = [ci]
@@ -321,6 +323,20 @@ def match_top2(Q, T, device=0):
     rc = lib().orbm_match_top2(Q.ctypes.data, nq, T.ctypes.data, nt, idx.ctypes.data, best.ctypes.data, sec.ctypes.data, device)
     if rc != ORBX_OK:
         raise OrbxError(rc, "orbm_match_top2")
+    return idx, best, sec
+
+
+def match_top2_masked(Q, T, t_valid, device=0):
+    """dense top-2 over the train descriptors with t_valid != 0 only (src/ORBmatcher.cc:205-206); indices refer to T"""
+    Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 32)
+    T = np.ascontiguousarray(T, dtype=np.uint8).reshape(-1, 32)
+    v = np.ascontiguousarray(t_valid, dtype=np.uint8)
+    nq, nt = len(Q), len(T)
+    assert len(v) == nt
+    idx = np.empty(nq, np.int32); best = np.empty(nq, np.int32); sec = np.empty(nq, np.int32)
+    rc = lib().orbm_match_top2_masked(Q.ctypes.data, nq, T.ctypes.data, nt, v.ctypes.data if nt else None, idx.ctypes.data, best.ctypes.data, sec.ctypes.data, device)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbm_match_top2_masked")
     return idx, best, sec
 
 

@@ -31,6 +31,20 @@ public:
         if (rc != ORBX_OK) throw std::runtime_error("orbm_match_top2 failed: no usable MI355X / HIP runtime");
     }
 
+    // The same scan skipping train rows that are already taken — `if(vpMapPointMatches[realIdxF]) continue;` (reference
+    // src/ORBmatcher.cc:205-206): tValid[t] != 0 marks the rows still in play; bestIdx holds rows of T.
+    void MatchTop2(const cv::Mat& Q, const cv::Mat& T, const std::vector<unsigned char>& tValid, std::vector<int>& bestIdx, std::vector<int>& bestDist,
+                   std::vector<int>& bestDist2) const {
+        if (!Q.empty() && (!Q.isContinuous() || Q.cols != 32)) throw std::runtime_error("MatchTop2: Q must be N x 32 continuous");
+        if (!T.empty() && (!T.isContinuous() || T.cols != 32)) throw std::runtime_error("MatchTop2: T must be M x 32 continuous");
+        if ((int)tValid.size() != T.rows) throw std::runtime_error("MatchTop2: tValid must have T.rows entries");
+        const int nq = Q.rows, nt = T.rows;
+        bestIdx.assign(nq, -1); bestDist.assign(nq, INT_MAX); bestDist2.assign(nq, INT_MAX);
+        if (nq == 0 || nt == 0) return;
+        const int rc = orbm_match_top2_masked(Q.data, nq, T.data, nt, tValid.data(), bestIdx.data(), bestDist.data(), bestDist2.data(), device_);
+        if (rc != ORBX_OK) throw std::runtime_error("orbm_match_top2_masked failed: no usable MI355X / HIP runtime");
+    }
+
     // Candidate-set form of the same scan (GetFeaturesInArea windows, vocabulary-node feature lists): query q scans
     // T rows cand[segOff[q] .. segOff[q+1]) in list order; bestIdx holds train row indices.
     void MatchTop2Candidates(const cv::Mat& Q, const cv::Mat& T, const std::vector<int>& segOff, const std::vector<int>& cand,

@@ -739,6 +739,104 @@ int orbm_match_top2_segments(const uint8_t* Q, int nq, const uint8_t* T, int nt,
     return rc;
 }
 
+// ---- dense top-2 over a SUBSET of the train descriptors (the optional t_valid mask) ------------------------------------
+// The reference's scans skip train features that are already matched — `if(vpMapPointMatches[realIdxF]) continue;`
+// (src/ORBmatcher.cc:205-206 and siblings).  Skipping entries of a sequential scan = scanning the ORDER-PRESERVING compaction of the list,
+// so: compact the valid descriptors (one workgroup: ordered ballot ranks, the waves' counts through LDS) with their original indices,
+// run the batch form of the dense kernels on the compacted set (its train count is read on the device), map the winners' indices back.
+__global__ __launch_bounds__(1024) void k_mask_compact(const uint32_t* __restrict__ T, const uint8_t* __restrict__ valid, int nt, int nq,
+                                                       uint32_t* __restrict__ Tc, int32_t* __restrict__ map, int32_t* __restrict__ counts) {
+    __shared__ int wsum[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int base = 0, par = 0;
+    for (int i0 = 0; i0 < nt; i0 += 1024, par ^= 1) {
+        const int i = i0 + tid;
+        const bool ok = i < nt && valid[i] != 0;
+        const unsigned long long mk = __ballot(ok);
+        if (lane == 0) wsum[par][wave] = __popcll(mk);
+        __syncthreads();                                    // (two sets of words: one barrier per round)
+        int off = base, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const int c = wsum[par][w]; if (w < wave) off += c; tot += c; }
+        if (ok) {
+            const int pos = off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            map[pos] = i;
+#pragma unroll
+            for (int k = 0; k < 8; k++) Tc[(size_t)pos * 8 + k] = T[(size_t)i * 8 + k];
+        }
+        base += tot;
+    }
+    if (tid == 0) { counts[0] = nq; counts[1] = base; }
+}
+__global__ __launch_bounds__(256) void k_mask_remap(int32_t* __restrict__ best_idx, const int32_t* __restrict__ map, int nq) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < nq) { const int i = best_idx[q]; if (i >= 0) best_idx[q] = map[i]; }
+}
+
+int orbm_match_top2_masked_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt, const uint8_t* d_t_valid, int32_t* d_best_idx,
+                                  int32_t* d_best, int32_t* d_second, void* stream_) {
+    if (!d_t_valid) return orbm_match_top2_device(dQ, nq, dT, nt, d_best_idx, d_best, d_second, stream_);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nq < 0 || nt < 0 || nt >= (1 << KEY_SHIFT) || nq >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
+    if (nq == 0) return ORBX_OK;
+    if (((uintptr_t)dQ & 3) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
+    const int cap = std::max(nq, std::max(nt, 1));
+    // scratch: compacted train set (padded by two tiles: the kernels load whole tiles), index map, the two counts
+    const size_t tc_bytes = ((size_t)cap + 64) * 32, map_bytes = ((size_t)nt + 1) * sizeof(int32_t);
+    const size_t need = tc_bytes + map_bytes + 16;
+    uint8_t* scratch = nullptr;
+    hipMemPool_t pool = match_pool();
+    const bool pooled = pool != nullptr;
+    if ((pooled ? hipMallocFromPoolAsync(reinterpret_cast<void**>(&scratch), need, pool, stream) : hipMalloc(reinterpret_cast<void**>(&scratch), need)) != hipSuccess) {
+        (void)hipGetLastError();
+        return ORBX_ERR_DEVICE;
+    }
+    uint32_t* Tc = reinterpret_cast<uint32_t*>(scratch);
+    int32_t* map = reinterpret_cast<int32_t*>(scratch + tc_bytes);
+    int32_t* counts = reinterpret_cast<int32_t*>(scratch + tc_bytes + map_bytes);
+    int rc = ORBX_OK;
+    hipLaunchKernelGGL(k_mask_compact, dim3(1), dim3(1024), 0, stream, (const uint32_t*)dT, d_t_valid, nt, nq, Tc, map, counts);
+    if (hipGetLastError() != hipSuccess) rc = ORBX_ERR_DEVICE;
+    if (rc == ORBX_OK) rc = orbm_match_top2_batch_device(dQ, counts, reinterpret_cast<const uint8_t*>(Tc), counts + 1, 1, cap, d_best_idx, d_best, d_second, stream);
+    if (rc == ORBX_OK) {
+        hipLaunchKernelGGL(k_mask_remap, dim3((nq + 255) / 256), dim3(256), 0, stream, d_best_idx, map, nq);
+        if (hipGetLastError() != hipSuccess) rc = ORBX_ERR_DEVICE;
+    }
+    if (pooled) {
+        if (hipFreeAsync(scratch, stream) != hipSuccess) rc = ORBX_ERR_DEVICE;
+    } else {
+        if (hipStreamSynchronize(stream) != hipSuccess) rc = ORBX_ERR_DEVICE;
+        if (hipFree(scratch) != hipSuccess) rc = ORBX_ERR_DEVICE;
+    }
+    return rc;
+}
+
+int orbm_match_top2_masked(const uint8_t* Q, int nq, const uint8_t* T, int nt, const uint8_t* t_valid, int32_t* best_idx, int32_t* best,
+                           int32_t* second, int device) {
+    if (!t_valid) return orbm_match_top2(Q, nq, T, nt, best_idx, best, second, device);
+    if (nq < 0 || nt < 0) return ORBX_ERR_ARG;
+    if (nq == 0) return ORBX_OK;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    uint8_t *dQ = nullptr, *dT = nullptr, *dV = nullptr;
+    int32_t* dout = nullptr;
+    int rc = ORBX_ERR_DEVICE;
+    if (hipMalloc(&dQ, (size_t)nq * 32) == hipSuccess && hipMalloc(&dT, (size_t)std::max(nt, 1) * 32) == hipSuccess &&
+        hipMalloc(&dV, (size_t)std::max(nt, 1)) == hipSuccess && hipMalloc(&dout, (size_t)nq * 3 * sizeof(int32_t)) == hipSuccess &&
+        hipMemcpy(dQ, Q, (size_t)nq * 32, hipMemcpyHostToDevice) == hipSuccess &&
+        (nt == 0 || (hipMemcpy(dT, T, (size_t)nt * 32, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dV, t_valid, (size_t)nt, hipMemcpyHostToDevice) == hipSuccess))) {
+        rc = orbm_match_top2_masked_device(dQ, nq, dT, nt, dV, dout, dout + nq, dout + 2 * (size_t)nq, nullptr);
+        if (rc == ORBX_OK && (hipStreamSynchronize(nullptr) != hipSuccess || hipMemcpy(best_idx, dout, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                              hipMemcpy(best, dout + nq, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                              hipMemcpy(second, dout + 2 * (size_t)nq, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess))
+            rc = ORBX_ERR_DEVICE;
+    }
+    if (dQ) (void)hipFree(dQ);
+    if (dT) (void)hipFree(dT);
+    if (dV) (void)hipFree(dV);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
 int orbm_match_top2(const uint8_t* Q, int nq, const uint8_t* T, int nt, int32_t* best_idx, int32_t* best, int32_t* second, int device) {
     if (nq < 0 || nt < 0) return ORBX_ERR_ARG;
     if (nq == 0) return ORBX_OK;

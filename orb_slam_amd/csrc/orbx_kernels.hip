@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(256) void k_cell_select(Batch b, int lds_entries) {
 
 // The cells k_cell_select left over (lists beyond its staging area).  A workgroup of four waves looks at the flags of SEL_LONG_CHUNK
 // consecutive cells and shares ONE full staging area (sel_lds_entries entries) by list length: lists that fit a quarter of it are taken
-// four at a time (one wave each), lists that fit half of it two at a time, the rest one at a time with all of it.  A wave's selection
+// four at a time (one wave each), lists that fit a third three at a time, half two at a time, the rest one at a time with all of it.  A wave's selection
 // is latency-bound (~20 us per cell whatever its length: ten partition passes of a few dependent LDS round trips each), so what counts
 // is the number of cells in flight per CU, and that is set by the LDS a cell holds.  (Rounds 2-4: one-wave workgroups with the full area
 // each, six cells per CU.  S-lowtex lists 440-480 corners per level-0 cell, S-noise 910 / 570 / 520 on levels 0 / 1 / 2: 0.42 and 1.1 ms
@@ -1184,9 +1184,10 @@ __global__ __launch_bounds__(256) void k_cell_select(Batch b, int lds_entries) {
 #define ORBX_SEL_LONG_CHUNK 8
 #endif
 constexpr int SEL_LONG_CHUNK = ORBX_SEL_LONG_CHUNK, SEL_LONG_WAVES = 4;
-__host__ __device__ constexpr int sel_long_bytes(int entries) {      // the shared area: four quarter areas, two half areas or one full one
-    const int a = 4 * sel_wave_bytes((entries + 3) / 4), c = 2 * sel_wave_bytes((entries + 1) / 2), d = sel_wave_bytes(entries);
-    return a > c ? (a > d ? a : d) : (c > d ? c : d);
+__host__ __device__ constexpr int sel_long_bytes(int entries) {      // the shared area: four quarter areas, three thirds, two halves or one full one
+    int m = 0;
+    for (int share = 1; share <= 4; share++) { const int v = share * sel_wave_bytes((entries + share - 1) / share); m = v > m ? v : m; }
+    return m;
 }
 __global__ __launch_bounds__(SEL_LONG_WAVES * 64) void k_cell_select_long(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1194,7 +1195,7 @@ __global__ __launch_bounds__(SEL_LONG_WAVES * 64) void k_cell_select_long(Batch 
     const int lane = (int)threadIdx.x & 63, wave = wave_id(), total = b.nframes * g.ncells_total;
     const int id0 = (int)blockIdx.x * SEL_LONG_CHUNK;
     static_assert(SEL_LONG_CHUNK <= 64, "one flag per lane");
-    const int quarter = (g.sel_lds_entries + 3) / 4, half = (g.sel_lds_entries + 1) / 2;
+    const int quarter = (g.sel_lds_entries + 3) / 4, third = (g.sel_lds_entries + 2) / 3, half = (g.sel_lds_entries + 1) / 2;
     // every wave reads the same flags and list lengths (lane i: cell id0 + i)
     int n_all = 0;
     const bool mine = lane < SEL_LONG_CHUNK && id0 + lane < total && b.long_cells[id0 + lane] != 0;
@@ -1204,14 +1205,14 @@ __global__ __launch_bounds__(SEL_LONG_WAVES * 64) void k_cell_select_long(Batch 
         const CellState* bst = b.cstate + (long long)frame * g.nbands_total + cgeo.band0;
         for (int k = 0; k < cgeo.nbands; k++) n_all += bst[k].n_all;
     }
-    const unsigned long long mQ = __ballot(mine && n_all <= quarter), mH = __ballot(mine && n_all > quarter && n_all <= half),
-                             mF = __ballot(mine && n_all > half);
-    if (!(mQ | mH | mF)) return;
+    const unsigned long long mQ = __ballot(mine && n_all <= quarter), mT = __ballot(mine && n_all > quarter && n_all <= third),
+                             mH = __ballot(mine && n_all > third && n_all <= half), mF = __ballot(mine && n_all > half);
+    if (!(mQ | mT | mH | mF)) return;
     // class c: `share` waves work side by side, wave w on the class's cells of rank w, w + share, ... in its own part of the area
-    const unsigned long long cls_m[3] = {mQ, mH, mF};
-    const int cls_share[3] = {4, 2, 1}, cls_entries[3] = {quarter, half, g.sel_lds_entries};
+    const unsigned long long cls_m[4] = {mQ, mT, mH, mF};
+    const int cls_share[4] = {4, 3, 2, 1}, cls_entries[4] = {quarter, third, half, g.sel_lds_entries};
 #pragma unroll 1
-    for (int c = 0; c < 3; c++) {
+    for (int c = 0; c < 4; c++) {
         unsigned long long m = cls_m[c];
         const int share = cls_share[c], entries = cls_entries[c];
         if (!m) continue;                                      // (workgroup-uniform)

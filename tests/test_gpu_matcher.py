@@ -53,6 +53,27 @@ def test_ties_duplicates_and_extremes(match_path):
     _check(few[:1500], few[1500:])
 
 
+@pytest.mark.parametrize("nq,nt,keep", [(1, 1, 1.0), (5, 3, 0.5), (1000, 1000, 0.7), (300, 4097, 0.1), (513, 70001, 0.9), (64, 2000, 0.0), (2000, 100, 0.5)])
+def test_train_mask(nq, nt, keep, match_path):
+    """SURVEY 8b's optional t_valid mask (src/ORBmatcher.cc:205-206: already matched train features are skipped): the scan over the
+    valid descriptors only = the oracle's sequential scan of the order-preserving compaction, indices mapped back to the train array"""
+    rng = np.random.default_rng(nq * 7 + nt)
+    Q, T = synth.descriptors(nq, 31 + nq), synth.descriptors(nt, 41 + nt)
+    if nt > 50:
+        T[10:nt:5] = T[3]                                   # duplicates: the first VALID index attaining the best distance must win
+    valid = (rng.random(nt) < keep).astype(np.uint8)
+    gi, gb, gs = capi.match_top2_masked(Q, T, valid)
+    kept = np.flatnonzero(valid)
+    ri, rb, rs = orc.match_top2(Q, T[kept])
+    ri = np.where(ri >= 0, kept[np.maximum(ri, 0)] if len(kept) else -1, -1).astype(np.int32)
+    np.testing.assert_array_equal(gb, rb)
+    np.testing.assert_array_equal(gs, rs)
+    np.testing.assert_array_equal(gi, ri)
+    if keep == 1.0:
+        for a, b in zip((gi, gb, gs), capi.match_top2(Q, T)):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_batch_device(match_path):
     torch = pytest.importorskip("torch")
     B, cap = 9, 1000

@@ -66,5 +66,19 @@ for v in mb4 hdg2 hdg4; do ORBX_LIB=$R/build_variants/$v/liborbx.so timeout 300 
 export ORBX_OVERLAP=0
 tools/exp_ab.sh c7ab head2:1 tree:1 mb4:1 head2:1:hd1080 hdg2:1:hd1080 hdg4:1:hd1080 2>&1 | tail -12
 ;;
+8)  # the masked dense match (t_valid) + where the default line stands
+mkdir -p gpurun_out/c8
+(timeout 600 python -m pytest tests/test_gpu_matcher.py -x -q 2>&1 | tail -5) > gpurun_out/c8/pytest.txt 2>&1; tail -2 gpurun_out/c8/pytest.txt
+(time timeout 600 python bench.py --detail-file gpurun_out/c8/bench.json > gpurun_out/c8/bench.stdout 2> gpurun_out/c8/bench.err) 2>&1 | grep real
+tail -1 gpurun_out/c8/bench.stdout | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms_per_step']); print({k:(v['value'], v['ms_per_step']) for k,v in d['also_summary'].items()})"
+;;
+9)  # a thirds class in k_cell_select_long (S-noise lists of 520-600 corners sat just above the quarter)
+mkdir -p gpurun_out/c9
+(timeout 600 python -m pytest tests/test_gpu_bench_shapes.py tests/test_gpu_parity.py -x -q 2>&1 | tail -5) > gpurun_out/c9/pytest.txt 2>&1; tail -2 gpurun_out/c9/pytest.txt
+timeout 300 python tools/fuzz_batch.py 40 902 > gpurun_out/c9/fuzz_batch.json 2>/dev/null; tail -c 200 gpurun_out/c9/fuzz_batch.json; echo
+ORBX_OVERLAP=0 tools/exp_ab.sh c9ab head3:0 tree:0 head3:3 tree:3 2>&1 | tail -4
+for v in head3 tree; do lib=$R/build_variants/$v/liborbx.so; [ $v = tree ] && lib=$R/orb_slam_amd/liborbx.so
+ORBX_LIB=$lib timeout 200 python bench.py --family 0 --no-also --no-cpu-baseline --min-seconds 4 --parity sample | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v noise 4 lanes', d['value'], d['ms_per_step'])"; done
+;;
 *) echo "usage: $0 <call number>"; exit 2 ;;
 esac
