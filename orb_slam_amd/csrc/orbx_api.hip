@@ -116,7 +116,7 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
     HIPCHK(h, hipMalloc(&h->d_pyr, B * g.frame_plane_bytes));
     HIPCHK(h, hipMalloc(&h->d_blur, B * g.frame_plane_bytes));
     HIPCHK(h, hipMalloc(&h->d_cand, B * std::max(g.frame_cands, 1) * sizeof(Cand)));
-    HIPCHK(h, hipMalloc(&h->d_sel, B * std::max(g.frame_sel, 1) * sizeof(Cand)));
+    HIPCHK(h, hipMalloc(&h->d_sel, (B * std::max(g.frame_sel, 1) + 4) * sizeof(Cand)));      // (+ 4: k_describe reads a wave's four keypoints as one 32-byte scalar load)
     HIPCHK(h, hipMalloc(&h->d_cstate, B * g.nbands_total * sizeof(CellState)));
     for (int k = 0; k < 2; k++) {
         HIPCHK(h, hipMalloc(&h->d_band_hint[k], (size_t)(g.nbands_total + 16) * sizeof(int32_t)));

@@ -784,6 +784,9 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     }
 }
 
+// (round 5: workgroups walking 2 / 4 / 16 bands grid-stride — one launch of long-lived workgroups instead of 729 k short ones — took
+//  1.02 / 1.02 / 1.05 ms against 0.845 per 1024 VGA frames: the dispatcher's interleaving of fresh workgroups is what hides a band's
+//  serial phases, a resident workgroup exposes them)
 template <bool ALIGNED, int NT, int PPT>
 __global__ __launch_bounds__(NT) void k_fast_cells(Batch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1795,9 +1798,22 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
     // as early as its address is known: the per-level counts (one load, lane l holds level l) and the frame status first, then the
     // wave's keypoints, and only then the LDS tables are built (their barrier rides on those loads); the 37 x 37 windows of the
     // blurred level follow by LDS-DMA as soon as the keypoints are there, in flight during IC_Angle and the angle arithmetic.
+#ifndef ORBX_DESC_EARLY_PATTERN
+#define ORBX_DESC_EARLY_PATTERN 1      // (0.701 -> 0.692 ms per 1024 VGA frames)
+#endif
+    // (round 5) the thread's word of the BRIEF pattern is requested FIRST: loads return in order, so the tables can be built while the
+    // counts and the keypoint are still on their way — before, the pattern load started only after the keypoint had arrived: one
+    // dependent round trip more in front of the tables' barrier
+    const uint32_t pk_first = ORBX_DESC_EARLY_PATTERN ? c_pattern[tid & 255] : 0u;
+#ifndef ORBX_DESC_SCALAR_LOADS
+#define ORBX_DESC_SCALAR_LOADS 1       // (0.692 -> 0.686)
+#endif
     const int32_t* counts = b.level_count + frame * MAX_LEVELS;
-    const int cl = lane < g.nlevels ? counts[lane] : 0;
-    const int st0 = b.status[frame];
+    int cl = 0, st0 = 0;
+    if (!ORBX_DESC_SCALAR_LOADS) {
+        cl = lane < g.nlevels ? counts[lane] : 0;
+        st0 = b.status[frame];
+    }
     const int quad = wgi * DESC_WAVES + wave_id();
     const bool live = quad < g.nquads;
     const int level = __builtin_amdgcn_readfirstlane(find_level(g.quad_bases, live ? quad : 0));
@@ -1812,23 +1828,30 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
     // whether it is one — the slot index is clamped into the level's list, what lies behind the list's end is never used).  One
     // dependent memory round trip less in front of the two gathers.
     const int k0 = (quad - L.quad_base) * DESC_KPW;
-    Cand kp = b.sel[(long long)frame * g.frame_sel + L.sel_base + min(max(k0 + grp, 0), __builtin_amdgcn_readfirstlane(LG.sel_cap) - 1)];
-    int out_base = 0, total = 0, cnt = 0;
-    for (int l = 0; l < g.nlevels; l++) {
-        const int c = __builtin_amdgcn_readlane(cl, l);
-        if (l < level) out_base += c;
-        if (l == level) cnt = c;
-        total += c;
-    }
-    const bool work = live && k0 < cnt && total <= b.cap && __builtin_amdgcn_readfirstlane(st0) == ORBX_OK;
-    const bool valid = work && k0 + grp < cnt;
-    const int k = valid ? k0 + grp : (work ? k0 : 0);       // idle groups shadow the wave's first keypoint (results dropped)
-    if (!valid) {
-        kp.pos = (uint32_t)__builtin_amdgcn_readlane((int)kp.pos, 0);
-        kp.resp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kp.resp), 0));
-    }
+    Cand kp;
+    typedef int v8i_s __attribute__((ext_vector_type(8)));
+    v8i_s s_cnt0 = {0, 0, 0, 0, 0, 0, 0, 0}, s_cnt1 = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ORBX_DESC_SCALAR_LOADS) {
+        // (round 5) The wave's four keypoints, the per-level counts and the frame status are wave-uniform data: SCALAR loads.  This kernel
+        // keeps the vector-memory front end 0.7-0.8 busy with its gathers, and a small vector load queues behind the gathers of the ~20
+        // other waves of the CU (the keypoint wait was 23 % of a wave's life, profiles/r04_describe_wave_phases.txt); the scalar cache path
+        // does not.  (Written by the selection kernels of earlier launches: coherent at the kernel boundary.)
+        const int sel_cap = __builtin_amdgcn_readfirstlane(LG.sel_cap);
+        const int ks = __builtin_amdgcn_readfirstlane(max(min(k0, sel_cap - DESC_KPW), 0));        // (the sel block carries 4 slots of padding)
+        const Cand* kp4 = b.sel + ((long long)frame * g.frame_sel + L.sel_base + ks);
+        const int32_t* stp = b.status + frame;
+        v8i_s kq;
+        int sst;
+        asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %5, 0x0\n\ts_load_dwordx8 %2, %5, 0x20\n\ts_load_dword %3, %6, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(kq), "=&s"(s_cnt0), "=&s"(s_cnt1), "=&s"(sst) : "s"(kp4), "s"(counts), "s"(stp) : "memory");
+        st0 = sst;
+        const int e = min(max(k0 + grp, 0), sel_cap - 1) - ks;       // 0 .. 3
+        kp.pos = (uint32_t)(e == 0 ? kq[0] : e == 1 ? kq[2] : e == 2 ? kq[4] : kq[6]);
+        kp.resp = __builtin_bit_cast(float, e == 0 ? kq[1] : e == 1 ? kq[3] : e == 2 ? kq[5] : kq[7]);
+    } else kp = b.sel[(long long)frame * g.frame_sel + L.sel_base + min(max(k0 + grp, 0), __builtin_amdgcn_readfirstlane(LG.sel_cap) - 1)];
+    auto build_tables = [&]() {
     for (int t = tid; t < 256; t += DESC_WAVES * 64) {
-        const uint32_t pk = c_pattern[t];
+        const uint32_t pk = (ORBX_DESC_EARLY_PATTERN && t == tid) ? pk_first : c_pattern[t];
 #if ORBX_DESC_PACKED_PATTERN
         s_pat[t] = pk;
 #else
@@ -1846,7 +1869,33 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
         }
         s_mask[t] = mask;
     }
-    __syncthreads();
+    };
+    if (ORBX_DESC_EARLY_PATTERN) build_tables();
+    int out_base = 0, total = 0, cnt = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        int c;
+        if (ORBX_DESC_SCALAR_LOADS) {
+            c = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { if (l == i) c = s_cnt0[i]; if (l == 8 + i) c = s_cnt1[i]; }
+        } else c = __builtin_amdgcn_readlane(cl, l);
+        if (l < level) out_base += c;
+        if (l == level) cnt = c;
+        total += c;
+    }
+    const bool work = live && k0 < cnt && total <= b.cap && __builtin_amdgcn_readfirstlane(st0) == ORBX_OK;
+    const bool valid = work && k0 + grp < cnt;
+    const int k = valid ? k0 + grp : (work ? k0 : 0);       // idle groups shadow the wave's first keypoint (results dropped)
+    if (!valid) {
+        kp.pos = (uint32_t)__builtin_amdgcn_readlane((int)kp.pos, 0);
+        kp.resp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kp.resp), 0));
+    }
+    if (!ORBX_DESC_EARLY_PATTERN) build_tables();
+#ifndef ORBX_DESC_LATE_BARRIER
+#define ORBX_DESC_LATE_BARRIER 1     // the tables' barrier behind the window DMA issue (round 5: 0.727 -> 0.701 ms; 0 = in front of it, rounds 2-4; behind the
+                                     // patch loads' issue as well: 0.714)
+#endif
+    if (!ORBX_DESC_LATE_BARRIER) __syncthreads();
     if (quad == 0 && lane == 0) {
         int st = st0, tot = total;
         if (tot > b.cap) { st = ORBX_ERR_CAPACITY; tot = 0; }
@@ -1892,6 +1941,11 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
         }
     }
 
+    if (ORBX_DESC_LATE_BARRIER) {
+        // the tables' barrier behind the window DMA issue: only the LDS writes have to be complete (no vmcnt wait: the DMA stays in flight);
+        // a wave that returned above has left the workgroup's barrier count with its s_endpgm
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     // IC_Angle on the unblurred level (:705-706 run before the blur)
     int m10, m01;
     {

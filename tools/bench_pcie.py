@@ -27,10 +27,17 @@ ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--warmup", type=int, default=4)
 ap.add_argument("--copy-streams", type=int, default=0, help="0: one upload stream per lane (a lane starts as soon as ITS slice is there); 1: one stream, one copy per step")
 ap.add_argument("--outputs", default="full", choices=["full", "counts"], help="full: every output array returns to the host; counts: only n per frame")
+ap.add_argument("--numa-bind", action="store_true", help="bind the process to the GPU's NUMA node BEFORE the pinned buffers are allocated (first touch decides where they live)")
+ap.add_argument("--chunks", type=int, default=1, help="split every lane's upload into this many copies, alternating over --streams-per-lane upload streams (more SDMA engines in flight)")
+ap.add_argument("--streams-per-lane", type=int, default=1)
 a = ap.parse_args()
 w, h, B, ring = a.width, a.height, a.batch, max(a.ring // a.batch, 1) * a.batch
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
+numa = None
+if a.numa_bind:
+    from orb_slam_amd import dist_util
+    numa = dist_util.bind_to_gpu_numa(0)
 
 host = torch.from_numpy(synth.frames(w, h, synth.BLOCKS, 0, ring)).pin_memory()            # the camera side: frames in pinned host memory
 pipe = LanePipeline(w, h, B, lanes=a.lanes, nfeatures=a.nfeatures, device=0)
@@ -41,6 +48,7 @@ torch.cuda.synchronize()
 pipe.tune(d_frames[0].data_ptr())
 
 copy_streams = [torch.cuda.Stream(dev) for _ in range(G)]
+extra_streams = [[copy_streams[g]] + [torch.cuda.Stream(dev) for _ in range(a.streams_per_lane - 1)] for g in range(G)]
 out = [dict(n=torch.empty(b, dtype=torch.int32).pin_memory(), kps=torch.empty((b, cap, 7), dtype=torch.float32).pin_memory(),
             desc=torch.empty((b, cap, 32), dtype=torch.uint8).pin_memory(), match=torch.empty((3, b, cap), dtype=torch.int32).pin_memory())
        for _ in range(G)]
@@ -66,8 +74,31 @@ def upload(i):
         cs = copy_streams[g]
         if released[g][p] is not None:
             cs.wait_event(released[g][p])
+        if a.chunks <= 1 and a.streams_per_lane <= 1:
+            with torch.cuda.stream(cs):
+                d_frames[p][g * b:(g + 1) * b].copy_(host[f0 + g * b:f0 + (g + 1) * b], non_blocking=True)
+                uploaded[g][p] = torch.cuda.Event()
+                uploaded[g][p].record(cs)
+            continue
+        # the lane's slice in `chunks` copies over its upload streams; the lane's first stream joins them and records the event
+        sts = extra_streams[g]
+        for st in sts[1:]:
+            if released[g][p] is not None:
+                st.wait_event(released[g][p])
+        per = (b + a.chunks - 1) // a.chunks
+        evs = []
+        for c in range(a.chunks):
+            lo, hi = g * b + c * per, min(g * b + (c + 1) * per, (g + 1) * b)
+            if lo >= hi:
+                break
+            st = sts[c % len(sts)]
+            with torch.cuda.stream(st):
+                d_frames[p][lo:hi].copy_(host[f0 + lo:f0 + hi], non_blocking=True)
+                if st is not cs:
+                    e = torch.cuda.Event(); e.record(st); evs.append(e)
+        for e in evs:
+            cs.wait_event(e)
         with torch.cuda.stream(cs):
-            d_frames[p][g * b:(g + 1) * b].copy_(host[f0 + g * b:f0 + (g + 1) * b], non_blocking=True)
             uploaded[g][p] = torch.cuda.Event()
             uploaded[g][p].record(cs)
 
@@ -127,10 +158,11 @@ print(json.dumps({"metric": "frames_per_s_pcie_inclusive", "value": round(B * a.
                   "steps": a.steps, "warmup": a.warmup, "workload": "%dx%d nf=%d, %d frames per step in %d lanes, extract + match" % (w, h, a.nfeatures, B, G),
                   "outputs_to_host": a.outputs, "upload_streams": 1 if a.copy_streams == 1 else G, "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h,
                   "h2d_GBps": round(h2d / ms / 1e6, 2), "d2h_GBps": round(d2h / ms / 1e6, 2),
-                  "frames_compared_with_device_resident_run": B, "mismatching_frames": bad, "placement": pipe.placement["chosen"]}))
+                  "frames_compared_with_device_resident_run": B, "mismatching_frames": bad, "placement": pipe.placement["chosen"],
+                  "upload_chunks_per_lane": a.chunks, "upload_streams_per_lane": a.streams_per_lane, "numa_binding": numa}))
 sys.stdout.flush()
 uploaded = released = None                 # events recorded on the lane streams go before the streams do
-del out, copy_streams
+del out, copy_streams, extra_streams
 torch.cuda.synchronize()
 pipe.close()
 pipe2.close()

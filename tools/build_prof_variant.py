@@ -38,7 +38,8 @@ def patch_source(s, which):
     elif which == "describe":
         rep("constexpr int DESC_KPW = 4;", DECL + "constexpr int DESC_KPW = 4;")
         rep("    const int32_t* counts = b.level_count + frame * MAX_LEVELS;", INIT + "    const int32_t* counts = b.level_count + frame * MAX_LEVELS;")
-        rep("    __syncthreads();\n    if (quad == 0 && lane == 0) {", "    PROF(0);\n    __syncthreads();\n    PROF(1);\n    if (quad == 0 && lane == 0) {")
+        rep("    if (!ORBX_DESC_LATE_BARRIER) __syncthreads();\n    if (quad == 0 && lane == 0) {", "    PROF(0);\n    if (!ORBX_DESC_LATE_BARRIER) __syncthreads();\n    if (quad == 0 && lane == 0) {")
+        rep("    if (ORBX_DESC_LATE_BARRIER) {\n", "    PROF(1);\n    if (ORBX_DESC_LATE_BARRIER) {\n")
         rep("    // IC_Angle on the unblurred level (:705-706 run before the blur)\n", "    PROF(2);\n    // IC_Angle on the unblurred level (:705-706 run before the blur)\n")
         rep("    const float angle = fast_atan2_deg((float)m01, (float)m10);", "    PROF(3);\n    const float angle = fast_atan2_deg((float)m01, (float)m10);")
         rep("    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");            // the wave's window DMA has landed (issued before IC_Angle)\n",
@@ -56,7 +57,8 @@ def main(which):
         src = os.path.join(R, d)
         (shutil.copytree if os.path.isdir(src) else shutil.copy)(src, os.path.join(tmp, d))
     p = os.path.join(tmp, KERNELS)
-    open(p, "w").write(patch_source(open(p).read(), which))
+    patched = patch_source(open(p).read(), which)        # (read BEFORE the file is opened for writing)
+    open(p, "w").write(patched)
     lib = os.path.join(tmp, "orb_slam_amd/liborbx.so")
     if os.path.exists(lib):
         os.remove(lib)

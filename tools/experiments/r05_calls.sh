@@ -80,5 +80,26 @@ ORBX_OVERLAP=0 tools/exp_ab.sh c9ab head3:0 tree:0 head3:3 tree:3 2>&1 | tail -4
 for v in head3 tree; do lib=$R/build_variants/$v/liborbx.so; [ $v = tree ] && lib=$R/orb_slam_amd/liborbx.so
 ORBX_LIB=$lib timeout 200 python bench.py --family 0 --no-also --no-cpu-baseline --min-seconds 4 --parity sample | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v noise 4 lanes', d['value'], d['ms_per_step'])"; done
 ;;
+10) # PCIe-inclusive line: NUMA-local pinned buffers, chunked uploads on two upload streams per lane
+mkdir -p gpurun_out/c10
+numactl -H 2>/dev/null | head -4; cat /sys/bus/pci/devices/*/numa_node 2>/dev/null | sort | uniq -c | head -4
+for v in "" "--numa-bind" "--chunks 4 --streams-per-lane 2" "--numa-bind --chunks 4 --streams-per-lane 2" "--numa-bind --chunks 8 --streams-per-lane 2" "--numa-bind --outputs counts"; do
+  timeout 120 python tools/bench_pcie.py --steps 30 $v 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-50s %9.1f frames/s  %.3f ms  h2d %.1f GB/s d2h %.1f  bad %d  %s' % ('$v', d['value'], d['ms_per_step'], d['h2d_GBps'], d['d2h_GBps'], d['mismatching_frames'], d.get('numa_binding')))"
+done | tee gpurun_out/c10/pcie.txt
+;;
+11) # k_fast_cells workgroups walking 2 / 4 / 16 bands (grid-stride); k_describe's table barrier behind the window DMA issue
+mkdir -p gpurun_out/c11
+for v in fp4 dlb; do ORBX_LIB=$R/build_variants/$v/liborbx.so timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bench_shapes.py -x -q 2>&1 | tail -1; done
+ORBX_OVERLAP=0 tools/exp_ab.sh c11ab tree:1 fp2:1 fp4:1 fp16:1 dlb:1 tree:1 tree:4 fp4:4 tree:1:hd1080 fp4:1:hd1080 dlb:1:hd1080 2>&1 | tail -12
+for v in tree fp4 dlb; do lib=$R/build_variants/$v/liborbx.so; [ $v = tree ] && lib=$R/orb_slam_amd/liborbx.so
+ORBX_LIB=$lib timeout 200 python bench.py --no-also --no-cpu-baseline --min-seconds 4 --parity sample | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v blocks 4 lanes', d['value'], d['ms_per_step'])"; done
+;;
+12) # k_describe's prologue: pattern word requested first (dep), barrier behind the patch loads (dlb2 / dep2), keypoints + counts + status by scalar loads (dsc1, dsc = + dep)
+mkdir -p gpurun_out/c12
+for v in dep2 dsc; do ORBX_LIB=$R/build_variants/$v/liborbx.so timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bench_shapes.py tests/test_golden.py -x -q 2>&1 | tail -1; done
+ORBX_OVERLAP=0 tools/exp_ab.sh c12ab tree:1 dep:1 dlb2:1 dep2:1 dsc1:1 dsc:1 tree:1 tree:1:hd1080 dep2:1:hd1080 dsc:1:hd1080 2>&1 | tail -12
+for v in tree dep2 dsc; do lib=$R/build_variants/$v/liborbx.so; [ $v = tree ] && lib=$R/orb_slam_amd/liborbx.so
+ORBX_LIB=$lib timeout 200 python bench.py --no-also --no-cpu-baseline --min-seconds 4 --parity sample | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v blocks 4 lanes', d['value'], d['ms_per_step'])"; done
+;;
 *) echo "usage: $0 <call number>"; exit 2 ;;
 esac

@@ -31,7 +31,7 @@ v = v[v[:, 10] == 1].astype(np.float64)
 names = ["entry->DMA issued", "DMA wait (vmcnt 0)", "barrier after staging", "dense rounds", "drain (expand+score)", "barrier before NMS", "NMS", "barrier after NMS",
          "list output"]
 if os.environ.get("PROF_KERNEL") == "describe":
-    names = ["entry->tables built", "barrier", "keypoint wait + window DMA issue", "IC_Angle (patch loads + sums)", "atan2 + sincos", "window DMA wait", "16 BRIEF tests",
+    names = ["entry->tables built", "scalar loads landed + window DMA issue", "tables' barrier (behind the DMA issue since round 5)", "IC_Angle (patch loads + sums)", "atan2 + sincos", "window DMA wait", "16 BRIEF tests",
              "bit transpose", "-"]
 def show(tag, r):
     m = r[:, :9].mean(0); tot = m.sum()
