@@ -101,5 +101,10 @@ ORBX_OVERLAP=0 tools/exp_ab.sh c12ab tree:1 dep:1 dlb2:1 dep2:1 dsc1:1 dsc:1 tre
 for v in tree dep2 dsc; do lib=$R/build_variants/$v/liborbx.so; [ $v = tree ] && lib=$R/orb_slam_amd/liborbx.so
 ORBX_LIB=$lib timeout 200 python bench.py --no-also --no-cpu-baseline --min-seconds 4 --parity sample | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v blocks 4 lanes', d['value'], d['ms_per_step'])"; done
 ;;
+13) # wave-life profiles of the round-5 k_describe / k_fast_cells (instrumented builds: tools/build_prof_variant.py describe | fast)
+mkdir -p gpurun_out/c13
+PROF_KERNEL=describe ORBX_LIB=$R/build_variants/profd/liborbx.so timeout 200 python tools/fast_prof.py 1 > gpurun_out/c13/describe_wave_phases.txt 2>&1; head -12 gpurun_out/c13/describe_wave_phases.txt
+ORBX_LIB=$R/build_variants/prof/liborbx.so timeout 200 python tools/fast_prof.py 1 > gpurun_out/c13/fast_wave_phases.txt 2>&1; head -12 gpurun_out/c13/fast_wave_phases.txt
+;;
 *) echo "usage: $0 <call number>"; exit 2 ;;
 esac
