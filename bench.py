@@ -833,6 +833,28 @@ def main():
             else:
                 bad += int(r["config"].get("parity_mismatches", 0))
                 also[key] = r
+    # The JSON line must be the LAST line of the job's stdout.  RCCL writes to the C-level stdout ("Librccl path ...": buffered by libc, it
+    # surfaced BEHIND the line when the process exited — tests/test_gpu_bench.py::test_rccl_path_at_world_size_one), and under
+    # torch.distributed.run every rank shares rank 0's stdout.  So: every rank flushes libc's buffers, the other ranks then close their
+    # stdout for good, a barrier, the communicator is destroyed, and only then rank 0 prints — and closes its stdout behind the line too.
+    def c_flush():
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+
+    def close_stdout():
+        c_flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+
+    c_flush()
+    if rank != 0:
+        close_stdout()
+    if dist is not None:
+        dist_util.barrier(dist, a.backend, local_rank)
+        dist.destroy_process_group()
     if rank == 0:
         # full reports first (lines that do not start with "{"), the compact line LAST: it is the one JSON line of this run
         print_detail("headline", out)
@@ -842,9 +864,9 @@ def main():
         if a.detail_file:
             with open(a.detail_file, "w") as f:
                 json.dump(dict(out, also=also, line=json.loads(line)), f)
+        c_flush()
         print(line, flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+        close_stdout()
     if bad:                 # every rank: the mismatch counters were summed over the ranks
         sys.stderr.write("bench.py: %d outputs differ from the oracle (config.parity_detail)\n" % bad)
         sys.exit(1)

@@ -106,5 +106,10 @@ mkdir -p gpurun_out/c13
 PROF_KERNEL=describe ORBX_LIB=$R/build_variants/profd/liborbx.so timeout 200 python tools/fast_prof.py 1 > gpurun_out/c13/describe_wave_phases.txt 2>&1; head -12 gpurun_out/c13/describe_wave_phases.txt
 ORBX_LIB=$R/build_variants/prof/liborbx.so timeout 200 python tools/fast_prof.py 1 > gpurun_out/c13/fast_wave_phases.txt 2>&1; head -12 gpurun_out/c13/fast_wave_phases.txt
 ;;
+14) # the bench tests after the change that keeps the JSON line last when RCCL writes to the C-level stdout
+mkdir -p gpurun_out/c14
+(time timeout 900 python -m pytest tests/test_gpu_bench.py -x -q) > gpurun_out/c14/pytest.txt 2>&1; tail -4 gpurun_out/c14/pytest.txt
+timeout 300 python bench.py --gpus 1 --backend nccl --force-dist --steps 2 --warmup 1 --batch 128 --ring 256 --min-seconds 0.2 --no-also --no-cpu-baseline > gpurun_out/c14/rccl.stdout 2> gpurun_out/c14/rccl.err; tail -c 300 gpurun_out/c14/rccl.stdout; echo; grep -c . gpurun_out/c14/rccl.stdout; grep -v "^{\|^#detail" gpurun_out/c14/rccl.stdout | head -3
+;;
 *) echo "usage: $0 <call number>"; exit 2 ;;
 esac
