@@ -192,7 +192,7 @@ def cpu_baseline_allcores(w, h, nfeat, do_match, seconds):
 def load_replayed_counters(build_id, traffic_file="traffic.json"):
     """profiles/traffic.json (rocprofv3 --pmc passes over the serial command) and profiles/valu_mix.json (static opcode mix) carry
     the hash of the kernel sources they were measured on; they are used only when it equals the loaded library's."""
-    out = {"traffic": None, "mix": None, "note": None}
+    out = {"traffic": None, "mix": None, "note": None, "clock": None}
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))
         if tj.get("src_hash") == build_id:
@@ -205,6 +205,14 @@ def load_replayed_counters(build_id, traffic_file="traffic.json"):
         mj = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
         if mj.get("src_hash") == build_id:
             out["mix"] = mj["kernels"]
+    except Exception:
+        pass
+    try:
+        # the shader clock every hot kernel actually holds (tools/run_pmc_clock.sh -> profiles/clock.json): the issue rooflines are priced at
+        # the nominal 2.4 GHz AND at that clock; only the long dispatches give a usable figure (values above nominal are dropped)
+        cj = json.load(open(os.path.join(ROOT, "profiles", "clock.json")))
+        if cj.get("src_hash") == build_id:
+            out["clock"] = cj
     except Exception:
         pass
     return out
@@ -454,13 +462,22 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
         mix = dict(mix, blur=mix["blur_valu"])         # levels wider than 1024 px keep the VALU form of the blur (k_blur), VGA-class ones run k_blur_mfma
         if "fast_cells_large" in mix:
             mix["fast_cells"] = mix["fast_cells_large"]    # ... and the large launch shape of k_fast_cells (two dwords per lane and round)
+    stage_kernel = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "blur": "k_blur" if wl_tag == "hd_1920x1080_nf2000" else "k_blur_mfma",
+                    "describe": "k_describe", "match": "k_match_batch_mfma", "cell_select": "k_cell_select", "level_select": "k_level_select", "quota": "k_quota"}
+    clocks = (rep["clock"] or {}).get("hd" if wl_tag == "hd_1920x1080_nf2000" else "vga", {}) if wl_tag else {}
+
+    def clock_ghz(stage):          # measured shader clock under this kernel, GHz (nominal 2.4 where there is no usable measurement)
+        c = clocks.get(stage_kernel.get(stage, ""), 2.4)
+        return c if 1.0 < c <= 2.4 else 2.4
     if valu_launch and mix and dom in mix:
         cpi = mix[dom]["cycles_per_inst_lo"]
         ach = valu_launch / (stage_ms[dom] * 1e-3)
         peak = SIMD_CYCLES_PER_S / cpi
         roofline["valu_issue"] = {
             "bound": "valu_issue", "kernel": dom, "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-insts/s",
-            "frac": round(ach / peak, 4), "wave_insts_per_launch": int(valu_launch), "cycles_per_inst": cpi,
+            "frac": round(ach / peak, 4), "clock_ghz": clock_ghz(dom) if clocks else None,
+            "frac_at_clock": round(ach / (peak * clock_ghz(dom) / 2.4), 4) if clocks else None,
+            "wave_insts_per_launch": int(valu_launch), "cycles_per_inst": cpi,
             "pricing": "SQ_INSTS_VALU of the kernel (profiles/%s) priced with its static opcode mix (profiles/valu_mix.json): 2 cycles per "
                        "wave64 instruction for mov/add/sub/and/or/xor/bitop3/right shifts/f32 add-mul-fma, 4 for every other measured opcode "
                        "(profiles/r01_valu_issue_rates.txt, r02_valu_issue_rates2.txt)" % traffic_file}
@@ -518,6 +535,9 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
             "peak": round(SIMD_CYCLES_PER_S / (lo / n_inst) / 1e9, 2), "frac": round(value / world * lo / SIMD_CYCLES_PER_S, 4),
             "frac_range": [round(value / world * lo / SIMD_CYCLES_PER_S, 4), round(value / world * hi / SIMD_CYCLES_PER_S, 4)],
             "cycles_per_inst_range": [round(lo / n_inst, 3), round(hi / n_inst, 3)],
+            "frac_at_clock": round(value / world * sum(v * mix[k]["cycles_per_inst_lo"] / (256 * 4 * clock_ghz(k) * 1e9) for k, v in valu_insts.items()), 4) if clocks else None,
+            "clock_note": "frac prices every kernel's instructions at the nominal 2.4 GHz; frac_at_clock at the clock measured under that kernel "
+                          "(profiles/clock.json = tools/run_pmc_clock.sh on this build)" if clocks else None,
             "source": "whole step in the timed region: SQ_INSTS_VALU of every kernel per frame (profiles/traffic.json, same source hash as the library) "
                       "x measured frames/s per GPU; the match kernel's MFMA work is not VALU and not counted"}
     elif rep["note"]:
@@ -696,14 +716,14 @@ def compact_line(full, also=None):
                    "frames_per_launch", "pairs_per_launch", "frac_of_achievable"))
     ro.setdefault("traffic", None)
     if isinstance(r.get("valu_issue"), dict):
-        ro["valu_issue"] = _pick(r["valu_issue"], ("achieved", "peak", "unit", "frac", "clock_ghz"))
+        ro["valu_issue"] = _pick(r["valu_issue"], ("achieved", "peak", "unit", "frac", "clock_ghz", "frac_at_clock"))
     if isinstance(r.get("hbm"), dict):
         ro["hbm"] = _pick(r["hbm"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch"))
     out["roofline"] = ro
     if isinstance(full.get("roofline_pipeline"), dict):
         out["roofline_pipeline"] = _pick(full["roofline_pipeline"], ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step_serial"))
     if isinstance(full.get("roofline_valu"), dict):
-        out["roofline_valu"] = _pick(full["roofline_valu"], ("bound", "achieved", "peak", "unit", "frac", "clock_ghz"))
+        out["roofline_valu"] = _pick(full["roofline_valu"], ("bound", "achieved", "peak", "unit", "frac", "frac_at_clock"))
     if "stage_ms_per_step" in full:
         out["stage_ms_per_step"] = full["stage_ms_per_step"]
     for k in ("cpu_baseline", "cpu_baseline_reference_source", "cpu_baseline_allcores"):

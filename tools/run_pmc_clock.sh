@@ -8,4 +8,5 @@ S="--steps 3 --warmup 2 --lanes 1 --region-timing --no-cpu-baseline --min-second
 timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O -o vga -- python $R/bench.py $S > $O/vga.log 2>&1
 timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O -o hd -- python $R/bench.py $S --config hd1080 > $O/hd.log 2>&1
 python $R/tools/pmc_clock_table.py $O > $O/pmc_clock.txt
+python $R/tools/pmc_clock_json.py $O/pmc_clock.txt $R/profiles/clock.json && cp $R/profiles/clock.json $O/clock.json
 cat $O/pmc_clock.txt
