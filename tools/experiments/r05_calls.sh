@@ -111,5 +111,13 @@ mkdir -p gpurun_out/c14
 (time timeout 900 python -m pytest tests/test_gpu_bench.py -x -q) > gpurun_out/c14/pytest.txt 2>&1; tail -4 gpurun_out/c14/pytest.txt
 timeout 300 python bench.py --gpus 1 --backend nccl --force-dist --steps 2 --warmup 1 --batch 128 --ring 256 --min-seconds 0.2 --no-also --no-cpu-baseline > gpurun_out/c14/rccl.stdout 2> gpurun_out/c14/rccl.err; tail -c 300 gpurun_out/c14/rccl.stdout; echo; grep -c . gpurun_out/c14/rccl.stdout; grep -v "^{\|^#detail" gpurun_out/c14/rccl.stdout | head -3
 ;;
+15) # k_describe: the patch of levels >= 1 from dword-aligned addresses (36 bytes per row, three lanes x 12 bytes; masks and weights shifted instead of the data)
+mkdir -p gpurun_out/c15
+ORBX_LIB=$R/build_variants/dap/liborbx.so timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bench_shapes.py tests/test_golden.py -x -q 2>&1 | tail -2
+ORBX_LIB=$R/build_variants/dap/liborbx.so timeout 300 python tools/fuzz_batch.py 40 1502 2>/dev/null | tail -c 250; echo
+ORBX_OVERLAP=0 tools/exp_ab.sh c15ab tree:1 dap:1 tree:1 dap:1 tree:1:hd1080 dap:1:hd1080 tree:4 dap:4 2>&1 | tail -8
+for v in tree dap; do lib=$R/build_variants/$v/liborbx.so; [ $v = tree ] && lib=$R/orb_slam_amd/liborbx.so
+ORBX_LIB=$lib timeout 200 python bench.py --no-also --no-cpu-baseline --min-seconds 4 --parity sample | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v blocks 4 lanes', d['value'], d['ms_per_step'])"; done
+;;
 *) echo "usage: $0 <call number>"; exit 2 ;;
 esac
