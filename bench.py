@@ -661,6 +661,13 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
                 "hbm": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 6),
                         "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 6), "algorithmic_bytes_per_launch": a_match, "traffic": None},
                 "traffic": None}
+    if not mfma:
+        # what the xor + popcount form can issue at best on THIS chip: v_xor_b32 costs 2.61 and v_bcnt_u32_b32 4.08 cycles per wave64
+        # instruction per SIMD (profiles/r01_valu_issue_rates.txt), so the 8 + 8 instructions of 64 pairs take 53.5 cycles before the
+        # top-2 bookkeeping: 1024 SIMDs x 64 / 53.5 x 2.4 GHz.  (SURVEY 8d's 4.9e12 assumes one lane-operation per lane and clock.)
+        ceil = 1024 * 64 / (8 * 2.61 + 8 * 4.08) * 2.4e9 / 1e12
+        roofline["measured_issue_ceiling"] = {"peak": round(ceil, 3), "unit": "10^12 pairs/s", "frac": round(tops / ceil, 4),
+                                              "note": "8 v_xor (2.61 cycles) + 8 v_bcnt (4.08 cycles) per 64 pairs and SIMD at 2.4 GHz, top-2 bookkeeping not counted"}
     out = {
         "metric": "pairs/s Hamming top-2, %d x %d 256-bit descriptors" % (n, n),
         "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "repeats": repeats, "timed_steps": nsteps,
