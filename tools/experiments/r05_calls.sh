@@ -119,5 +119,13 @@ ORBX_OVERLAP=0 tools/exp_ab.sh c15ab tree:1 dap:1 tree:1 dap:1 tree:1:hd1080 dap
 for v in tree dap; do lib=$R/build_variants/$v/liborbx.so; [ $v = tree ] && lib=$R/orb_slam_amd/liborbx.so
 ORBX_LIB=$lib timeout 200 python bench.py --no-also --no-cpu-baseline --min-seconds 4 --parity sample | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v blocks 4 lanes', d['value'], d['ms_per_step'])"; done
 ;;
+16) # the final state: smoke(), the whole GPU suite, the default line (final bench.py: clock-priced rooflines, the line printed last)
+mkdir -p gpurun_out/c16
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+(time python -m pytest tests -m gpu -q) > gpurun_out/c16/pytest_gpu.txt 2>&1; grep "passed\|failed" gpurun_out/c16/pytest_gpu.txt
+(time timeout 600 python bench.py --detail-file gpurun_out/c16/bench.json > gpurun_out/c16/bench.stdout 2> gpurun_out/c16/bench.err) 2>&1 | grep real
+tail -1 gpurun_out/c16/bench.stdout > gpurun_out/c16/bench.line.json; wc -c gpurun_out/c16/bench.line.json
+python -c "import json; d=json.load(open('gpurun_out/c16/bench.line.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['valu_issue'], d['roofline_valu']); print({k:(v['value'], v['parity_mismatches']) for k,v in d['also_summary'].items()})"
+;;
 *) echo "usage: $0 <call number>"; exit 2 ;;
 esac
