@@ -127,5 +127,12 @@ python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tai
 tail -1 gpurun_out/c16/bench.stdout > gpurun_out/c16/bench.line.json; wc -c gpurun_out/c16/bench.line.json
 python -c "import json; d=json.load(open('gpurun_out/c16/bench.line.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['valu_issue'], d['roofline_valu']); print({k:(v['value'], v['parity_mismatches']) for k,v in d['also_summary'].items()})"
 ;;
+17) # a second, larger fuzz round on the final build (other seeds)
+mkdir -p gpurun_out/c17
+timeout 900 python tools/fuzz_parity.py 8000 6201 > gpurun_out/c17/fuzz_parity_8000.json 2>/dev/null; tail -c 250 gpurun_out/c17/fuzz_parity_8000.json; echo
+timeout 900 python tools/fuzz_batch.py 700 6202 > gpurun_out/c17/fuzz_batch_700.json 2>/dev/null; tail -c 250 gpurun_out/c17/fuzz_batch_700.json; echo
+timeout 900 python tools/fuzz_frontend.py 6000 6203 > gpurun_out/c17/fuzz_frontend_6000.json 2>/dev/null; tail -c 250 gpurun_out/c17/fuzz_frontend_6000.json; echo
+timeout 900 python tools/fuzz_match.py 3000 6204 > gpurun_out/c17/fuzz_match_3000.json 2>/dev/null; tail -c 250 gpurun_out/c17/fuzz_match_3000.json; echo
+;;
 *) echo "usage: $0 <call number>"; exit 2 ;;
 esac
