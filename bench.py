@@ -27,8 +27,8 @@ frames only): keypoints + descriptors byte for byte, top-2 match against the pre
 carries `config.parity_checked_frames` / `config.parity_mismatches`; a mismatch makes every rank exit 1.  The default run
 (`--config vga`) then also runs, for >= 1.5 s each with the same parity leg, and embeds under `also` (headline keys unchanged;
 `--no-also` skips them): BASELINE.json's other GPU configurations — `vga_extract` (configs[1]), `hd1080` (configs[2]; at N > 1 this
-is configs[3], one 1080p stream per GPU), `match100k` (configs[4]; `match100k_popcount` = the same through the xor + popcount kernels
-the north_star names) — and the headline configuration on the other synthetic
+is configs[3], one 1080p stream per GPU), `match100k` (configs[4], FP4 MFMA kernels; `match100k_int8` = the same through the int8 MFMA
+kernels of rounds 2-4, `match100k_popcount` = through the xor + popcount kernels the north_star names) — and the headline configuration on the other synthetic
 families, whose corner statistics (and therefore FAST / selection cost) differ: `vga_noise` (SURVEY 8d's worst case), `vga_midtex`
 (textured: several times more corners at threshold 7 than at 20, no fallback cells), `vga_lowtex` (every cell takes the fallback).
 """
@@ -48,6 +48,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0  # ... 6.29 TB/s measured (float4 copy)
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
 I8_MFMA_PEAK_TOPS = 5000.0   # dense int8 = 2x the 2.5 PFLOP/s bf16 dense peak (MI355X_MICROARCH.md, matrix-core table)
+FP4_MFMA_PEAK_TOPS = 10000.0  # dense FP4 (block-scaled MFMA) = 2x the int8 / FP8 rate (same table: ~10 PF dense, 9.1 measured)
 
 CONFIGS = {
     "vga": dict(width=640, height=480, nfeatures=1000, batch=1024, ring=2048, match=True, baseline_config=1),
@@ -463,7 +464,7 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
         if "fast_cells_large" in mix:
             mix["fast_cells"] = mix["fast_cells_large"]    # ... and the large launch shape of k_fast_cells (two dwords per lane and round)
     stage_kernel = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "blur": "k_blur" if wl_tag == "hd_1920x1080_nf2000" else "k_blur_mfma",
-                    "describe": "k_describe", "match": "k_match_batch_mfma", "cell_select": "k_cell_select", "level_select": "k_level_select", "quota": "k_quota"}
+                    "describe": "k_describe", "match": "k_match_batch_mfma4", "cell_select": "k_cell_select", "level_select": "k_level_select", "quota": "k_quota"}
     clocks = (rep["clock"] or {}).get("hd" if wl_tag == "hd_1920x1080_nf2000" else "vga", {}) if wl_tag else {}
 
     def clock_ghz(stage):          # measured shader clock under this kernel, GHz (nominal 2.4 where there is no usable measurement)
@@ -571,7 +572,8 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
     nq = (n + world - 1) // world
     q0 = rank * nq
     nq = max(0, min(nq, n - q0))
-    capi.set_match_path(getattr(a, "match_path", -1))          # -1: the process default (the MFMA kernels); 0: the xor + popcount kernels north_star names
+    capi.set_match_path(getattr(a, "match_path", -1))          # -1: the process default (the FP4 MFMA kernels); 0: the xor + popcount kernels north_star names; 1: int8 MFMA
+    path = capi.get_match_path()                               # the kernels in effect (environment default or the forced path): 0 / 1 / 2
     Qall = synth.descriptors(n, 1)
     Q = torch.from_numpy(Qall[q0:q0 + nq].copy()).to(dev)
     T = torch.from_numpy(synth.descriptors(n, 2)).to(dev)
@@ -641,18 +643,22 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
     a_match = 32 * (nq + n) + 12 * nq
     gbs = a_match / (kernel_ms * 1e-3) / 1e9
     tops = 2.0 * 256.0 * nq * n / (kernel_ms * 1e-3) / 1e12
-    mfma = os.environ.get("ORBX_MATCH_MFMA", "1") != "0" and getattr(a, "match_path", -1) != 0
+    mfma, fp4 = path != 0, path == 2
     if not mfma:
         # the popcount form: 8 x v_xor + 8 x v_bcnt per pair (accumulating form) = 16 lane-operations -> 7.9e13 / 16 = 4.9e12 pairs/s
         pps = float(nq) * n / (kernel_ms * 1e-3)
         tops, peak_override = pps / 1e12, 4.9
     else:
         peak_override = None
-    roofline = {"bound": "mfma" if mfma else "valu_issue", "kernel": "k_match_split_mfma" if mfma else "k_match_split",
-                "achieved": round(tops, 3 if peak_override else 1), "peak": peak_override or I8_MFMA_PEAK_TOPS,
-                "unit": "TOP/s (int8 multiply-accumulates x 2)" if mfma else "10^12 pairs/s (16 lane-operations per pair: 8 v_xor + 8 v_bcnt)",
-                "frac": round(tops / (peak_override or I8_MFMA_PEAK_TOPS), 4),
-                "peak_note": "dense int8 MFMA = 2 x the 2.5 PFLOP/s bf16 dense peak; tools/microbench/valu_rate2 measures 4470 TOP/s for v_mfma_i32_32x32x32_i8",
+    mfma_peak = FP4_MFMA_PEAK_TOPS if fp4 else I8_MFMA_PEAK_TOPS
+    roofline = {"bound": "mfma" if mfma else "valu_issue", "kernel": ("k_match_split_mfma4" if fp4 else "k_match_split_mfma") if mfma else "k_match_split",
+                "achieved": round(tops, 3 if peak_override else 1), "peak": peak_override or mfma_peak,
+                "unit": ("TOP/s (FP4 multiply-accumulates x 2)" if fp4 else "TOP/s (int8 multiply-accumulates x 2)") if mfma
+                        else "10^12 pairs/s (16 lane-operations per pair: 8 v_xor + 8 v_bcnt)",
+                "frac": round(tops / (peak_override or mfma_peak), 4),
+                "peak_note": ("dense FP4 through v_mfma_scale_f32_32x32x64_f8f6f4 = 2 x the int8 / FP8 dense peak (the guide measures 9.1 POP/s); the same call "
+                              "through the int8 kernels (ORBX_MATCH_MFMA=8) is priced against 5 POP/s" if fp4 else
+                              "dense int8 MFMA = 2 x the 2.5 PFLOP/s bf16 dense peak; tools/microbench/valu_rate2 measures 4470 TOP/s for v_mfma_i32_32x32x32_i8"),
                 "avg_launch_ms": round(kernel_ms, 4), "pairs_per_launch": float(nq) * n,
                 "per_call_ms": {"min": round(per_call[0], 4), "median": round(kernel_ms, 4), "max": round(per_call[-1], 4), "calls": len(per_call),
                                 "timed_region_average": round(region_ms, 4)},
@@ -672,7 +678,7 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
         "metric": "pairs/s Hamming top-2, %d x %d 256-bit descriptors" % (n, n),
         "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "repeats": repeats, "timed_steps": nsteps,
         "timed_seconds": round(tmax, 3), "ms_per_step": round(tmax / nsteps * 1e3, 4), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "i8 (+-1 encoded bits, i32 accumulate)" if mfma else "u32 xor + popcount", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": ("fp4 e2m1 (+-1 encoded bits, f32 accumulate, exact)" if fp4 else "i8 (+-1 encoded bits, i32 accumulate)") if mfma else "u32 xor + popcount", "data": "synthetic",
         "config": {"workload": "match100k: batched N-to-M descriptor match, %d x %d random 256-bit descriptors, dense top-2 (BASELINE.json configs[4])" % (n, n),
                    "queries_per_gpu": nq, "train_descriptors": n, "parallelism": "queries sharded by rank, train set replicated, no exchange",
                    "best_distance_checksum": int(counters[1]), "parity_checked_rows": int(counters[3]), "parity_mismatches": int(counters[4]),
@@ -841,13 +847,15 @@ def main():
         # configurations (--also-min-seconds, 6 s: the chip clocks down over the first seconds of a region).  At
         # N > 1 `hd1080` is configs[3] (one 1080p stream per GPU); the frame families add nothing to a scaling run and are skipped there.
         entries = [("vga_extract", "vga_extract", synth.BLOCKS, False), ("hd1080", "hd1080", synth.BLOCKS, True),
-                   ("match100k", "match100k", synth.BLOCKS, True), ("match100k_popcount", "match100k", synth.BLOCKS, False),
+                   ("match100k", "match100k", synth.BLOCKS, True), ("match100k_int8", "match100k", synth.BLOCKS, False),
+                   ("match100k_popcount", "match100k", synth.BLOCKS, False),
                    ("vga_noise", "vga", synth.NOISE, False), ("vga_midtex", "vga", synth.MIDTEX, False), ("vga_lowtex", "vga", synth.LOWTEX, False)]
         if world > 1:
             entries = [e for e in entries if e[0] in ("hd1080", "match100k")]
         for key, name, family, cpu in entries:
             a2 = argparse.Namespace(**vars(a))
-            a2.match_path = 0 if key == "match100k_popcount" else -1      # the uint64 x 4 xor + popcount kernels north_star names, beside the MFMA form
+            # beside the default (FP4 MFMA) form: the int8 MFMA kernels of rounds 2-4 and the uint64 x 4 xor + popcount kernels north_star names
+            a2.match_path = {"match100k_popcount": 0, "match100k_int8": 1}.get(key, -1)
             a2.config, a2.cpu_seconds, a2.cpu_allcores_seconds, a2.cpu_reference_seconds = name, a.also_cpu_seconds, 0.0, 0.0
             a2.min_seconds = a.also_match_min_seconds if name == "match100k" else a.also_min_seconds
             a2.batch = a2.ring = a2.width = a2.height = a2.nfeatures = None

@@ -140,9 +140,11 @@ int orbm_hamming256(const uint8_t* a, const uint8_t* b);
  * results of the train splits — is allocated and freed in stream order from a memory pool the library creates for itself
  * (hipMallocFromPoolAsync; the device's default pool is left as the host set it), so concurrent calls on different streams,
  * also from one host thread, never share a buffer).  nt < 2^22.
- * The kernels compute the distances on the matrix cores (int8 MFMA on +-1 encoded bits, exact); ORBX_MATCH_MFMA=0 in the
- * environment selects the xor + popcount kernels instead as the process default, orbm_debug_set_match_path() at run time
- * (same results; tests/test_gpu_matcher.py runs every case through both).
+ * The kernels compute the distances on the matrix cores, exactly: +-1 encoded bits through CDNA4's block-scaled FP4 MFMA
+ * (v_mfma_scale_f32_32x32x64_f8f6f4, f32 accumulate; the process default since round 5) or through the int8 MFMA
+ * (ORBX_MATCH_MFMA=8 in the environment); ORBX_MATCH_MFMA=0 selects the xor + popcount kernels instead, ORBX_MATCH_MFMA=4 names
+ * the default; orbm_debug_set_match_path() switches at run time (same results; tests/test_gpu_matcher.py runs every case
+ * through all three).  The FP4 form keeps train indices in 15 bits per scan: batch calls with cap > 32768 take the int8 form.
  * Alignment: 4 bytes for every descriptor array of every matcher entry point — what the reference's DescriptorDistance needs, which
  * reads a descriptor as 8 x int32 (src/ORBmatcher.cc:1796-1801).  ORBX_ERR_ARG otherwise. */
 int orbm_match_top2(const uint8_t* Q, int nq, const uint8_t* T, int nt,
@@ -173,8 +175,10 @@ int orbm_match_top2_segments_device(const uint8_t* dQ, int nq, const uint8_t* dT
                                     const int32_t* d_cand, int32_t* d_best_idx, int32_t* d_best, int32_t* d_second, void* stream);
 /* number of queries passing  best <= th && (float)best < ratio*(float)second  (host arrays) */
 int orbm_count_accepted(const int32_t* best, const int32_t* second, int nq, int th, float ratio);
-/* test hook: which kernels the dense top-2 calls use from now on in this process: -1 = default (environment), 0 = xor + popcount, 1 = MFMA */
+/* test hook: which kernels the dense top-2 calls use from now on in this process: -1 = default (environment), 0 = xor + popcount,
+ * 1 = int8 MFMA, 2 = FP4 MFMA; orbm_debug_get_match_path() = the path in effect (0 / 1 / 2) */
 int orbm_debug_set_match_path(int path);
+int orbm_debug_get_match_path(void);
 
 /* Device-memory helpers for hosts that do not want to include the HIP headers (a C or C++ translation unit of ORB_SLAM can
  * keep frames, keypoints, descriptors and the search structures resident on the GPU with these four calls and chain the

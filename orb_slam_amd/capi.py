@@ -32,6 +32,7 @@ EXPORTS = [
     "orbx_stream_wait_event", "orbx_device_copy_async", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
     "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element", "orbx_debug_geometry",
     "orbm_debug_set_match_path",
+    "orbm_debug_get_match_path",
 ]
 # include/orbf.h (Frame-side steps: undistortion, search grid, window query)
 EXPORTS_F = [
@@ -138,6 +139,7 @@ def lib():
         L.orbm_match_top2_masked_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp]
         L.orbm_count_accepted.argtypes = [vp, vp, ci, ci, cf]
         L.orbm_debug_set_match_path.argtypes = [ci]
+        L.orbm_debug_get_match_path.argtypes = []
         L.orbs_debug_set_buckets.argtypes = [ci]
         L.orbm_match_top2_segments.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci]
         L.orbm_match_top2_segments_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp]
@@ -373,8 +375,13 @@ def match_top2_batch_device(dQ, d_nq, dT, d_nt, nbatch, cap, d_idx, d_best, d_se
         raise OrbxError(rc, "orbm_match_top2_batch_device")
 
 
+def get_match_path():
+    """the dense top-2 kernels in effect: 0 xor + popcount, 1 int8 MFMA, 2 FP4 MFMA"""
+    return int(lib().orbm_debug_get_match_path())
+
+
 def set_match_path(path):
-    """test hook: -1 process default (ORBX_MATCH_MFMA), 0 xor + popcount kernels, 1 MFMA kernels"""
+    """test hook: -1 process default (ORBX_MATCH_MFMA = 0 / 8 / 4), 0 xor + popcount kernels, 1 int8 MFMA kernels, 2 FP4 MFMA kernels"""
     rc = lib().orbm_debug_set_match_path(path)
     if rc != ORBX_OK:
         raise OrbxError(rc, "orbm_debug_set_match_path")

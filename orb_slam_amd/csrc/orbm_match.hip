@@ -216,6 +216,26 @@ __device__ __forceinline__ void mfma_scan(const uint32_t* __restrict__ Qp, int n
     uint2* lut = reinterpret_cast<uint2*>(smem);                // lut[v]: byte j of the pair = bit j of v as +1 (0x01) / -1 (0xFF)   (queries)
     uint2* lut64 = lut + 256;                                   // lut64[v]: ... as +64 (0x40) / -64 (0xC0)                           (trains, looked up with ~v)
     uint8_t* tiles = smem + 4096;
+    const int ntiles = (t1 - t0 + 31) >> 5;
+    // Every global load of the prologue is requested before anything waits (round 5): the queries' 8 dwords per lane and tile and the
+    // first four train tiles, from CLAMPED indices instead of under `if (valid)` — queries past nq are never written, train rows past t1
+    // are masked by the last tile's chains, so what they hold does not matter.  (The guarded form compiled to one load + s_waitcnt
+    // vmcnt(0) + table lookups per dword: 32 dependent round trips in front of a workgroup's first MFMA — half the life of a
+    // workgroup of the per-frame batch form, which scans only 32 train tiles.)
+    uint32_t qraw[QT][8];
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) {
+        const int q = min(qblock0 + (wave * QT + qt) * 32 + n, nq - 1);
+#pragma unroll
+        for (int c = 0; c < 8; c++) qraw[qt][c] = Qp[(long long)q * 8 + c];
+    }
+    // expansion of one train dword per thread and tile: row m = tid / 8, dword wd = tid % 8 -> 32 bytes of -(+-1) (the lookup of ~byte)
+    const int m_st = tid >> 3, wd_st = tid & 7;
+    auto load_raw = [&](int tile_i) -> uint32_t {
+        return Tp[(long long)min(t0 + tile_i * 32 + m_st, t1 - 1) * 8 + wd_st];
+    };
+    uint32_t raw0 = 0, raw1 = 0, raw2 = 0, raw_next = 0;
+    if (ntiles > 0) { raw0 = load_raw(0); raw1 = load_raw(1); raw2 = load_raw(2); raw_next = load_raw(3); }
     {
         const uint32_t v = (uint32_t)tid;
         uint32_t lo = 0, hi = 0;
@@ -232,26 +252,16 @@ __device__ __forceinline__ void mfma_scan(const uint32_t* __restrict__ Qp, int n
     i32x4_t breg[QT][8];
 #pragma unroll
     for (int qt = 0; qt < QT; qt++) {
-        const int q = qblock0 + (wave * QT + qt) * 32 + n;
-        const bool qv = q < nq;
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-            const uint32_t w = qv ? Qp[(long long)q * 8 + c] : 0u;
-            const uint32_t h16 = (w >> (16 * kh)) & 0xFFFFu;
+            const uint32_t h16 = (qraw[qt][c] >> (16 * kh)) & 0xFFFFu;
             const uint2 e0 = lut[h16 & 255u], e1 = lut[h16 >> 8];
             breg[qt][c] = (i32x4_t){(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
         }
     }
     K1.a0 = K1.a1 = K1.a2 = K1.a3 = KEY_NONE;
     K2.a0 = K2.a1 = K2.a2 = K2.a3 = KEY_NONE;
-    const int ntiles = (t1 - t0 + 31) >> 5;
     if (ntiles <= 0) return;
-    // expansion of one train dword per thread and tile: row m = tid / 8, dword wd = tid % 8 -> 32 bytes of -(+-1) (the lookup of ~byte)
-    const int m_st = tid >> 3, wd_st = tid & 7;
-    auto load_raw = [&](int tile_i) -> uint32_t {
-        const int t = t0 + tile_i * 32 + m_st;
-        return t < t1 ? Tp[(long long)t * 8 + wd_st] : 0u;
-    };
     auto expand = [&](uint32_t raw, int buf) {
         const uint32_t x = ~raw;
         const uint2 a = lut64[x & 255u], bb = lut64[(x >> 8) & 255u], c = lut64[(x >> 16) & 255u], d = lut64[x >> 24];
@@ -285,10 +295,9 @@ __device__ __forceinline__ void mfma_scan(const uint32_t* __restrict__ Qp, int n
     // every 16-byte A operand read from LDS feeds four MFMAs instead of two, and the train-tile expansion and the barrier are paid
     // once per 32 MFMAs.  (Round 2 ran chunk-major with 2 x QT accumulator sets: QT = 2 was all that fitted.)
     static_assert(QT == 2 || QT == 4, "chains alternate accumulator sets by the parity of the query tile");
-    expand(load_raw(0), 0);
-    expand(load_raw(1), 1);
-    expand(load_raw(2), 2);
-    uint32_t raw_next = load_raw(3);
+    expand(raw0, 0);
+    expand(raw1, 1);
+    expand(raw2, 2);
     __syncthreads();
     i32x16_t accP, accQ;                                       // chain qt writes accP (qt even) or accQ (qt odd)
     i32x4_t areg[8];
@@ -435,6 +444,258 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ------------------------------------------------------------------------------------ Hamming by FP4 MFMA (round 5, gfx950 only)
+// The same scan on v_mfma_scale_f32_32x32x64_f8f6f4 with both operands in FP4 (E2M1): CDNA4's block-scaled matrix instruction runs
+// FP4 at twice the int8 rate (guide: 9.1 against 4.4 POP/s measured) and a bit costs a nibble instead of a byte — half the operand
+// registers (16 VGPRs per query tile), half the LDS bytes per train tile, half the expansion work.  Exact: bit b -> the nibble 0x2 | b << 3
+// (+1.0 / -1.0), trains looked up negated and given the block scale 2^(S-1) (E8M0 byte 126 + S; the queries' scale is 1), so the K = 256
+// dot product is 2^(S-1) (2 hamming - 256); with the accumulator of row i of the chunk started at 2^(S+7) + i the result is
+// hamming * 2^S + i: an integer below 2^24 (S <= 15), exact in f32, and ordered like its bit pattern.  S = idx_bits is chosen by the
+// host as the smallest that holds the chunk's indices (10 for a 1000-feature frame, 13 for the 100k x 100k chunks), i.e. the sums stay
+// well inside the 24-bit significand.
+//   Because the key carries the CHUNK-relative index, not a tile-local one, the running pair of a query tile lives across train tiles
+// in the key's own form (float bit patterns compared as u32): no per-tile widening and merging (14 VALU instructions per chain in the
+// int8 form), the accumulator's start is re-made per tile instead (16 v_add_f32 for QT chains).  Rows past the chunk's end start
+// 2^(S+9) higher — they lose against every real key and decode to "none".  Per chain: 4 MFMAs of ~35 cycles against 32 VALU
+// instructions (v_med3 + v_min per pair) — the two pipes are level now, where the int8 form left the VALU half idle.
+// Operand layout: the usual 32 x 32 one (lane l: row / column l % 32, K half l / 32; D as in the int8 form — the guide: D is
+// dtype-independent); WHICH 32 of the 64 K values a lane's 16 bytes are does not matter, both operands use the same map.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+constexpr int M4_PITCH = 144;                      // bytes per expanded train row in LDS (128 + 16: the 16-byte reads of 16 consecutive lanes cover all 64 banks)
+constexpr int M4_TILE_BYTES = 32 * M4_PITCH;
+constexpr int M4_LDS_BYTES = 1024 + 4 * M4_TILE_BYTES;     // byte -> 8 nibbles table + ring of four train tiles
+constexpr int M4_MAX_IDX_BITS = 15;                // hamming * 2^S + index < 2^24
+#ifndef ORBX_M4_QT
+#define ORBX_M4_QT 4
+#endif
+constexpr int M4_QT = ORBX_M4_QT;
+#ifndef ORBX_M4_WAVES
+#define ORBX_M4_WAVES 3                           // waves per SIMD the FP4 kernels are compiled for (= workgroups per CU): 168 VGPRs; 2 (194 VGPRs): +2...3 % time
+#endif
+#ifndef ORBX_M4_TWO_A_SETS
+#define ORBX_M4_TWO_A_SETS 1
+#endif
+
+// (by value: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index — clang takes the vector's address)
+__device__ __forceinline__ uint32_t key_of(float f) { return __float_as_uint(f); }
+
+__device__ __forceinline__ f32x16_t mfma_fp4(const i32x4_t& a, const i32x4_t& b, const f32x16_t& c, int scale_a, int scale_b) {
+    const i32x8_t a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0}, b8 = {b.x, b.y, b.z, b.w, 0, 0, 0, 0};      // FP4 reads the first four registers only
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, scale_a, 0, scale_b);
+}
+
+template <int QT>
+__device__ __forceinline__ void mfma4_scan(const uint32_t* __restrict__ Qp, int nq, int qblock0, const uint32_t* __restrict__ Tp, int t0, int t1,
+                                           int idx_bits, uint8_t* smem, Top2State& K1, Top2State& K2) {
+    static_assert(QT == 2 || QT == 4, "chains alternate accumulator sets by the parity of the query tile");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, kh = lane >> 5;
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);          // lut[v]: nibble j = bit j of v as +1.0 (0x2) / -1.0 (0xA)
+    uint8_t* tiles = smem + 1024;
+    const int ntiles = (t1 - t0 + 31) >> 5;
+    // every global load of the prologue first, from clamped indices (see mfma_scan): this lane's dword 2c + kh of each chunk of its QT queries
+    // and the first four train tiles
+    uint32_t qraw[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) {
+        const int q = min(qblock0 + (wave * QT + qt) * 32 + n, nq - 1);
+#pragma unroll
+        for (int c = 0; c < 4; c++) qraw[qt][c] = Qp[(long long)q * 8 + 2 * c + kh];
+    }
+    // expansion of one train dword per thread and tile: row m = tid / 8, dword wd = tid % 8 -> 16 bytes of nibbles of the NEGATED bits
+    const int m_st = tid >> 3, wd_st = tid & 7;
+    auto load_raw = [&](int tile_i) -> uint32_t {               // (rows past t1: any descriptor — they start 2^(S+9) higher and never win)
+        return Tp[(long long)min(t0 + tile_i * 32 + m_st, t1 - 1) * 8 + wd_st];
+    };
+    uint32_t raw0 = 0, raw1 = 0, raw2 = 0, raw_next = 0;
+    if (ntiles > 0) { raw0 = load_raw(0); raw1 = load_raw(1); raw2 = load_raw(2); raw_next = load_raw(3); }
+    {
+        const uint32_t v = (uint32_t)tid;
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) w |= (0x2u | (((v >> j) & 1u) << 3)) << (4 * j);
+        lut[tid] = w;
+    }
+    __syncthreads();
+    auto nibbles = [&](uint32_t w) -> i32x4_t {
+        return (i32x4_t){(int)lut[w & 255u], (int)lut[(w >> 8) & 255u], (int)lut[(w >> 16) & 255u], (int)lut[w >> 24]};
+    };
+    // B operands: QT x 4 chunks (K = 64: descriptor dwords 2c and 2c + 1, this lane's half is dword 2c + kh) x 16 bytes per lane
+    i32x4_t breg[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) breg[qt][c] = nibbles(qraw[qt][c]);
+    }
+    K1.a0 = K1.a1 = K1.a2 = K1.a3 = KEY_NONE;
+    K2.a0 = K2.a1 = K2.a2 = K2.a3 = KEY_NONE;
+    if (ntiles <= 0) return;
+    const int scale_a = (int)((uint32_t)(126 + idx_bits) * 0x01010101u), scale_b = 0x7F7F7F7F;      // E8M0: trains 2^(S-1), queries 1 (every byte: whichever the lane's block reads)
+    auto expand = [&](uint32_t raw, int buf) {
+        const i32x4_t e = nibbles(~raw);
+        *reinterpret_cast<uint4*>(tiles + buf * M4_TILE_BYTES + m_st * M4_PITCH + 16 * wd_st) = make_uint4((uint32_t)e.x, (uint32_t)e.y, (uint32_t)e.z, (uint32_t)e.w);
+    };
+    auto load_a = [&](const uint8_t* p) -> i32x4_t {
+        const uint4 av = *reinterpret_cast<const uint4*>(p);
+        return (i32x4_t){(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+    };
+    // accumulator start of the tile at chunk-relative row base `rel`: 2^(S+7) + rel + row(r, lane); rows at or past `lim` (the
+    // padded end of the chunk's last tile) 2^(S+9) higher.  (Sixteen adds of non-zero constants to start0 - 1: with row 0's "+ 0"
+    // folded away the compiler pairs the rest into v_pk_add_f32 at odd register offsets and moves every result into the tuple.)
+    const float start0 = (float)((1 << (idx_bits + 7)) + 4 * kh - 1), penalty = (float)(1 << (idx_bits + 9));
+    auto make_cin = [&](int rel, auto last_c, int lim) -> f32x16_t {
+        constexpr bool LAST = decltype(last_c)::value;
+        const float s = start0 + (float)rel;
+        f32x16_t c;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            c[r] = s + (float)(8 * (r / 4) + (r % 4) + 1);
+            if (LAST && rel + 8 * (r / 4) + (r % 4) + 4 * kh >= lim) c[r] += penalty;
+        }
+        return c;
+    };
+    expand(raw0, 0);
+    expand(raw1, 1);
+    expand(raw2, 2);
+    __syncthreads();
+    f32x16_t accP, accQ, cin;                                   // chain qt writes accP (qt even) or accQ (qt odd)
+#if ORBX_M4_TWO_A_SETS
+    i32x4_t aregA[4], aregB[4];                                 // A operands of the even / odd tiles (two sets: a single one is copied register by register at the loop head)
+#else
+    i32x4_t aregA[4];
+    i32x4_t (&aregB)[4] = aregA;
+#endif
+    const uint8_t* lane_tile = tiles + n * M4_PITCH + 16 * kh;
+#pragma unroll
+    for (int c = 0; c < 4; c++) aregA[c] = load_a(lane_tile + 32 * c);
+    // one chain: the 4 MFMAs of (tile, qt) into `acc`; in their shadow the previous chain's 16 keys `prv` enter the running pair
+    // (k1, k2) of ITS query tile (HAVE: there is one); REFILL: the other A set is loaded for the next tile under the tile's last chain
+    auto chain = [&](auto qc, const i32x4_t (&areg)[4], i32x4_t (&afill)[4], f32x16_t& acc, const f32x16_t& prv, auto have_c, uint32_t& k1, uint32_t& k2,
+                     bool refill, const uint8_t* next_tile) {
+        constexpr int qt = decltype(qc)::value;
+        constexpr bool HAVE = decltype(have_c)::value;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            acc = mfma_fp4(areg[c], breg[qt][c], c == 0 ? cin : acc, scale_a, scale_b);
+            __builtin_amdgcn_sched_barrier(0);
+            if (HAVE) {
+#pragma unroll
+                for (int r = 4 * c; r < 4 * c + 4; r++) top2_update(k1, k2, key_of(prv[r]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (refill) afill[c] = load_a(next_tile + 32 * c);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    // one tile: its QT chains; the first one takes in the keys of the last chain of the tile before (if any)
+    auto tile_pass = [&](int it, auto first_c, auto last_c, const i32x4_t (&areg)[4], i32x4_t (&afill)[4]) {
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;      // no tile before / the chunk's last tile
+        const uint8_t* next_tile = lane_tile + ((it + 1) & 3) * M4_TILE_BYTES;
+        cin = make_cin(it * 32, last_c, t1 - t0);
+        static_for<QT>([&](auto qc) {
+            constexpr int qt = decltype(qc)::value;
+            constexpr int pq = (qt + QT - 1) % QT;               // the chain before this one belongs to query tile pq
+            f32x16_t& acc = (qt & 1) ? accQ : accP;
+            const f32x16_t& prv = (qt & 1) ? accP : accQ;
+            const bool refill = !LAST && qt == QT - 1;
+            if constexpr (qt == 0 && FIRST) chain(qc, areg, afill, acc, prv, F{}, K1.at<pq>(), K2.at<pq>(), refill, next_tile);
+            else chain(qc, areg, afill, acc, prv, T{}, K1.at<pq>(), K2.at<pq>(), refill, next_tile);
+        });
+    };
+    auto advance = [&](int it) {                               // tile it + 3 into the ring, tile it + 4 requested
+        expand(raw_next, (it + 3) & 3);
+        raw_next = load_raw(it + 4);
+        __syncthreads();
+    };
+    if (ntiles == 1) tile_pass(0, T{}, T{}, aregA, aregB);
+    else {
+        tile_pass(0, T{}, F{}, aregA, aregB);
+        advance(0);
+        int it = 1;                                            // odd tiles read set B and fill A, even ones the other way round
+        for (; it + 2 < ntiles; it += 2) {
+            tile_pass(it, F{}, F{}, aregB, aregA);
+            advance(it);
+            tile_pass(it + 1, F{}, F{}, aregA, aregB);
+            advance(it + 1);
+        }
+        if (it + 1 < ntiles) {
+            tile_pass(it, F{}, F{}, aregB, aregA);
+            advance(it);
+            tile_pass(it + 1, F{}, T{}, aregA, aregB);
+        } else tile_pass(it, F{}, T{}, aregB, aregA);
+    }
+    {   // the last chain of the last tile: nothing left to overlap it with
+        const f32x16_t& prv = ((QT - 1) & 1) ? accQ : accP;
+#pragma unroll
+        for (int r = 0; r < 16; r++) top2_update(K1.at<QT - 1>(), K2.at<QT - 1>(), key_of(prv[r]));
+    }
+    // float keys -> (hamming << 22) | train index; lanes l and l + 32 hold the two row halves of the same query
+    const uint32_t none_from = __builtin_bit_cast(uint32_t, penalty), idx_mask = (1u << idx_bits) - 1u;
+    auto widen = [&](uint32_t k) -> uint32_t {
+        const uint32_t u = (uint32_t)__builtin_bit_cast(float, k);
+        return k >= none_from ? KEY_NONE : ((u >> idx_bits) << KEY_SHIFT) + (u & idx_mask) + (uint32_t)t0;
+    };
+    static_for<QT>([&](auto qc) {
+        constexpr int qt = decltype(qc)::value;
+        uint32_t& k1 = K1.at<qt>();
+        uint32_t& k2 = K2.at<qt>();
+        k1 = widen(k1);
+        k2 = widen(k2);
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)k1, 32, 64), o2 = (uint32_t)__shfl_xor((int)k2, 32, 64);
+        const uint32_t lo = min(k1, o1), hi = max(k1, o1);
+        k2 = min(hi, min(k2, o2));
+        k1 = lo;
+    });
+}
+
+template <int QT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORBX_M4_WAVES, ORBX_M4_WAVES))) void k_match_batch_mfma4(const uint32_t* __restrict__ Q, const int32_t* __restrict__ nqs, const uint32_t* __restrict__ T,
+                                                           const int32_t* __restrict__ nts, int cap, int idx_bits, int32_t* __restrict__ idx, int32_t* __restrict__ best,
+                                                           int32_t* __restrict__ second) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int prob = blockIdx.y;
+    const int nq = min(nqs[prob], cap), nt = min(nts[prob], cap);
+    const int qblock0 = blockIdx.x * (128 * QT);
+    if (qblock0 >= nq) return;
+    Top2State K1, K2;
+    mfma4_scan<QT>(Q + (long long)prob * cap * 8, nq, qblock0, T + (long long)prob * cap * 8, 0, nt, idx_bits, smem, K1, K2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 32) {
+        static_for<QT>([&](auto qc) {
+            constexpr int qt = decltype(qc)::value;
+            const int q = qblock0 + (wave * QT + qt) * 32 + lane;
+            if (q < nq) {
+                const long long o = (long long)prob * cap + q;
+                write_result(K1.at<qt>(), K2.at<qt>(), idx + o, best + o, second + o);
+            }
+        });
+    }
+}
+
+template <int QT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORBX_M4_WAVES, ORBX_M4_WAVES))) void k_match_split_mfma4(const uint32_t* __restrict__ Q, int nq, const uint32_t* __restrict__ T, int nt, int chunk, int idx_bits,
+                                                           uint32_t* __restrict__ pk1, uint32_t* __restrict__ pk2) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int qblock0 = blockIdx.x * (128 * QT);
+    const int t0 = blockIdx.y * chunk, t1 = min(nt, t0 + chunk);
+    Top2State K1, K2;
+    mfma4_scan<QT>(Q, nq, qblock0, T, t0, t1, idx_bits, smem, K1, K2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 32) {
+        static_for<QT>([&](auto qc) {
+            constexpr int qt = decltype(qc)::value;
+            const int q = qblock0 + (wave * QT + qt) * 32 + lane;
+            if (q < nq) {
+                pk1[(long long)blockIdx.y * nq + q] = K1.at<qt>();
+                pk2[(long long)blockIdx.y * nq + q] = K2.at<qt>();
+            }
+        });
+    }
+}
+
 // Candidate-set form (what every ORBmatcher search really scans: the grid window of GetFeaturesInArea or the features of
 // one vocabulary node): query q scans the train descriptors cand[seg_off[q] .. seg_off[q+1]) IN LIST ORDER.  One wave per
 // query, one candidate per lane and step; key = (distance << 22) | position-in-list keeps the reference's "first candidate
@@ -545,19 +806,36 @@ int orbm_count_accepted(const int32_t* best, const int32_t* second, int nq, int 
     return n;
 }
 
-// ORBX_MATCH_MFMA=0 selects the xor + popcount kernels (the A/B baseline of the MFMA form) as the process default;
-// orbm_debug_set_match_path() overrides it per process at run time (the parity tests run both forms in one process).
-static std::atomic<int> g_match_path{-1};        // -1: environment default, 0: xor + popcount, 1: MFMA
-static bool use_mfma() {
-    static const bool env_default = [] { const char* e = getenv("ORBX_MATCH_MFMA"); return !(e && e[0] == '0'); }();
+// Which kernels the dense top-2 calls use: 0 = xor + popcount (the form north_star names; the A/B baseline), 1 = int8 MFMA, 2 = FP4 MFMA
+// (round 5).  Process default: ORBX_MATCH_MFMA = 0 / 8 / 4 in the environment, otherwise ORBX_MATCH_DEFAULT_PATH;
+// orbm_debug_set_match_path() overrides it per process at run time (the parity tests run all forms in one process).
+#ifndef ORBX_MATCH_DEFAULT_PATH
+#define ORBX_MATCH_DEFAULT_PATH 2
+#endif
+static std::atomic<int> g_match_path{-1};        // -1: environment default
+static int match_path() {
+    static const int env_default = [] {
+        const char* e = getenv("ORBX_MATCH_MFMA");
+        if (!e || !e[0]) return ORBX_MATCH_DEFAULT_PATH;
+        return e[0] == '0' ? 0 : e[0] == '8' ? 1 : e[0] == '4' ? 2 : ORBX_MATCH_DEFAULT_PATH;
+    }();
     const int f = g_match_path.load(std::memory_order_relaxed);
-    return f < 0 ? env_default : f != 0;
+    return f < 0 ? env_default : f;
 }
 
 int orbm_debug_set_match_path(int path) {
-    if (path < -1 || path > 1) return ORBX_ERR_ARG;
+    if (path < -1 || path > 2) return ORBX_ERR_ARG;
     g_match_path.store(path, std::memory_order_relaxed);
     return ORBX_OK;
+}
+
+int orbm_debug_get_match_path(void) { return match_path(); }
+
+// index bits of the FP4 form's keys for chunks of `chunk` train descriptors (whole tiles): the smallest S >= 5 with chunk <= 2^S; 0 = too long
+static int m4_idx_bits(int chunk) {
+    const int padded = (chunk + 31) / 32 * 32;
+    for (int s = 5; s <= orbx::M4_MAX_IDX_BITS; s++) if (padded <= (1 << s)) return s;
+    return 0;
 }
 
 // compute units of the current device (cached per host thread and device)
@@ -572,6 +850,16 @@ static int device_cus() {
         cached_dev = dev;
     }
     return cus;
+}
+
+// workgroups of the FP4 split kernel a CU holds (registers and LDS decide; asked of the runtime once)
+static int m4_wgs_per_cu() {
+    static const int n = [] {
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, orbx::k_match_split_mfma4<orbx::M4_QT>, 256, orbx::M4_LDS_BYTES) != hipSuccess || blocks < 1) { (void)hipGetLastError(); blocks = 2; }
+        return blocks;
+    }();
+    return n;
 }
 
 // Scratch of the split form (partial top-2 per train split): stream-ordered allocation from a PRIVATE memory pool per device (round 4;
@@ -621,20 +909,22 @@ int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
     if (nq < 0 || nt < 0 || nt >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
     if (nq == 0) return ORBX_OK;
     if (((uintptr_t)dQ & 3) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
-    const bool mfma = use_mfma();
-    constexpr int QPL = 2, QT = MF_QT;                        // popcount form: 2 queries per lane; MFMA form: QT query tiles per wave
-    const int q_per_block = mfma ? 128 * QT : MATCH_BLOCK * QPL;
+    const int path = match_path();
+    const bool mfma = path != 0, fp4 = path == 2;
+    constexpr int QPL = 2, QT = MF_QT, QT4 = M4_QT;          // popcount form: 2 queries per lane; MFMA forms: QT query tiles per wave
+    const int q_per_block = fp4 ? 128 * QT4 : mfma ? 128 * QT : MATCH_BLOCK * QPL;
     const int qblocks = (nq + q_per_block - 1) / q_per_block;
     // enough workgroups to fill 256 CUs several times over, but chunks of >= 256 train descriptors
     const int target_wgs = mfma ? 2048 : 4096;
     int nsplit = std::max(1, std::min((nt + 255) / 256, (target_wgs + qblocks - 1) / qblocks));
     if (mfma) {
-        // The MFMA workgroups run two per CU and take as long as their chunk is, so the launch proceeds in rounds of 2 x CUs
-        // workgroups: a split count that leaves the last round nearly empty wastes it (100k x 100k: 196 query blocks x 11 splits =
-        // 4.2 rounds took 1.69 ms, x 13 = 4.98 rounds 1.62 ms, x 8 = 3.06 rounds 1.81 ms).  Cost model: rounds x tiles per chunk, in
-        // the neighbourhood of the target; the smallest split count among the best wins (less to merge).
-        const int slots = 2 * device_cus();
-        const int lo = std::max(1, nsplit / 2), hi = std::max(1, std::min((nt + 255) / 256, 2 * nsplit));
+        // The MFMA workgroups run two (FP4 form: m4_wgs_per_cu()) per CU and take as long as their chunk is, so the launch proceeds in
+        // rounds of that many x CUs workgroups: a split count that leaves the last round nearly empty wastes it (100k x 100k: 196 query
+        // blocks x 11 splits = 4.2 rounds took 1.69 ms, x 13 = 4.98 rounds 1.62 ms, x 8 = 3.06 rounds 1.81 ms).  Cost model: rounds x
+        // tiles per chunk, in the neighbourhood of the target; the smallest split count among the best wins (less to merge).
+        const int slots = (fp4 ? m4_wgs_per_cu() : 2) * device_cus();
+        const int floor_ns = fp4 ? (nt + (1 << M4_MAX_IDX_BITS) - 1) >> M4_MAX_IDX_BITS : 1;      // FP4 keys: at most 2^15 train descriptors per chunk
+        const int lo = std::max(std::max(1, floor_ns), nsplit / 2), hi = std::max(lo, std::min((nt + 255) / 256, 2 * nsplit));
         long best_cost = LONG_MAX;
         for (int ns = lo; ns <= hi; ++ns) {
             const long rounds = ((long)qblocks * ns + slots - 1) / slots, tiles = ((nt + ns - 1) / ns + 31) / 32;
@@ -645,6 +935,8 @@ int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
     int chunk = nt > 0 ? (nt + nsplit - 1) / nsplit : 1;
     if (mfma) chunk = (chunk + 31) / 32 * 32;                // whole train tiles
     nsplit = nt > 0 ? (nt + chunk - 1) / chunk : 1;
+    const int idx_bits = fp4 ? m4_idx_bits(chunk) : 0;
+    if (fp4 && idx_bits == 0) return ORBX_ERR_DEVICE;        // (cannot happen: floor_ns bounds the chunk)
     // Partial (k1, k2) per (split, query): stream-ordered allocation, so calls on different streams never share a buffer and the
     // call stays asynchronous (the free is queued behind the merge kernel).
     const size_t need = (size_t)2 * nsplit * nq * sizeof(uint32_t);
@@ -656,8 +948,10 @@ int orbm_match_top2_device(const uint8_t* dQ, int nq, const uint8_t* dT, int nt,
         return ORBX_ERR_DEVICE;
     }
     uint32_t* pk2 = pk1 + (size_t)nsplit * nq;
-    if (mfma) hipLaunchKernelGGL(k_match_split_mfma<QT>, dim3(qblocks, nsplit), dim3(256), MF_LDS_BYTES, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt,
-                                 chunk, pk1, pk2);
+    if (fp4) hipLaunchKernelGGL(k_match_split_mfma4<QT4>, dim3(qblocks, nsplit), dim3(256), M4_LDS_BYTES, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt,
+                                chunk, idx_bits, pk1, pk2);
+    else if (mfma) hipLaunchKernelGGL(k_match_split_mfma<QT>, dim3(qblocks, nsplit), dim3(256), MF_LDS_BYTES, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt,
+                                      chunk, pk1, pk2);
     else hipLaunchKernelGGL(k_match_split<QPL>, dim3(qblocks, nsplit), dim3(MATCH_BLOCK), 0, stream, (const uint32_t*)dQ, nq, (const uint32_t*)dT, nt,
                             chunk, pk1, pk2);
     int rc = hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
@@ -680,7 +974,14 @@ int orbm_match_top2_batch_device(const uint8_t* dQ, const int32_t* d_nq, const u
     if (nbatch < 0 || cap < 1 || cap >= (1 << KEY_SHIFT)) return ORBX_ERR_ARG;
     if (nbatch == 0) return ORBX_OK;
     if (((uintptr_t)dQ & 3) || ((uintptr_t)dT & 3)) return ORBX_ERR_ARG;
-    if (use_mfma()) {
+    const int path = match_path();
+    if (path == 2 && m4_idx_bits(cap) != 0) {                    // FP4 keys hold 2^15 train indices; larger capacities take the int8 form
+        constexpr int QT = M4_QT;
+        hipLaunchKernelGGL(k_match_batch_mfma4<QT>, dim3((cap + 128 * QT - 1) / (128 * QT), nbatch), dim3(256), M4_LDS_BYTES, stream, (const uint32_t*)dQ, d_nq,
+                           (const uint32_t*)dT, d_nt, cap, m4_idx_bits(cap), d_best_idx, d_best, d_second);
+        return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+    }
+    if (path != 0) {
         constexpr int QT = MF_QT;                                // 512 queries per workgroup: two workgroups per ~1000-feature frame
         hipLaunchKernelGGL(k_match_batch_mfma<QT>, dim3((cap + 128 * QT - 1) / (128 * QT), nbatch), dim3(256), MF_LDS_BYTES, stream, (const uint32_t*)dQ, d_nq,
                            (const uint32_t*)dT, d_nt, cap, d_best_idx, d_best, d_second);

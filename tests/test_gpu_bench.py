@@ -105,9 +105,12 @@ def test_default_line_carries_every_baseline_config():
     assert mt["unit"] == "pairs/s" and mt["roofline"]["bound"] == "mfma" and mt["cpu_baseline"]["value"] > 0
     assert mt["roofline"]["per_call_ms"]["calls"] == 30 and mt["roofline"]["per_call_ms"]["min"] <= mt["roofline"]["avg_launch_ms"]
     assert mt["config"]["parity_checked_rows"] >= 50 and mt["config"]["parity_mismatches"] == 0
-    pc = d["also"]["match100k_popcount"]
-    assert pc["roofline"]["bound"] == "valu_issue" and pc["roofline"]["kernel"] == "k_match_split" and 0 < pc["value"] < mt["value"]
-    assert pc["config"]["parity_mismatches"] == 0 and pc["config"]["best_distance_checksum"] == mt["config"]["best_distance_checksum"]
+    assert mt["roofline"]["kernel"] == "k_match_split_mfma4" and mt["roofline"]["peak"] == 10000.0 and mt["dtype"].startswith("fp4")      # the default form (round 5)
+    pc, i8 = d["also"]["match100k_popcount"], d["also"]["match100k_int8"]
+    assert pc["roofline"]["bound"] == "valu_issue" and pc["roofline"]["kernel"] == "k_match_split" and 0 < pc["value"] < i8["value"] < mt["value"]
+    assert i8["roofline"]["bound"] == "mfma" and i8["roofline"]["kernel"] == "k_match_split_mfma" and i8["roofline"]["peak"] == 5000.0 and i8["dtype"].startswith("i8")
+    for o in (pc, i8):
+        assert o["config"]["parity_mismatches"] == 0 and o["config"]["best_distance_checksum"] == mt["config"]["best_distance_checksum"]
 
 
 def test_single_rank_configs_and_min_duration():

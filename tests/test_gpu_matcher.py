@@ -7,13 +7,13 @@ from orb_slam_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 
-PATHS = {"mfma": 1, "popcount": 0}
+PATHS = {"mfma": 1, "mfma_fp4": 2, "popcount": 0}
 
 
 @pytest.fixture(params=sorted(PATHS))
 def match_path(request):
-    """Every dense top-2 case runs through both kernel families the library ships: the int8 MFMA form (default) and the
-    xor + popcount form `north_star` describes (ORBX_MATCH_MFMA=0) — selected at run time through the C ABI's test hook."""
+    """Every dense top-2 case runs through the three kernel families the library ships: the FP4 and the int8 MFMA forms and the
+    xor + popcount form `north_star` describes (ORBX_MATCH_MFMA=4 / 8 / 0) — selected at run time through the C ABI's test hook."""
     capi.set_match_path(PATHS[request.param])
     yield request.param
     capi.set_match_path(-1)
@@ -97,6 +97,32 @@ def test_batch_device(match_path):
         assert (o[:, i, nq[i]:] == -7).all()          # nothing written past nq
 
 
+@pytest.mark.parametrize("cap,nq,nt", [(20000, 300, 19997), (32768, 40, 32768), (40000, 33, 39999)])
+def test_batch_long_train_lists(cap, nq, nt, match_path):
+    """One problem with a long train list.  The FP4 form's keys are hamming * 2^S + index in an f32 accumulator: S = 15 (the largest:
+    sums up to 2^23 + 2^15) at 20000 and 32768 entries, and past 2^15 entries the call takes the int8 kernels.  Extremes planted: exact
+    matches (hamming 0), complements (hamming 256), repeated rows at the far end of the list (first index wins)."""
+    torch = pytest.importorskip("torch")
+    Q, T = synth.descriptors(cap, 31 + cap), synth.descriptors(cap, 32 + cap)
+    Q[0] = T[nt - 1]                                     # distance 0 at the last index
+    Q[1] = ~T[nt - 2]                                    # distance 256 to one entry
+    T[nt - 40:nt:3] = T[5]                               # repeated rows: the first index attains the best distance
+    Q[2] = T[5]
+    Q[3] = 0; Q[4] = 255
+    dQ, dT = torch.from_numpy(Q).cuda(), torch.from_numpy(T).cuda()
+    dnq, dnt = torch.tensor([nq], dtype=torch.int32, device="cuda"), torch.tensor([nt], dtype=torch.int32, device="cuda")
+    out = torch.full((3, cap), -7, dtype=torch.int32, device="cuda")
+    capi.match_top2_batch_device(dQ.data_ptr(), dnq.data_ptr(), dT.data_ptr(), dnt.data_ptr(), 1, cap,
+                                 out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    ri, rb, rs = orc.match_top2(Q[:nq], T[:nt])
+    np.testing.assert_array_equal(o[0, :nq], ri)
+    np.testing.assert_array_equal(o[1, :nq], rb)
+    np.testing.assert_array_equal(o[2, :nq], rs)
+    assert (o[:, nq:] == -7).all()
+
+
 def test_full_size_properties(match_path):
     """100k x 100k (BASELINE config 5) is too slow for the scalar oracle; check size-independent properties:
     self-match (best=0 at own index when descriptors are unique) and agreement with the oracle on a query sample."""
@@ -125,14 +151,15 @@ def test_full_size_every_row_against_the_oracle():
     Q[::4999] = T[40000:40000 + len(Q[::4999])]        # exact matches (distance 0)
     Q[7::9973] = T[123]                                 # best = 0 with multiplicity: second = 0
     gi, gb, gs = capi.match_top2(Q, T)
-    capi.set_match_path(0)                              # the xor + popcount kernels on the same problem (the oracle scan runs once)
-    try:
-        pi, pb, ps = capi.match_top2(Q, T)
-    finally:
-        capi.set_match_path(-1)
-    np.testing.assert_array_equal(pi, gi)
-    np.testing.assert_array_equal(pb, gb)
-    np.testing.assert_array_equal(ps, gs)
+    for other in (0, 1, 2):                             # the xor + popcount, int8 MFMA and FP4 MFMA kernels on the same problem (the oracle scan runs once)
+        capi.set_match_path(other)
+        try:
+            pi, pb, ps = capi.match_top2(Q, T)
+        finally:
+            capi.set_match_path(-1)
+        np.testing.assert_array_equal(pi, gi)
+        np.testing.assert_array_equal(pb, gb)
+        np.testing.assert_array_equal(ps, gs)
     try:
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
         cores = int(float(q) / float(p)) if q != "max" else len(os.sched_getaffinity(0))

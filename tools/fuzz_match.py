@@ -74,7 +74,7 @@ kinds = {"dense": 0, "batch": 0, "segments": 0}
 t0 = time.time()
 st = torch.cuda.current_stream().cuda_stream
 for c in range(cases):
-    path = int(rng.random() < 0.75)                                        # 1 = MFMA (the default), 0 = xor + popcount
+    path = int(rng.choice([0, 1, 2, 2]))                                   # 2 = FP4 MFMA, 1 = int8 MFMA, 0 = xor + popcount
     capi.set_match_path(path)
     mode = rng.choice(["dense", "dense", "batch", "segments"])
     kinds[str(mode)] += 1
