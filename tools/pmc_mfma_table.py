@@ -23,7 +23,8 @@ for tag in ("m100k", "batch"):
                 dur[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
     for n, c in sorted(acc.items()):
         m = {k: sum(v) / len(v) for k, v in c.items()}
-        mfma, busy = m.get("SQ_INSTS_VALU_MFMA_I8", 0.0), m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        fp4 = m.get("SQ_INSTS_VALU_MFMA_F6F4", 0.0) > 0          # the FP4 kernels (v_mfma_scale_f32_32x32x64_f8f6f4: twice the K, twice the peak)
+        mfma, busy = m.get("SQ_INSTS_VALU_MFMA_F6F4" if fp4 else "SQ_INSTS_VALU_MFMA_I8", 0.0), m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         if not mfma:
             continue
         active = m.get("GRBM_GUI_ACTIVE", 0.0) / XCDS
@@ -37,5 +38,7 @@ for tag in ("m100k", "batch"):
             split = "GRBM_GUI_ACTIVE spans more than this short dispatch (no MfmaUtil / clock split)"
         else:
             split = "MfmaUtil %.3f at a shader clock of %.2f GHz" % (util, clk * 1e-9)
-        print("    MFMA busy cycles per v_mfma_i32_32x32x32_i8: %.1f;  %s;  busy cycles / (1024 SIMDs x duration x 2.4 GHz) = %.3f of the int8 peak;"
-              "  VALU instructions per MFMA (all classes, the MFMAs included) %.2f" % (busy / mfma, split, frac, m.get("SQ_INSTS_VALU", 0.0) / mfma))
+        print("    MFMA busy cycles per %s: %.1f;  %s;  busy cycles / (1024 SIMDs x duration x 2.4 GHz) = %.3f of the %s peak;"
+              "  VALU instructions per MFMA (all classes, the MFMAs included) %.2f;  VALU busy (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles at 2.4 GHz) %.3f" %
+              ("v_mfma_scale_f32_32x32x64_f8f6f4 (FP4)" if fp4 else "v_mfma_i32_32x32x32_i8", busy / mfma, split, frac, "FP4" if fp4 else "int8",
+               m.get("SQ_INSTS_VALU", 0.0) / mfma, m.get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (SIMDS * t * 2.4e9) if t else 0.0))
