@@ -29,6 +29,7 @@ timeout 300 python bench.py --region-timing $Q --detail-file $D/bench_region_tim
 timeout 300 python bench.py --config vga_extract $Q --detail-file $D/bench_extract_only.json > $D/bench_extract_only.line.json 2>/dev/null
 timeout 300 python bench.py --family 0 $Q --detail-file $D/bench_noise.json > $D/bench_noise.line.json 2>/dev/null
 ORBX_MATCH_MFMA=0 timeout 300 python bench.py --config match100k --no-cpu-baseline --min-seconds 2 --detail-file $D/bench_match100k_popcount.json > $D/bench_match100k_popcount.line.json 2>/dev/null
+ORBX_MATCH_MFMA=8 timeout 300 python bench.py --config match100k --no-cpu-baseline --min-seconds 2 --detail-file $D/bench_match100k_int8.json > $D/bench_match100k_int8.line.json 2>/dev/null
 timeout 600 python bench.py --gpus 2 --backend gloo --share-device --no-cpu-baseline --batch 512 --min-seconds 2 --also-min-seconds 1 --detail-file $D/bench_two_ranks_one_gpu_gloo.json > $D/bench_two_ranks_one_gpu_gloo.line.json 2>/dev/null
 timeout 200 python tools/corun_probe.py > $D/corun_probe.json 2>/dev/null
 (timeout 100 python tools/bench_single_frame.py; timeout 100 python tools/bench_single_frame.py 1920 1080 2000; timeout 100 orb_slam_amd/cpp/bench_single_frame; timeout 100 orb_slam_amd/cpp/bench_single_frame 1920 1080 2000) > $D/single_frame.txt 2>/dev/null

@@ -3,7 +3,7 @@
 orbm_match_top2_segments_device) against the sequential-scan oracle: random query / train sizes around every tile boundary of the
 kernels (32-row MFMA tiles, 128 / 256-query blocks, the train splits of large scans), empty sets, planted duplicates, exact matches
 and low-entropy descriptors (dense distance ties: first index and the multiplicity of the second-best must survive), arrays that
-start 4 bytes into their allocation, and both kernel families (int8 MFMA and xor + popcount).  Integer exact or it counts as bad.
+start 4 bytes into their allocation, and the three kernel families (FP4 MFMA, int8 MFMA, xor + popcount).  Integer exact or it counts as bad.
 usage: fuzz_match.py [cases] [seed]   — prints one JSON line."""
 import json, os, sys, time
 from concurrent.futures import ThreadPoolExecutor
