@@ -4,6 +4,7 @@ consecutive frames, each lane with its own extractor handle and HIP stream, ever
 Lanes never join.  The only cross-lane dependency is the one frame per lane whose predecessor lies in the lane to its left
 (lane 0: in the last lane's slice of the previous step): that frame's descriptors travel through a two-slot hand-off buffer
 ordered by HIP events.  torch is used for device memory, streams and events only."""
+import ctypes
 import os
 import time
 
@@ -63,9 +64,21 @@ class LanePipeline:
         handles = [capi.ORBextractor(nfeatures=nfeatures, device=device, max_batch=self.b, **extractor_kw) for _ in range(G)]
         self._raw_sets, self._spacers = [], []
         ncand = 3 if (G > 1 and (autotune or placement is not None)) else 1
+        # ORBX_LANE_PRIORITIES="p0,p1,..." (an experiment switch, NOTES.md 10.9): HIP stream priorities of the lanes, cyclically (-1 high, 0 normal, 1 low)
+        prios = [int(x) for x in os.environ.get("ORBX_LANE_PRIORITIES", "").split(",") if x.strip() != ""]
+
+        def lane_stream(g):
+            if not prios:
+                return capi.stream_create(device)
+            p = ctypes.c_void_p()
+            rc = capi.lib().orbx_stream_create_priority(device, prios[g % len(prios)], ctypes.byref(p))
+            if rc != capi.ORBX_OK:
+                raise capi.OrbxError(rc, "orbx_stream_create_priority")
+            return p.value
+
         for spacer in range(ncand):
             self._spacers += [capi.stream_create(device) for _ in range(spacer)]
-            self._raw_sets.append([capi.stream_create(device) for _ in range(G)])
+            self._raw_sets.append([lane_stream(g) for g in range(G)])
         self._sets = [[torch.cuda.ExternalStream(p, device=dev) for p in raw] for raw in self._raw_sets]
         chosen = min(placement, ncand - 1) if placement is not None else 0          # (one lane: a single candidate)
         self.lanes = [_Lane(handles[g], device, self.b, self._sets[chosen][g]) for g in range(G)]
