@@ -64,6 +64,8 @@ class LanePipeline:
         handles = [capi.ORBextractor(nfeatures=nfeatures, device=device, max_batch=self.b, **extractor_kw) for _ in range(G)]
         self._raw_sets, self._spacers = [], []
         ncand = 3 if (G > 1 and (autotune or placement is not None)) else 1
+        if ncand == 3 and os.environ.get("ORBX_LANE_CANDIDATES", "").isdigit():      # experiment switch (NOTES.md 10.9): more rotations against the side streams' queues
+            ncand = max(3, min(8, int(os.environ["ORBX_LANE_CANDIDATES"])))
         # ORBX_LANE_PRIORITIES="p0,p1,..." (an experiment switch, NOTES.md 10.9): HIP stream priorities of the lanes, cyclically (-1 high, 0 normal, 1 low)
         prios = [int(x) for x in os.environ.get("ORBX_LANE_PRIORITIES", "").split(",") if x.strip() != ""]
 
