@@ -230,6 +230,8 @@ def measure_live_traffic(frames_per_launch, timeout_s=150.0):
     rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rp):
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) or k == "HSA_TOOLS_LIB" for k in os.environ):
+        return None, "this run is itself under a profiler (its environment would reach the child runs)"
     stage = {"k_resize": "pyramid", "k_fast_cells": "fast_cells", "k_quota": "quota", "k_cell_select": "cell_select", "k_level_select": "level_select",
              "k_blur": "blur", "k_blur_mfma": "blur", "k_describe": "describe", "k_match_batch": "match", "k_match_batch_mfma": "match"}
     td = tempfile.mkdtemp(prefix="orbx_live_traffic_", dir="/tmp")
