@@ -9,7 +9,7 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -ffp-contract=off -mll
 ORBX_SRCS  := $(wildcard orb_slam_amd/csrc/*.hip)
 ORBX_HDRS  := $(wildcard orb_slam_amd/csrc/*.h orb_slam_amd/csrc/*.inc include/*.h)
 
-all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so oracle_ref orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/cpp/example_lanes orb_slam_amd/cpp/bench_single_frame tools/microbench/valu_rate tools/microbench/valu_rate2 tools/microbench/mfma_layout tools/microbench/mfma_valu_mix tools/microbench/fetch_calib tools/microbench/valu_exec_mask tools/microbench/ta_shapes
+all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so oracle_ref orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/cpp/example_lanes orb_slam_amd/cpp/bench_single_frame tools/microbench/valu_rate tools/microbench/valu_rate2 tools/microbench/mfma_layout tools/microbench/mfma_layout_fp4 tools/microbench/mfma_valu_mix tools/microbench/fetch_calib tools/microbench/valu_exec_mask tools/microbench/ta_shapes
 
 # the hash of the kernel sources travels inside the library (orbx_build_id): counters replayed by bench.py must come from THIS build
 SRC_HASH   := $(shell cat $(sort $(ORBX_SRCS) $(ORBX_HDRS)) | sha256sum | cut -c1-16)
@@ -50,6 +50,8 @@ tools/microbench/valu_rate2: tools/microbench/valu_rate2.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value $< -o $@
 tools/microbench/mfma_layout: tools/microbench/mfma_layout.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result $< -o $@
+tools/microbench/mfma_layout_fp4: tools/microbench/mfma_layout_fp4.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value $< -o $@
 tools/microbench/mfma_valu_mix: tools/microbench/mfma_valu_mix.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-result $< -o $@
 tools/microbench/fetch_calib: tools/microbench/fetch_calib.hip
@@ -61,7 +63,7 @@ tools/microbench/ta_shapes: tools/microbench/ta_shapes.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++20 -Wno-unused-value $< -o $@
 
 clean:
-	rm -f tools/microbench/valu_exec_mask tools/microbench/ta_shapes tools/microbench/valu_rate tools/microbench/valu_rate2 tools/microbench/mfma_layout tools/microbench/mfma_valu_mix tools/microbench/fetch_calib orb_slam_amd/cpp/bench_single_frame orb_slam_amd/cpp/example_lanes orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
+	rm -f tools/microbench/mfma_layout_fp4 tools/microbench/valu_exec_mask tools/microbench/ta_shapes tools/microbench/valu_rate tools/microbench/valu_rate2 tools/microbench/mfma_layout tools/microbench/mfma_valu_mix tools/microbench/fetch_calib orb_slam_amd/cpp/bench_single_frame orb_slam_amd/cpp/example_lanes orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
 	rm -rf oracle/_ref
 
 .PHONY: all clean oracle_ref
