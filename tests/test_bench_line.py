@@ -51,6 +51,35 @@ def test_compact_line_eight_ranks():
     assert len(line["per_rank"]["rows"]) == 8 and line["per_rank"]["columns"][0] == "rank"
 
 
+def test_compact_line_of_the_final_build_with_live_traffic():
+    """round 5's final shape: eight `also` rows (the int8 matcher line beside the FP4 and popcount ones), `roofline.traffic` measured in the run,
+    the step's total traffic in `roofline_pipeline` — one rank <= 4 KB, eight ranks <= 6 KB"""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05b_bench_live_traffic.json")))
+    also = d.pop("also")
+    d.pop("line", None)
+    line = bench.compact_line(d, also)
+    text = json.dumps(line)
+    assert len(text) <= 4096, len(text)
+    assert set(line["also_summary"]) == {"vga_extract", "hd1080", "match100k", "match100k_int8", "match100k_popcount", "vga_noise", "vga_midtex", "vga_lowtex"}
+    assert line["roofline"]["traffic_measured_in_this_run"] is True and line["roofline"]["traffic"] == d["roofline"]["traffic"]
+    assert line["roofline_pipeline"]["traffic"] == sum(d["traffic_per_stage_this_run"].values())
+    assert line["also_summary"]["match100k"]["roofline_bound"] == "mfma" and "roofline_bound" not in line["also_summary"]["hd1080"]       # "hbm" rows omit the key
+    d["n_gpus"] = 8
+    d["per_rank"] = [dict(copy.deepcopy(d["per_rank"][0]), rank=r, device=r) for r in range(8)]
+    assert len(json.dumps(bench.compact_line(d, {k: also[k] for k in ("hd1080", "match100k")}))) <= 6144
+
+
+def test_live_traffic_refuses_to_nest_under_a_profiler(monkeypatch):
+    """the child runs of `measure_live_traffic` would inherit a profiler's environment: the replayed table stays in the line then"""
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "x")
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        import pytest
+        pytest.skip("no rocprofv3 in this image")
+    lt, why = bench.measure_live_traffic(1024, timeout_s=1.0)
+    assert lt is None and "profiler" in why
+
+
 def test_match_report_compacts():
     _, also = _full()
     line = bench.compact_line(also["match100k"])
