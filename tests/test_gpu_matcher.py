@@ -123,6 +123,22 @@ def test_batch_long_train_lists(cap, nq, nt, match_path):
     assert (o[:, nq:] == -7).all()
 
 
+def test_many_queries_long_train_list(match_path):
+    """So many query blocks (> 2048) that the split heuristic would take the whole train list as ONE chunk — longer than the 2^15 entries the FP4
+    form's keys can index: the host splits it (`floor_ns`), S = 15.  Sampled rows against the oracle + the self-match property on planted rows."""
+    nq, nt = 1_060_000, 40_000
+    Q, T = synth.descriptors(nq, 91), synth.descriptors(nt, 92)
+    plant = np.arange(0, nq, 9973)
+    Q[plant] = T[(plant * 7) % nt]                       # exact matches, some of them in the second chunk
+    gi, gb, gs = capi.match_top2(Q, T)
+    assert (gb[plant] == 0).all()
+    sample = np.unique(np.concatenate([plant[:40], np.arange(0, nq, 26501), [nq - 1]]))
+    ri, rb, rs = orc.match_top2(Q[sample], T)
+    np.testing.assert_array_equal(gi[sample], ri)
+    np.testing.assert_array_equal(gb[sample], rb)
+    np.testing.assert_array_equal(gs[sample], rs)
+
+
 def test_full_size_properties(match_path):
     """100k x 100k (BASELINE config 5) is too slow for the scalar oracle; check size-independent properties:
     self-match (best=0 at own index when descriptors are unique) and agreement with the oracle on a query sample."""
