@@ -199,6 +199,13 @@ int orbx_event_destroy(int device, void* event);
 int orbx_event_record(void* event, void* stream);
 int orbx_stream_wait_event(void* stream, void* event);
 int orbx_device_copy_async(void* d_dst, const void* d_src, size_t bytes, void* stream);    /* device to device */
+/* Pinned host memory and stream-ordered copies: what a host-side caller with small per-call inputs needs to keep one search at
+ * two copies + its launches + ONE synchronisation (orb_slam_amd/cpp/ORBmatcher.cc stages every search through one pinned block).
+ * h_src / h_dst should come from orbx_host_alloc (pageable memory works but the copy then blocks the calling thread). */
+int orbx_host_alloc(int device, size_t bytes, void** h_ptr);        /* hipHostMalloc */
+int orbx_host_free(int device, void* h_ptr);
+int orbx_device_upload_async(void* d_dst, const void* h_src, size_t bytes, void* stream);
+int orbx_device_download_async(void* h_dst, const void* d_src, size_t bytes, void* stream);
 
 /* MapPoint::ComputeDistinctiveDescriptors for M map points at once (src/MapPoint.cc:216-244): point p owns the descriptors
  * [seg_off[p], seg_off[p+1]) of `desc`; best_idx[p] = the index INSIDE its segment of the descriptor whose sorted row of

@@ -59,6 +59,7 @@ public:
     size_t elemSize() const { return type_ == CV_32F ? 4 : 1; }
     int type() const { return type_; }
     bool empty() const { return data == 0 || rows == 0 || cols == 0; }
+    bool isContinuous() const { return step == (size_t)cols * elemSize(); }
 
     Mat view(int r0, int r1, int c0, int c1) const {
         Mat m(*this);

@@ -77,12 +77,57 @@ int index_of(const std::vector<MapPoint*>& owner, MapPoint* p) {
     for (size_t i = 0; i < owner.size(); i++) if (owner[i] == p) return (int)i;
     return -2;
 }
+
+// The pose every projection-based entry point below gives its frame / key frame (default: identity, which is what the CPU pin tests
+// reproduce in plain float arithmetic).  tests/test_gpu_orbmatcher_dropin.py moves it (ref_set_pose / ref_set_sim3) to run the
+// reference's and the product's projection code at a general pose; the two libraries are then compared with each other only.
+float g_Rt[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, g_scale = 1.0f;        // R (row major), t; Scw = g_scale * [R|t]
+float g_simRt[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, g_sim_scale = 1.0f;  // SearchBySim3's R12, t12, s12
+cv::Mat pose_R(const float* Rt = g_Rt) {
+    cv::Mat R(3, 3, CV_32F);
+    for (int i = 0; i < 9; i++) R.at<float>(i / 3, i % 3) = Rt[i];
+    return R;
+}
+cv::Mat pose_t(const float* Rt = g_Rt) {
+    cv::Mat t(3, 1, CV_32F);
+    for (int i = 0; i < 3; i++) t.at<float>(i) = Rt[9 + i];
+    return t;
+}
+cv::Mat pose_centre() {                        // Ow = -R' t
+    cv::Mat o(3, 1, CV_32F);
+    for (int c = 0; c < 3; c++) {
+        double acc = 0;
+        for (int r = 0; r < 3; r++) acc += (double)g_Rt[3 * r + c] * g_Rt[9 + r];
+        o.at<float>(c) = (float)(0.0 - acc);
+    }
+    return o;
+}
+cv::Mat pose_44(float scale) {                 // [scale*R | scale*t; 0 0 0 1]
+    cv::Mat T(4, 4, CV_32F);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) T.at<float>(r, c) = scale * g_Rt[3 * r + c];
+        T.at<float>(r, 3) = scale * g_Rt[9 + r];
+    }
+    T.at<float>(3, 3) = 1.0f;
+    return T;
+}
 }  // namespace
 
 float Frame::fx = 0, Frame::fy = 0, Frame::cx = 0, Frame::cy = 0;
 int Frame::mnMinX = 0, Frame::mnMaxX = 0, Frame::mnMinY = 0, Frame::mnMaxY = 0;
 
 extern "C" {
+
+void ref_set_pose(const float* Rt, float scale) {
+    static const float I[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    memcpy(g_Rt, Rt ? Rt : I, sizeof(g_Rt));
+    g_scale = Rt ? scale : 1.0f;
+}
+void ref_set_sim3(const float* Rt, float scale) {
+    static const float I[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    memcpy(g_simRt, Rt ? Rt : I, sizeof(g_simRt));
+    g_sim_scale = Rt ? scale : 1.0f;
+}
 
 void ref_matcher_three_maxima(const int32_t* sizes, int L, int32_t* ind) {
     std::vector<std::vector<int> > h(L);
@@ -187,8 +232,7 @@ int ref_search_by_projection_last_frame(const void* bounds, float ratio, int che
     C.mvKeysUn = kp_vec(kps_un2, n2); C.mDescriptors = desc_mat(desc2, n2);
     C.mvScaleFactors.assign(scale_factors, scale_factors + nlevels); C.mnScaleLevels = nlevels;
     fill_grid(C.grid, bounds, cell_off2, cell_feat2, n2);
-    C.mTcw = cv::Mat(4, 4, CV_32F);
-    for (int i = 0; i < 4; i++) C.mTcw.at<float>(i, i) = 1.0f;
+    C.mTcw = pose_44(1.0f);
     MapPoint old;
     C.mvpMapPoints.assign(n2, (MapPoint*)0);
     for (int i = 0; i < n2; i++) if (claimed2 && claimed2[i]) C.mvpMapPoints[i] = &old;
@@ -220,8 +264,7 @@ int ref_search_by_projection_two_frames(const void* bounds, float ratio, const f
     F1.mvKeysUn = kp_vec(kps_un1, n1); F1.mDescriptors = desc_mat(desc1, n1);
     F2.mvKeysUn = kp_vec(kps_un2, n2); F2.mDescriptors = desc_mat(desc2, n2);
     fill_grid(F2.grid, bounds, cell_off2, cell_feat2, n2);
-    F2.mTcw = cv::Mat(4, 4, CV_32F);
-    for (int i = 0; i < 4; i++) F2.mTcw.at<float>(i, i) = 1.0f;
+    F2.mTcw = pose_44(1.0f);
     MapPoint old;
     F2.mvpMapPoints.assign(n2, (MapPoint*)0);
     for (int i = 0; i < n2; i++) if (claimed2 && claimed2[i]) F2.mvpMapPoints[i] = &old;
@@ -253,8 +296,7 @@ int ref_search_by_projection_keyframe(const void* bounds, int check, float th, i
     C.mvKeysUn = kp_vec(kps_un2, n2); C.mDescriptors = desc_mat(desc2, n2);
     C.mvScaleFactors.assign(scale_factors, scale_factors + nlevels); C.mnScaleLevels = nlevels;
     fill_grid(C.grid, bounds, cell_off2, cell_feat2, n2);
-    C.mTcw = cv::Mat(4, 4, CV_32F);
-    for (int i = 0; i < 4; i++) C.mTcw.at<float>(i, i) = 1.0f;
+    C.mTcw = pose_44(1.0f);
     MapPoint old;
     C.mvpMapPoints.assign(n2, (MapPoint*)0);
     for (int i = 0; i < n2; i++) if (claimed2 && claimed2[i]) C.mvpMapPoints[i] = &old;
@@ -361,8 +403,7 @@ void identity_keyframe(KeyFrame& k, const void* bounds, const float* cam, const 
     k.scaleFactors.assign(scale_factors, scale_factors + nlevels);
     k.fx = cam[0]; k.fy = cam[1]; k.cx = cam[2]; k.cy = cam[3];
     k.minX = bb.min_x; k.maxX = bb.max_x; k.minY = bb.min_y; k.maxY = bb.max_y;
-    k.Rcw = cv::Mat(3, 3, CV_32F); k.tcw = cv::Mat(3, 1, CV_32F); k.Ow = cv::Mat(3, 1, CV_32F);
-    for (int i = 0; i < 3; i++) k.Rcw.at<float>(i, i) = 1.0f;
+    k.Rcw = pose_R(); k.tcw = pose_t(); k.Ow = pose_centre();
 }
 std::vector<MapPoint*> query_points(std::deque<MapPoint>& pool, const uint8_t* state, const float* world, const float* mindist, const uint8_t* desc, int nq) {
     std::vector<MapPoint*> q(nq, (MapPoint*)0);
@@ -400,8 +441,7 @@ int ref_search_by_projection_scw(const void* bounds, int th, const float* cam, c
     int slot = 0;
     for (int i = 0; i < nq; i++) if (qstate[i] == 3) { while (slot < nKF && !claimed[slot]) slot++; if (slot < nKF) matched[slot++] = q[i]; }
     std::vector<MapPoint*> before = matched;
-    cv::Mat Scw(4, 4, CV_32F);
-    for (int i = 0; i < 4; i++) Scw.at<float>(i, i) = 1.0f;
+    cv::Mat Scw = pose_44(g_scale);
     ORBmatcher matcher(0.75f, true);
     const int n = matcher.SearchByProjection(&kf, Scw, q, matched, th);
     for (int i = 0; i < nKF; i++) t2q[i] = before[i] ? -2 : index_of(q, matched[i]);
@@ -424,8 +464,7 @@ int ref_fuse(int which, const void* bounds, float th, const float* cam, const fl
     int n;
     if (which == 0) n = matcher.Fuse(&kf, q, th);
     else {
-        cv::Mat Scw(4, 4, CV_32F);
-        for (int i = 0; i < 4; i++) Scw.at<float>(i, i) = 1.0f;
+        cv::Mat Scw = pose_44(g_scale);
         std::vector<MapPoint*> q2;
         for (MapPoint* p : q) if (p) q2.push_back(p);               // this overload does not accept NULL entries
         n = matcher.Fuse(&kf, Scw, q2, th);
@@ -453,8 +492,7 @@ int ref_search_by_sim3(const void* bounds, float th, const float* cam, const flo
         k.scaleFactors.assign(scale_factors, scale_factors + nlevels);
         k.fx = cam[0]; k.fy = cam[1]; k.cx = cam[2]; k.cy = cam[3];
         k.minX = bb.min_x; k.maxX = bb.max_x; k.minY = bb.min_y; k.maxY = bb.max_y;
-        k.Rcw = cv::Mat(3, 3, CV_32F); k.tcw = cv::Mat(3, 1, CV_32F);
-        for (int i = 0; i < 3; i++) k.Rcw.at<float>(i, i) = 1.0f;
+        k.Rcw = pose_R(); k.tcw = pose_t();
         k.mapPoints = map_points(pool, state, n);
         for (int i = 0; i < n; i++) if (k.mapPoints[i]) {
             MapPoint& m = *k.mapPoints[i];
@@ -467,11 +505,10 @@ int ref_search_by_sim3(const void* bounds, float th, const float* cam, const flo
     KeyFrame k1, k2;
     make(k1, kps1, desc1, cell_off1, cell_feat1, state1, world1, mindist1, n1);
     make(k2, kps2, desc2, cell_off2, cell_feat2, state2, world2, mindist2, n2);
-    cv::Mat R12(3, 3, CV_32F), t12(3, 1, CV_32F);
-    for (int i = 0; i < 3; i++) R12.at<float>(i, i) = 1.0f;
+    cv::Mat R12 = pose_R(g_simRt), t12 = pose_t(g_simRt);
     std::vector<MapPoint*> m12(n1, (MapPoint*)0);
     ORBmatcher matcher(0.75f, true);
-    const float s12 = 1.0f;
+    const float s12 = g_sim_scale;
     const int n = matcher.SearchBySim3(&k1, &k2, m12, s12, R12, t12, th);
     for (int i = 0; i < n1; i++) match12[i] = index_of(k2.mapPoints, m12[i]);
     return n;

@@ -29,7 +29,7 @@ EXPORTS = [
     "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbm_distinctive", "orbm_distinctive_device",
     "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_device_download",
     "orbx_stream_create", "orbx_stream_create_priority", "orbx_stream_destroy", "orbx_stream_synchronize", "orbx_event_create", "orbx_event_destroy", "orbx_event_record",
-    "orbx_stream_wait_event", "orbx_device_copy_async", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
+    "orbx_stream_wait_event", "orbx_device_copy_async", "orbx_host_alloc", "orbx_host_free", "orbx_device_upload_async", "orbx_device_download_async", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
     "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element", "orbx_debug_geometry",
     "orbm_debug_set_match_path",
     "orbm_debug_get_match_path",

@@ -1,26 +1,77 @@
-// ORB_SLAM::ORBmatcher — the part of the reference class that is on the hot path (reference
-// include/ORBmatcher.h:41-44,:90-92 and the scan loop shared by all its searches), on the MI355X C ABI.
-// The 11 Frame/KeyFrame/MapPoint search methods keep living in ORB-SLAM's host code (they walk Map objects
-// under mutexes: out of scope); INTEGRATION.md shows how their inner loops call MatchTop2.
+// ORB_SLAM::ORBmatcher on the MI355X C ABI — the reference's class surface (reference include/ORBmatcher.h:41-103): the
+// constructor, DescriptorDistance, the thirteen Frame / KeyFrame / MapPoint searches with the reference's signatures, the three
+// thresholds.  The searches are DEFINED in ORBmatcher.cc: each does on the host what only the host can do — walk the MapPoint /
+// Frame / KeyFrame objects, project, test visibility, pick radius and level range (the reference's own cv::Mat expressions, so the
+// floats are the reference's) — and hands the scan (best / second-best over the grid window or the vocabulary node, the in-order
+// "already matched" masking, the accept rule, the rotation histogram) to the kernels behind include/orbs.h, then writes the
+// result back where the reference writes it.
+//
+// Two ways to use this header:
+//   * inside ORB_SLAM (drop-in for include/ORBmatcher.h + src/ORBmatcher.cc): the SLAM headers are on the include path and are
+//     pulled in below exactly as the reference header does; compile ORBmatcher.cc into the project, link liborbx.so;
+//   * stand-alone (examples, the dense / candidate-list forms MatchTop2*): without MapPoint.h / KeyFrame.h / Frame.h on the include
+//     path the three classes are only forward-declared; the thirteen searches are then declared but not linkable.
 #pragma once
 #include <climits>
+#include <set>
 #include <stdexcept>
+#include <utility>
 #include <vector>
 
 #include "cvcompat.h"
 #include "orbx.h"
 
+#if defined(__has_include)
+#if __has_include("MapPoint.h") && __has_include("KeyFrame.h") && __has_include("Frame.h")
+#include "MapPoint.h"
+#include "KeyFrame.h"
+#include "Frame.h"
+#define ORBMATCHER_HAS_SLAM_TYPES 1
+#endif
+#endif
+
 namespace ORB_SLAM {
+
+class MapPoint;
+class KeyFrame;
+class Frame;
 
 class ORBmatcher {
 public:
+    // reference include/ORBmatcher.h:41; `device` = the GPU the searches run on (one process per GPU: 0)
     ORBmatcher(float nnratio = 0.6, bool checkOri = true, int device = 0) : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device) {}
 
-    // Computes the Hamming distance between two ORB descriptors (reference src/ORBmatcher.cc:1794-1810)
+    // Computes the Hamming distance between two ORB descriptors (reference :44, src/ORBmatcher.cc:1794-1810)
     static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b) { return orbm_hamming256(a.ptr<unsigned char>(), b.ptr<unsigned char>()); }
 
-    // Dense form of the best / second-best scan every search shares (e.g. reference src/ORBmatcher.cc:201-222):
-    // for each row of Q (N x 32, CV_8U) the two smallest distances over all rows of T, first index on ties.
+    // ---- the thirteen searches, signatures of reference include/ORBmatcher.h:48-88 (defined in ORBmatcher.cc) ----
+    // Tracking: local map -> frame (src/ORBmatcher.cc:48-125)
+    int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3);
+    // Tracking: last frame -> current frame (:1507-1619)
+    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, float th);
+    // Relocalisation: key frame -> frame (:1622-1746)
+    int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, float th, int ORBdist);
+    // Loop closing: map points through a similarity into a key frame (:286-407)
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th);
+    // Same vocabulary node, key frame -> frame (:155-281) and key frame -> key frame (:715-850)
+    int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
+    int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
+    // Window around the position in frame 1 (:408-516); the same behind a pose guess (:519-594)
+    int WindowSearch(Frame& F1, Frame& F2, int windowSize, std::vector<MapPoint*>& vpMapPointMatches2, int minOctave = -1, int maxOctave = INT_MAX);
+    int SearchByProjection(Frame& F1, Frame& F2, int windowSize, std::vector<MapPoint*>& vpMapPointMatches2);
+    // Map initialisation (:596-713)
+    int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10);
+    // New map points: epipolar constraint (:852-1014)
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<cv::KeyPoint>& vMatchedKeys1,
+                               std::vector<cv::KeyPoint>& vMatchedKeys2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs);
+    // Loop closing: both directions through [s12*R12|t12] (:1267-1505)
+    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12, float th);
+    // Duplicate map points (:1016-1134, :1136-1265)
+    int Fuse(KeyFrame* pKF, std::vector<MapPoint*>& vpMapPoints, float th = 2.5);
+    int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th = 2.5);
+
+    // ---- dense / candidate-list forms of the scan every search shares (not in the reference class) ----
+    // For each row of Q (N x 32, CV_8U) the two smallest distances over all rows of T, first index on ties (e.g. src/ORBmatcher.cc:201-222).
     void MatchTop2(const cv::Mat& Q, const cv::Mat& T, std::vector<int>& bestIdx, std::vector<int>& bestDist, std::vector<int>& bestDist2) const {
         if (!Q.empty() && (!Q.isContinuous() || Q.cols != 32)) throw std::runtime_error("MatchTop2: Q must be N x 32 continuous");
         if (!T.empty() && (!T.isContinuous() || T.cols != 32)) throw std::runtime_error("MatchTop2: T must be M x 32 continuous");
@@ -63,11 +114,17 @@ public:
         return orbm_count_accepted(bestDist.data(), bestDist2.data(), (int)bestDist.size(), th, mfNNratio);
     }
 
-    static const int TH_LOW = 50;        // reference src/ORBmatcher.cc:40-42
+public:
+    static const int TH_LOW = 50;        // reference include/ORBmatcher.h:92-94, src/ORBmatcher.cc:40-42
     static const int TH_HIGH = 100;
     static const int HISTO_LENGTH = 30;
 
 protected:
+    // reference include/ORBmatcher.h:99-103 (host helpers; the device searches carry their own copies of these rules)
+    bool CheckDistEpipolarLine(const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const cv::Mat& F12, const KeyFrame* pKF);
+    float RadiusByViewingCos(const float& viewCos);
+    void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
+
     float mfNNratio;
     bool mbCheckOrientation;
     int device_;

@@ -599,4 +599,31 @@ int orbx_device_copy_async(void* d_dst, const void* d_src, size_t bytes, void* s
     return hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
 
+int orbx_host_alloc(int device, size_t bytes, void** h_ptr) {
+    if (!h_ptr || bytes == 0) return ORBX_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return ORBX_ERR_DEVICE;
+    *h_ptr = p;
+    return ORBX_OK;
+}
+
+int orbx_host_free(int device, void* h_ptr) {
+    if (!h_ptr) return ORBX_OK;
+    if (hipSetDevice(device) != hipSuccess) return ORBX_ERR_DEVICE;
+    return hipHostFree(h_ptr) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbx_device_upload_async(void* d_dst, const void* h_src, size_t bytes, void* stream) {
+    if (bytes == 0) return ORBX_OK;
+    if (!d_dst || !h_src) return ORBX_ERR_ARG;
+    return hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
+int orbx_device_download_async(void* h_dst, const void* d_src, size_t bytes, void* stream) {
+    if (bytes == 0) return ORBX_OK;
+    if (!h_dst || !d_src) return ORBX_ERR_ARG;
+    return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+}
+
 }  // extern "C"

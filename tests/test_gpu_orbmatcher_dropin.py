@@ -1,0 +1,163 @@
+"""The matcher's drop-in claim executed: the PRODUCT's ORB_SLAM::ORBmatcher (orb_slam_amd/cpp/ORBmatcher.cc + ORBmatcher.h — the reference's
+thirteen search signatures, host side in C++, scans on the GPU through include/orbs.h) against the REFERENCE's own src/ORBmatcher.cc.
+
+Both are compiled behind the same harness (oracle/ref_orbmatcher_wrap.cpp) against the same stand-in Frame / KeyFrame / MapPoint
+(oracle/matcherstub): oracle/_ref/libprod_orbmatcher.so links orb_slam_amd/liborbx.so and no oracle code, oracle/_ref/libref_orbmatcher.so is the
+reference's translation unit.  Every case of tests/test_ref_pin_matcher.py (the 47 that go through ORBmatcher) is run through BOTH: each harness
+call goes to the reference first (on copies of every array argument) and then to the product, and the return value and every array the call
+could have written must be equal — no oracle in that comparison.  (The case then goes on to compare the product with the oracle restatement as
+well, as the CPU pin does for the reference.)  A second pass repeats the projection-based searches at general poses / similarities, where the
+two libraries are compared with each other only: that runs the product's projection, visibility, radius and level code (host C++) against the
+reference's."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import test_ref_pin_matcher as trm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libref_orbmatcher.so")
+PROD_PATH = os.path.join(ROOT, "oracle", "_ref", "libprod_orbmatcher.so")
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not (os.path.exists(REF_PATH) and os.path.exists(PROD_PATH)), reason="oracle/_ref/lib{ref,prod}_orbmatcher.so are built where /root/reference exists")]
+
+
+class DropInMismatch(Exception):
+    """product and reference disagree (deliberately NOT an AssertionError: the posed pass swallows the case's own oracle assertions)"""
+
+
+class Both:
+    """ref_* calls to the reference's ORBmatcher.cc (on copies) and to the product's; results compared; the product's are what the caller sees"""
+
+    def __init__(self):
+        self.ref, self.prod = trm.load(REF_PATH), trm.load(PROD_PATH)
+        self.arrays = {}
+        self.calls = []          # (name, return value)
+
+    def P(self, a):
+        self.arrays[a.ctypes.data] = a
+        return a.ctypes.data
+
+    def set_pose(self, Rt, scale=1.0):
+        for L in (self.ref, self.prod):
+            L.ref_set_pose(None if Rt is None else Rt.ctypes.data, scale)
+
+    def set_sim3(self, Rt, scale=1.0):
+        for L in (self.ref, self.prod):
+            L.ref_set_sim3(None if Rt is None else Rt.ctypes.data, scale)
+
+    def __getattr__(self, name):
+        fr, fp = getattr(self.ref, name), getattr(self.prod, name)
+
+        def call(*args):
+            arrs = [(i, self.arrays[a]) for i, a in enumerate(args) if isinstance(a, int) and a in self.arrays]
+            copies = {i: a.copy() for i, a in arrs}
+            rargs = list(args)
+            for i, c in copies.items():
+                rargs[i] = c.ctypes.data
+            want = fr(*rargs)
+            got = fp(*args)
+            if want != got:
+                raise DropInMismatch(f"{name}: the reference returns {want}, the product {got}")
+            for i, a in arrs:
+                if not np.array_equal(a.view(np.uint8), copies[i].view(np.uint8)):
+                    bad = np.flatnonzero(a.reshape(-1) != copies[i].reshape(-1)) if a.dtype.names is None else []
+                    raise DropInMismatch(f"{name}: argument {i} differs after the call at {len(bad)} places, first {list(bad[:8])}")
+            self.calls.append((name, got))
+            return got
+        return call
+
+
+@pytest.fixture()
+def both(monkeypatch):
+    import torch
+    assert torch.cuda.is_available()
+    b = Both()
+    monkeypatch.setattr(trm, "ref", lambda: b)
+    monkeypatch.setattr(trm, "P", b.P)
+    yield b
+    b.set_pose(None)
+    b.set_sim3(None)
+
+
+def _cases(fn):
+    """the parameter sets of one of test_ref_pin_matcher's parametrised cases"""
+    out = []
+    for m in getattr(fn, "pytestmark", []):
+        if m.name == "parametrize":
+            names = [n.strip() for n in m.args[0].split(",")]
+            out.append((names, list(m.args[1])))
+    return out
+
+
+def _run_all(fn, both, swallow=False):
+    """every parameter combination of `fn`; returns the harness return values.  swallow: the case's own assertions (oracle at the identity pose,
+    sanity thresholds) do not apply, only the product / reference comparison inside `both` does"""
+    sets = _cases(fn)
+    combos = [{}]
+    for names, values in sets:
+        combos = [dict(c, **dict(zip(names, v if len(names) > 1 else (v,)))) for c in combos for v in values]
+    for kw in combos:
+        try:
+            fn(**kw)
+        except AssertionError:
+            if not swallow:
+                raise
+    return [r for _, r in both.calls]
+
+
+# ---- pass 1: every case of the CPU pin, product and reference side by side, then product against the oracle ------------------------------
+ALL = ["test_three_maxima_and_descriptor_distance", "test_check_dist_epipolar_line", "test_search_by_projection_of_map_points", "test_window_search",
+       "test_search_for_initialization", "test_search_by_projection_from_last_frame", "test_search_by_sim3",
+       "test_search_by_projection_between_two_frames", "test_search_by_projection_from_keyframe", "test_search_by_projection_with_sim3_pose",
+       "test_fuse", "test_search_by_bow_keyframe_frame", "test_search_by_bow_keyframe_keyframe", "test_search_for_triangulation"]
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_product_orbmatcher_equals_reference_orbmatcher(name, both):
+    n = _run_all(getattr(trm, name), both)
+    assert len(n) >= 1
+
+
+def test_every_search_signature_was_exercised(both):
+    """the thirteen searches + the three helpers all went through the comparison (one small case each is enough here: the full ones ran above)"""
+    for name in ALL:
+        fn = getattr(trm, name)
+        sets = _cases(fn)
+        kw = {}
+        for names, values in sets:
+            v = values[-1]
+            kw.update(dict(zip(names, v if len(names) > 1 else (v,))))
+        fn(**kw)
+    called = {c for c, _ in both.calls}
+    want = {"ref_matcher_three_maxima", "ref_matcher_descriptor_distance", "ref_matcher_check_epipolar", "ref_search_by_projection_mappoints", "ref_window_search",
+            "ref_search_for_initialization", "ref_search_by_projection_last_frame", "ref_search_by_sim3", "ref_search_by_projection_two_frames",
+            "ref_search_by_projection_keyframe", "ref_search_by_projection_scw", "ref_fuse", "ref_search_by_bow", "ref_search_by_bow_kf", "ref_search_for_triangulation"}
+    assert called == want
+
+
+# ---- pass 2: general poses ---------------------------------------------------------------------------------------------------------------
+def _pose(seed, angle_deg, shift):
+    rng = np.random.default_rng(seed)
+    w = rng.normal(0, 1, 3); w /= np.linalg.norm(w)
+    th = np.deg2rad(angle_deg)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    t = rng.normal(0, shift, 3)
+    return np.ascontiguousarray(np.concatenate([R.reshape(9), t]).astype(np.float32))
+
+
+POSED = ["test_search_by_projection_from_last_frame", "test_search_by_projection_between_two_frames", "test_search_by_projection_from_keyframe",
+         "test_search_by_projection_with_sim3_pose", "test_fuse", "test_search_by_sim3"]
+
+
+@pytest.mark.parametrize("angle,shift,scale", [(0.1, 0.001, 1.0), (0.5, 0.004, 1.07), (0.3, 0.002, 0.93)])
+@pytest.mark.parametrize("name", POSED)
+def test_product_equals_reference_at_general_poses(name, angle, shift, scale, both):
+    both.set_pose(_pose(int(angle * 100), angle, shift), scale)
+    both.set_sim3(_pose(int(angle * 100) + 7, angle / 2, shift / 2), 2.0 - scale)
+    n = _run_all(getattr(trm, name), both, swallow=True)
+    print("posed", name, angle, n)
+    assert len(n) >= 3 and max(n) > 0, n          # the windows moved, the searches still find matches to disagree about

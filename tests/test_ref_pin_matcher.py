@@ -22,10 +22,11 @@ SCALE = np.array([np.float32(1.2) ** i for i in range(8)], np.float32)
 _REF = None
 
 
-def ref():
-    global _REF
-    if _REF is None:
-        L = ctypes.CDLL(PATH)
+def load(path):
+    """the harness of oracle/ref_orbmatcher_wrap.cpp with its prototypes (libref_orbmatcher.so = in front of the reference's src/ORBmatcher.cc;
+    libprod_orbmatcher.so = in front of the product's orb_slam_amd/cpp/ORBmatcher.cc: tests/test_gpu_orbmatcher_dropin.py)"""
+    if True:
+        L = ctypes.CDLL(path)
         f, i, vp = ctypes.c_float, ctypes.c_int, ctypes.c_void_p
         L.ref_matcher_three_maxima.argtypes = [vp, i, vp]
         L.ref_matcher_descriptor_distance.argtypes = [vp, vp]
@@ -42,7 +43,15 @@ def ref():
         L.ref_search_by_bow.argtypes = [f, i] + [vp, vp, vp, i, vp, vp, vp, i] + [vp, vp, vp, i, vp, vp, i] + [vp]
         L.ref_search_by_bow_kf.argtypes = [f, i] + [vp, vp, vp, i, vp, vp, vp, i] * 2 + [vp]
         L.ref_search_for_triangulation.argtypes = [f, i, vp, vp, i] + [vp, vp, vp, i, vp, vp, vp, i] * 2 + [vp]
-        _REF = L
+        L.ref_set_pose.argtypes = [vp, f]
+        L.ref_set_sim3.argtypes = [vp, f]
+    return L
+
+
+def ref():
+    global _REF
+    if _REF is None:
+        _REF = load(PATH)
     return _REF
 
 
