@@ -159,5 +159,4 @@ def test_product_equals_reference_at_general_poses(name, angle, shift, scale, bo
     both.set_pose(_pose(int(angle * 100), angle, shift), scale)
     both.set_sim3(_pose(int(angle * 100) + 7, angle / 2, shift / 2), 2.0 - scale)
     n = _run_all(getattr(trm, name), both, swallow=True)
-    print("posed", name, angle, n)
-    assert len(n) >= 3 and max(n) > 0, n          # the windows moved, the searches still find matches to disagree about
+    assert len(n) >= 3 and min(n) > 60, n          # the windows moved, the searches still find matches to disagree about

@@ -1,0 +1,76 @@
+"""Latency of the drop-in ORB_SLAM::ORBmatcher searches (orb_slam_amd/cpp/ORBmatcher.cc: host C++ + one kernel launch per search) next to the
+reference's own src/ORBmatcher.cc on the host CPU, on the problems of tests/test_ref_pin_matcher.py (1000-feature frames).  Both run behind the
+same harness (oracle/ref_orbmatcher_wrap.cpp), whose cost of building the stand-in Frame / KeyFrame / MapPoint objects is in both numbers.
+    python tools/bench_orbmatcher_dropin.py [--repeat 7] [--out profiles/r06_orbmatcher_dropin.json]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_ref_pin_matcher as trm                      # noqa: E402
+import test_gpu_orbmatcher_dropin as drop               # noqa: E402
+
+
+class Timed(drop.Both):
+    def __init__(self, repeat):
+        super().__init__()
+        self.repeat, self.rows = repeat, {}
+
+    def __getattr__(self, name):
+        fr, fp = getattr(self.ref, name), getattr(self.prod, name)
+
+        def call(*args):
+            arrs = [(i, self.arrays[a]) for i, a in enumerate(args) if isinstance(a, int) and a in self.arrays]
+            saved = {i: a.copy() for i, a in arrs}
+            best = {}
+            for key, f in (("reference_cpu_ms", fr), ("product_gpu_ms", fp)):
+                ts = []
+                for _ in range(self.repeat):
+                    for i, a in arrs:
+                        a[...] = saved[i]
+                    t0 = time.perf_counter()
+                    ret = f(*args)
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                best[key] = min(ts)
+            self.rows.setdefault(name, []).append(best)
+            return ret
+        return call
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--repeat", type=int, default=7)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    import torch
+    assert torch.cuda.is_available()
+    b = Timed(a.repeat)
+    trm.ref, trm.P = (lambda: b), b.P
+    for name in drop.ALL[2:]:
+        fn = getattr(trm, name)
+        sets = drop._cases(fn)
+        kw = {}
+        for names, values in sets:                       # the first (largest: ~1000 x 1000) case of each search
+            v = values[0]
+            kw.update(dict(zip(names, v if len(names) > 1 else (v,))))
+        try:
+            fn(**kw)
+        except AssertionError:
+            pass
+    out = {"what": "min of %d calls, ms; harness object construction included on both sides" % a.repeat, "device": torch.cuda.get_device_name(0),
+           "host_cores": os.cpu_count(), "searches": {}}
+    for name, rows in b.rows.items():
+        r = {k: round(min(x[k] for x in rows), 4) for k in rows[0]}
+        r["speedup"] = round(r["reference_cpu_ms"] / r["product_gpu_ms"], 2)
+        out["searches"][name.replace("ref_", "")] = r
+        print(f"{name:40s} reference {r['reference_cpu_ms']:8.3f} ms   product {r['product_gpu_ms']:8.3f} ms   x{r['speedup']}")
+    if a.out:
+        json.dump(out, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
