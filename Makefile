@@ -64,6 +64,6 @@ tools/microbench/ta_shapes: tools/microbench/ta_shapes.hip
 
 clean:
 	rm -f tools/microbench/mfma_layout_fp4 tools/microbench/valu_exec_mask tools/microbench/ta_shapes tools/microbench/valu_rate tools/microbench/valu_rate2 tools/microbench/mfma_layout tools/microbench/mfma_valu_mix tools/microbench/fetch_calib orb_slam_amd/cpp/bench_single_frame orb_slam_amd/cpp/example_lanes orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
-	rm -rf oracle/_ref
+	rm -rf oracle/_ref oracle/_ref_native
 
 .PHONY: all clean oracle_ref

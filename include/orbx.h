@@ -53,6 +53,18 @@ extern "C" {
 #define ORBX_BLUR_X86_SSE2 0
 #define ORBX_BLUR_HALF_UP  1
 
+/* How the two float expressions of src/ORBextractor.cc that a compiler may contract are evaluated:
+ * `x*b + y*a`, `x*a - y*b` in computeOrbDescriptor (:165-166) and the Harris response (:118-119).
+ *   ORBX_FP_ISO           unfused, one rounding per operation: the source text under ISO C++ rules = the reference built with
+ *                         -ffp-contract=off, or for a CPU without FMA instructions (default; oracle/_ref, the golden fixtures)
+ *   ORBX_FP_GCC_CONTRACT  fused where GCC fuses them under the reference's own flags (CMakeLists.txt:12-13: -O3 -march=native with
+ *                         GCC's default -ffp-contract=fast, any x86 since 2013): fma(x,b,y*a), fma(x,a,-(y*b)),
+ *                         fma(-(a+b), k*(a+b), fma(a,b,-(c*c))) — read off that build's object code (oracle/_ref_native).
+ * The two differ in ~1 descriptor bit per 10^5 key points and in the last bits of ~30 % of the Harris responses
+ * (tests/test_ref_pin_native.py).  orbx_default_params takes ORBX_FP_CONTRACT=1 from the environment. */
+#define ORBX_FP_ISO          0
+#define ORBX_FP_GCC_CONTRACT 1
+
 /* identical to OpenCV 2.4's cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id */
 typedef struct orbx_keypoint {
     float x, y;
@@ -74,7 +86,8 @@ typedef struct orbx_params {
     int32_t device;         /* HIP device ordinal */
     int32_t max_batch;      /* frames processed per launch group by orbx_extract_batch_device (>=1) */
     int32_t blur_rounding;  /* ORBX_BLUR_* */
-    int32_t reserved[8];    /* must be zero */
+    int32_t fp_contract;    /* ORBX_FP_* (took the first reserved slot: a zeroed struct of an older caller means ORBX_FP_ISO) */
+    int32_t reserved[7];    /* must be zero */
 } orbx_params;
 
 typedef struct orbx_extractor orbx_extractor;   /* opaque; not thread-safe (same as the reference instance) */

@@ -305,7 +305,10 @@ void retainBest(std::vector<KeyPoint>& v, int n) {
 }
 
 // reference src/ORBextractor.cc:79-120 (HarrisResponses), `img` = the cell view inside the level.
-void HarrisResponses(const uint8_t* ptr00, int step, std::vector<KeyPoint>& pts, int blockSize, float harris_k) {
+// fp_contract: the reference's own build (CMakeLists.txt:12-13: -O3 -march=native, GCC's default -ffp-contract=fast) fuses two
+// multiply-adds of the last expression (read off its object code: oracle/Makefile _ref_native):
+//   t = fma(a, b, -(c*c));  response = fma(-(a+b), k*(a+b), t) * scale^4
+void HarrisResponses(const uint8_t* ptr00, int step, std::vector<KeyPoint>& pts, int blockSize, float harris_k, bool fp_contract = false) {
     int r = blockSize / 2;
     float scale = (1 << 2) * blockSize * 255.0f;
     scale = 1.0f / scale;
@@ -324,6 +327,11 @@ void HarrisResponses(const uint8_t* ptr00, int step, std::vector<KeyPoint>& pts,
                 b += Iy * Iy;
                 c += Ix * Iy;
             }
+        if (fp_contract) {
+            const float cc = (float)c * c, sum = (float)a + b;
+            const float t = fmaf((float)a, (float)b, -cc);
+            pts[p].response = fmaf(-sum, harris_k * sum, t) * scale_sq_sq;
+        } else
         pts[p].response = ((float)a * b - (float)c * c - harris_k * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
     }
 }
@@ -353,12 +361,14 @@ const Point bit_pattern_31[512] = {
 
 // reference :154-194 (computeOrbDescriptor).  cos/sin of a float resolve to cosf/sinf.
 const float factorPI = (float)(M_PI / 180.f);
-void computeOrbDescriptor(const KeyPoint& kpt, const uint8_t* roi, int step, const Point* pattern, uint8_t* desc) {
+// fp_contract: the reference's own build fuses `x*b + y*a` into fma(x, b, y*a) and `x*a - y*b` into fma(x, a, -(y*b)) (see HarrisResponses).
+void computeOrbDescriptor(const KeyPoint& kpt, const uint8_t* roi, int step, const Point* pattern, uint8_t* desc, bool fp_contract = false) {
     float angle = (float)kpt.angle * factorPI;
     float a = (float)cosf(angle), b = (float)sinf(angle);
     const uint8_t* center = roi + (ptrdiff_t)cvRound(kpt.y) * step + cvRound(kpt.x);
 #define GET_VALUE(idx) \
-    center[cvRound(pattern[idx].x * b + pattern[idx].y * a) * step + cvRound(pattern[idx].x * a - pattern[idx].y * b)]
+    (fp_contract ? center[cvRound(fmaf((float)pattern[idx].x, b, pattern[idx].y * a)) * step + cvRound(fmaf((float)pattern[idx].x, a, -(pattern[idx].y * b)))] \
+                 : center[cvRound(pattern[idx].x * b + pattern[idx].y * a) * step + cvRound(pattern[idx].x * a - pattern[idx].y * b)])
     for (int i = 0; i < 32; ++i, pattern += 16) {
         int val = 0;
         for (int k = 0; k < 8; k++) {
@@ -451,6 +461,7 @@ struct Extractor {
     std::vector<std::vector<KeyPoint>> level_kps;   // stage dump: allKeypoints (level coords, with angle)
     std::vector<CellDump> cells;     // stage dump
     bool keep_dumps = false;
+    bool fp_contract = false;        // orc_set_fp_contract
     int error = 0;
 
     // reference :457-511
@@ -566,7 +577,7 @@ struct Extractor {
                         cv_FAST(cellImage, cw, ch, pyr[level].stride, ck, 7);
                         fb = 1;
                     }
-                    if (scoreType == 0 /*HARRIS_SCORE*/) HarrisResponses(cellImage, pyr[level].stride, ck, 7, HARRIS_K);
+                    if (scoreType == 0 /*HARRIS_SCORE*/) HarrisResponses(cellImage, pyr[level].stride, ck, 7, HARRIS_K, fp_contract);
                     if (keep_dumps) {
                         CellDump cd = {level, i, j, (int)iniX, (int)iniY, fb, cw, ch, ck};
                         cells.push_back(cd);
@@ -648,7 +659,7 @@ struct Extractor {
             if (n == 0) continue;
             gaussian_blur7_inplace(pyr[level], blur_mode);
             for (int i = 0; i < n; i++)
-                computeOrbDescriptor(keypoints[i], pyr[level].roi(), pyr[level].stride, bit_pattern_31, out_desc + (size_t)(offset + i) * 32);
+                computeOrbDescriptor(keypoints[i], pyr[level].roi(), pyr[level].stride, bit_pattern_31, out_desc + (size_t)(offset + i) * 32, fp_contract);
             if (level != 0) {
                 float scale = mvScaleFactor[level];
                 for (KeyPoint& kp : keypoints) { kp.x *= scale; kp.y *= scale; }
@@ -688,6 +699,8 @@ void* orc_create(int nfeatures, float scaleFactor, int nlevels, int scoreType, i
 }
 void orc_destroy(void* h) { delete (Extractor*)h; }
 void orc_keep_dumps(void* h, int on) { ((Extractor*)h)->keep_dumps = on != 0; }
+// 1: the float expressions of HarrisResponses / computeOrbDescriptor as the reference's own build flags contract them (default 0: ISO evaluation)
+void orc_set_fp_contract(void* h, int on) { ((Extractor*)h)->fp_contract = on != 0; }
 
 int orc_extract(void* h, const uint8_t* img, int w, int hh, int stride, orc_keypoint* kps, uint8_t* desc, int cap) {
     return ((Extractor*)h)->extract(img, w, hh, stride, kps, desc, cap);

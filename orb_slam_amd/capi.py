@@ -61,7 +61,7 @@ class OrbxError(RuntimeError):
 class Params(ctypes.Structure):
     _fields_ = [("nfeatures", ctypes.c_int32), ("scale_factor", ctypes.c_float), ("nlevels", ctypes.c_int32),
                 ("score_type", ctypes.c_int32), ("fast_th", ctypes.c_int32), ("device", ctypes.c_int32),
-                ("max_batch", ctypes.c_int32), ("blur_rounding", ctypes.c_int32), ("reserved", ctypes.c_int32 * 8)]
+                ("max_batch", ctypes.c_int32), ("blur_rounding", ctypes.c_int32), ("fp_contract", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7)]
 
 
 class Camera(ctypes.Structure):
@@ -197,12 +197,14 @@ class ORBextractor:
     (include/ORBextractor.h:38) plus device placement; __call__(image) is operator()."""
 
     def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, scoreType=FAST_SCORE, fastTh=20,
-                 device=0, max_batch=1, blur_rounding=BLUR_X86_SSE2):
+                 device=0, max_batch=1, blur_rounding=BLUR_X86_SSE2, fp_contract=None):
         L = lib()
         p = Params()
         L.orbx_default_params(ctypes.byref(p))
         p.nfeatures, p.scale_factor, p.nlevels, p.score_type, p.fast_th = nfeatures, scaleFactor, nlevels, scoreType, fastTh
         p.device, p.max_batch, p.blur_rounding = device, max_batch, blur_rounding
+        if fp_contract is not None:                      # None: orbx_default_params' choice (ORBX_FP_CONTRACT in the environment, else ISO)
+            p.fp_contract = 1 if fp_contract else 0
         h = ctypes.c_void_p()
         rc = L.orbx_create(ctypes.byref(p), ctypes.byref(h))
         if rc != ORBX_OK:

@@ -154,6 +154,8 @@ void orbx_default_params(orbx_params* p) {
     p->device = 0;
     p->max_batch = 1;
     p->blur_rounding = ORBX_BLUR_X86_SSE2;
+    const char* fc = getenv("ORBX_FP_CONTRACT");           // setup time only (never on a launch path)
+    p->fp_contract = (fc && fc[0] == '1' && fc[1] == 0) ? ORBX_FP_GCC_CONTRACT : ORBX_FP_ISO;
 }
 
 int orbx_create(const orbx_params* p, orbx_extractor** out) {

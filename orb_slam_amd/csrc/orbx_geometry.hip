@@ -39,6 +39,7 @@ static int build_geometry_band(const orbx_params& p, int w, int h, HostGeom& out
     memset(&g, 0, sizeof(g));
     g.nlevels = nl;
     g.score_type = p.score_type;
+    g.fp_contract = p.fp_contract ? 1 : 0;
     g.fast_th = std::min(std::max(p.fast_th, 0), 255);   // cv::FAST clamps its threshold
     g.tmin = std::min(g.fast_th, 7);                    // one score pass serves fastTh and the fallback 7
 

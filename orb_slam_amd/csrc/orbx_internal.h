@@ -185,6 +185,7 @@ struct DevGeom {
     int nquads;              // sum of ceil(ndesired / 4): k_describe waves per frame
     int quota_cells;         // cells of the level with the most cells, rounded up to 64 (k_quota LDS arrays)
     int score_type, fast_th, tmin;
+    int fp_contract;         // orbx_params::fp_contract (Harris response, descriptor rotation)
     int frame_plane_bytes;   // bytes of one frame's pyramid block (== blur block == nms block)
     int frame_cands;         // Cand slots per frame
     int frame_sel;           // sel slots per frame

@@ -1063,7 +1063,9 @@ __device__ __forceinline__ void wave_nth_element(Cand* a, int first, int nth, in
 }
 
 // reference :79-120 (HarrisResponses, blockSize 7) on the unblurred level; x,y = level coords of the corner
-__device__ float harris_response(const uint8_t* img, long long step, int x, int y) {
+// fp_contract: the last expression as the reference's own build flags fuse it (orbx_params::fp_contract):
+// t = fma(a, b, -(c*c)); response = fma(-(a+b), k*(a+b), t) * scale^4
+__device__ float harris_response(const uint8_t* img, long long step, int x, int y, int fp_contract) {
     const float scale = 1.0f / ((1 << 2) * 7 * 255.0f);
     const float scale_sq_sq = scale * scale * scale * scale;
     const uint8_t* p0 = img + (long long)(y - 3) * step + (x - 3);
@@ -1077,6 +1079,10 @@ __device__ float harris_response(const uint8_t* img, long long step, int x, int 
             bb += Iy * Iy;
             c += Ix * Iy;
         }
+    if (fp_contract) {
+        const float cc = (float)c * (float)c, sum = (float)a + (float)bb;
+        return __builtin_fmaf(-sum, 0.04f * sum, __builtin_fmaf((float)a, (float)bb, -cc)) * scale_sq_sq;
+    }
     return ((float)a * (float)bb - (float)c * (float)c - 0.04f * ((float)a + (float)bb) * ((float)a + (float)bb)) * scale_sq_sq;
 }
 
@@ -1118,7 +1124,7 @@ __device__ __forceinline__ bool cell_select_body(const Batch& b, int frame, int 
                 for (int i = 0; i < nb; i++) { const Cand e = bc[i]; if (e.resp >= thr) c[m++] = e; }
             }
             if (g.score_type == ORBX_HARRIS_SCORE)
-                for (int i = 0; i < m; i++) c[i].resp = harris_response(img, stride, c[i].pos & 0xFFFF, c[i].pos >> 16);
+                for (int i = 0; i < m; i++) c[i].resp = harris_response(img, stride, c[i].pos & 0xFFFF, c[i].pos >> 16, g.fp_contract);
             if (m > s.nretain) std::nth_element(c, c + s.nretain, c + m, RespGreater());
             const int keep = min(m, s.nretain);
             for (int i = 0; i < keep; i++) out[i] = c[i];
@@ -1154,7 +1160,7 @@ __device__ __forceinline__ bool cell_select_body(const Batch& b, int frame, int 
     }
     wave_lds_fence();
     if (g.score_type == ORBX_HARRIS_SCORE) {
-        for (int i = lane; i < m; i += 64) lst[i].resp = harris_response(img, stride, lst[i].pos & 0xFFFF, lst[i].pos >> 16);
+        for (int i = lane; i < m; i += 64) lst[i].resp = harris_response(img, stride, lst[i].pos & 0xFFFF, lst[i].pos >> 16, g.fp_contract);
         wave_lds_fence();
     }
     if (m > s.nretain) wave_nth_element(lst, 0, s.nretain, m, lpos, rpos, lane);
@@ -1781,6 +1787,9 @@ __global__ __launch_bounds__(SMALL ? FAST_SMALL.threads : FAST_LARGE.threads) vo
 constexpr int DESC_KPW = 4;
 constexpr int DESC_WIN_PITCH = 40, DESC_WIN_ROWS = 37, DESC_WIN_BYTES = DESC_WIN_PITCH * DESC_WIN_ROWS;   // 37 px + up to 3 px of dword alignment per row
 
+// FMA: the two rotation expressions of computeOrbDescriptor as the reference's own build flags contract them (orbx_params::fp_contract):
+// `x*b + y*a` -> fma(x, b, y*a), `x*a - y*b` -> fma(x, a, -(y*b)); false: unfused (ISO evaluation, the default).
+template <bool FMA>
 __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
 #if ORBX_DESC_PACKED_PATTERN
     __shared__ uint32_t s_pat[256];                                    // test t: x0, y0, x1, y1 as the four int8 of c_pattern[t] (1 KB: six workgroups per CU; as floats, 4 KB: five)
@@ -2007,8 +2016,8 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const float4 P = pat[16 * j];
-            const float fy0 = P.x * sn + P.y * cs, fx0 = P.x * cs - P.y * sn;
-            const float fy1 = P.z * sn + P.w * cs, fx1 = P.z * cs - P.w * sn;
+            const float fy0 = FMA ? __builtin_fmaf(P.x, sn, P.y * cs) : P.x * sn + P.y * cs, fx0 = FMA ? __builtin_fmaf(P.x, cs, -(P.y * sn)) : P.x * cs - P.y * sn;
+            const float fy1 = FMA ? __builtin_fmaf(P.z, sn, P.w * cs) : P.z * sn + P.w * cs, fx1 = FMA ? __builtin_fmaf(P.z, cs, -(P.w * sn)) : P.z * cs - P.w * sn;
             // cvRound (ties to even) of both coordinates, then iy * pitch + ix exactly in float (the fused multiply-add rounds nothing here)
             const int o0 = (int)__builtin_fmaf(__builtin_rintf(fy0), (float)DESC_WIN_PITCH, __builtin_rintf(fx0));
             const int o1 = (int)__builtin_fmaf(__builtin_rintf(fy1), (float)DESC_WIN_PITCH, __builtin_rintf(fx1));
@@ -2023,8 +2032,8 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const float px = e ? P.z : P.x, py = e ? P.w : P.y;
-                const int iy = cv_round_f(px * sn + py * cs);
-                const int ix = cv_round_f(px * cs - py * sn);
+                const int iy = cv_round_f(FMA ? __builtin_fmaf(px, sn, py * cs) : px * sn + py * cs);
+                const int ix = cv_round_f(FMA ? __builtin_fmaf(px, cs, -(py * sn)) : px * cs - py * sn);
                 int X = x + ix, Y = y + iy;
                 // inside the level: blurred pixel.  Outside (<= 2 px, only for keypoints 16..17 px from the edge): the
                 // reference reads the level's UNBLURRED reflect-101 border; one reflection suffices.
@@ -2231,7 +2240,8 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
 describe:
     if (phases & ORBX_PHASE_DESCRIBE) {
         StageScope sc(timer, stream, ST_DESCRIBE);
-        hipLaunchKernelGGL(k_describe, dim3(frame_item_blocks(b, (g.nquads + DESC_WAVES - 1) / DESC_WAVES)), dim3(DESC_WAVES * 64), 0, stream, b);
+        if (g.fp_contract) hipLaunchKernelGGL(k_describe<true>, dim3(frame_item_blocks(b, (g.nquads + DESC_WAVES - 1) / DESC_WAVES)), dim3(DESC_WAVES * 64), 0, stream, b);
+        else hipLaunchKernelGGL(k_describe<false>, dim3(frame_item_blocks(b, (g.nquads + DESC_WAVES - 1) / DESC_WAVES)), dim3(DESC_WAVES * 64), 0, stream, b);
         ORBX_LAUNCH_CHECK();
     }
     return ORBX_OK;

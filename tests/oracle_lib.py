@@ -85,12 +85,14 @@ def lib():
 class OracleExtractor:
     """Mirror of the reference constructor ORBextractor(nfeatures, scaleFactor, nlevels, scoreType, fastTh)."""
 
-    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, scoreType=FAST_SCORE, fastTh=20, blur_mode=0, dumps=False):
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, scoreType=FAST_SCORE, fastTh=20, blur_mode=0, dumps=False, fp_contract=False):
         self.L = lib()
         self.nfeatures, self.nlevels = nfeatures, nlevels
         self.h = self.L.orc_create(nfeatures, scaleFactor, nlevels, scoreType, fastTh, blur_mode)
         assert self.h
         self.L.orc_keep_dumps(self.h, 1 if dumps else 0)
+        self.L.orc_set_fp_contract.argtypes = [c_void_p, c_int]
+        self.L.orc_set_fp_contract(self.h, 1 if fp_contract else 0)     # the float expressions as the reference's own build flags contract them
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -289,11 +291,22 @@ def ref_available():
 _REF = {}
 
 
-def ref_lib(name):
-    """the reference's own sources compiled against oracle/cvstub (oracle/Makefile → oracle/_ref/)"""
-    if name not in _REF:
+NATIVE_DIR = os.path.join(os.path.dirname(REF_DIR), "_ref_native")
+
+
+def native_available():
+    return os.path.exists(os.path.join(NATIVE_DIR, "libref_orbextractor.so"))
+
+
+def ref_lib(name, native=False):
+    """the reference's own sources compiled against oracle/cvstub (oracle/Makefile → oracle/_ref/; native: → oracle/_ref_native/, the
+    extractor built with the reference's own optimisation flags, i.e. with GCC's default FMA contraction)"""
+    key = ("native:" if native else "") + name
+    if key in _REF:
+        return _REF[key]
+    if True:
         lib()     # liborb_oracle.so first: the stand-in cv primitives resolve into it
-        R = ctypes.CDLL(os.path.join(REF_DIR, name), mode=ctypes.RTLD_GLOBAL)
+        R = ctypes.CDLL(os.path.join(NATIVE_DIR if native else REF_DIR, name), mode=ctypes.RTLD_LOCAL if native else ctypes.RTLD_GLOBAL)
         if name == "libref_orbextractor.so":
             R.ref_orb_create.restype = c_void_p
             R.ref_orb_create.argtypes = [c_int, c_float, c_int, c_int, c_int]
@@ -313,15 +326,15 @@ def ref_lib(name):
             R.ref_voc_transform.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7
             R.ref_voc_score.restype = c_double
             R.ref_voc_score.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]
-        _REF[name] = R
-    return _REF[name]
+        _REF[key] = R
+    return _REF[key]
 
 
 class RefExtractor:
     """ORB_SLAM::ORBextractor compiled from /root/reference/src/ORBextractor.cc (OpenCV primitives = the oracle's)"""
 
-    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, scoreType=FAST_SCORE, fastTh=20, blur_mode=0):
-        self.R = ref_lib("libref_orbextractor.so")
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, scoreType=FAST_SCORE, fastTh=20, blur_mode=0, native=False):
+        self.R = ref_lib("libref_orbextractor.so", native=native)
         self.blur_mode = blur_mode
         self.nfeatures = nfeatures
         self.h = self.R.ref_orb_create(nfeatures, scaleFactor, nlevels, scoreType, fastTh)

@@ -587,3 +587,69 @@ def test_blur_planes_of_a_full_launch_group(gpu_extractor_factory, cfg):
             got = ex.fetch_plane(capi.DBG_BLUR, l, frame=f)
             bad = np.argwhere(got != orc.gaussian_blur7(plain, mode))
             assert bad.size == 0, "frame %d level %d (%dx%d): %d pixels differ, first %s" % (f, l, plain.shape[1], plain.shape[0], len(bad), bad[0])
+
+
+# ---- round 6: the FMA caveat.  orbx_params::fp_contract = ORBX_FP_GCC_CONTRACT evaluates the descriptor rotation and the Harris response as
+# the reference's OWN build flags fuse them (oracle/_ref_native = src/ORBextractor.cc with -O3 and GCC's default contraction; the oracle's
+# fp_contract mode is pinned to it byte for byte by tests/test_ref_pin_native.py)
+@pytest.mark.parametrize("cfg", [
+    dict(w=640, h=480, nfeatures=1000),
+    dict(w=640, h=480, nfeatures=2000),
+    dict(w=640, h=480, nfeatures=1000, scoreType=capi.HARRIS_SCORE),
+    dict(w=752, h=480, nfeatures=1500, scaleFactor=1.3, nlevels=6, fastTh=12),
+    dict(w=321, h=243, nfeatures=500, scaleFactor=1.5, nlevels=5, scoreType=capi.HARRIS_SCORE, fastTh=9),
+    dict(w=97, h=83, nfeatures=50, nlevels=4),
+    dict(w=1920, h=1080, nfeatures=2000),
+], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_fp_contract_mode_equals_the_native_reference_build(gpu_extractor_factory, cfg):
+    cfg = dict(cfg)
+    w, h = cfg.pop("w"), cfg.pop("h")
+    ex = gpu_extractor_factory(fp_contract=True, **cfg)
+    ex_iso = gpu_extractor_factory(fp_contract=False, **cfg)
+    o = orc.OracleExtractor(fp_contract=True, **cfg)
+    native = orc.RefExtractor(native=True, **cfg) if orc.native_available() else None
+    differs = 0
+    for fam in (synth.NOISE, synth.BLOCKS, synth.FLAT, synth.LOWTEX, synth.MIDTEX):
+        for idx in (0, 5):
+            img = synth.frame(w, h, fam, idx)
+            gk, gd = ex(img)
+            ok, od = o(img)
+            _assert_kps_equal(gk, ok)
+            np.testing.assert_array_equal(gd, od)
+            if native is not None:                    # and with no oracle in the chain: the reference's own translation unit, its own flags
+                rk, rd = native(img)
+                assert gk.tobytes() == rk.tobytes() and gd.tobytes() == rd.tobytes()
+            ik, idd = ex_iso(img)
+            differs += int(gk.tobytes() != ik.tobytes() or gd.tobytes() != idd.tobytes())
+    if cfg.get("scoreType") == capi.HARRIS_SCORE:
+        assert differs > 0                            # the switch is live: Harris responses change in their last bits on almost every frame
+
+
+def test_fp_contract_mode_through_the_batch_path(gpu_extractor_factory):
+    """the throughput entry point in the contracted mode: one launch group of 40 VGA frames, every frame against the oracle's fp_contract mode;
+    the handful of descriptor bits that separate the two modes on this sample are all on the contracted side"""
+    import torch
+    F, w, h, cap = 40, 640, 480, 1000
+    frames = np.stack([synth.frame(w, h, [synth.BLOCKS, synth.MIDTEX][i % 2], 100 + i) for i in range(F)])
+    d = torch.from_numpy(frames).cuda()
+    outs = {}
+    for mode in (True, False):
+        ex = gpu_extractor_factory(max_batch=F, fp_contract=mode)
+        kps = torch.zeros((F, cap, 28), dtype=torch.uint8, device="cuda")
+        desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device="cuda")
+        n = torch.zeros(F, dtype=torch.int32, device="cuda")
+        ex.extract_batch_device(d.data_ptr(), F, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), cap)
+        torch.cuda.synchronize()
+        outs[mode] = (kps.cpu().numpy(), desc.cpu().numpy(), n.cpu().numpy())
+    o = orc.OracleExtractor(fp_contract=True)
+    o_iso = orc.OracleExtractor()
+    bits = 0
+    for f in range(F):
+        ok, od = o(frames[f])
+        ik, idd = o_iso(frames[f])
+        for mode, (wk, wd) in ((True, (ok, od)), (False, (ik, idd))):
+            k, dd, n = outs[mode]
+            assert n[f] == len(wk)
+            assert k[f, :n[f]].tobytes() == wk.tobytes() and np.array_equal(dd[f, :n[f]], wd)
+        bits += int(np.unpackbits(od ^ idd).sum())
+    print("descriptor bits separating the two modes on %d frames: %d" % (F, bits))
