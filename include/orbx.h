@@ -239,6 +239,10 @@ int orbm_distinctive_device(const uint8_t* d_desc, const int32_t* d_seg_off, int
 /* run the kernel sequence only up to `stage` (0 pyramid, 1 FAST + NMS + cell lists, 2 quotas, 3 per-cell retainBest,
  * 4 per-level cap, 5 blur, 6 describe); <0 = everything (default) */
 int orbx_debug_set_stop_after(orbx_extractor* h, int stage);
+/* 1: full launch groups compute the GaussianBlur per keypoint window inside the description kernel (k_describe_od: no blurred plane, no blur
+ * kernel); 0: the blur kernels + k_describe.  Same outputs.  Default: ORBX_BLUR_ON_DEMAND in the environment at orbx_create, else the build's
+ * choice.  ORBX_DBG_BLUR planes exist only in mode 0. */
+int orbx_debug_set_blur_on_demand(orbx_extractor* h, int mode);
 /* per-stage GPU time from HIP events recorded on the launch stream: enable = 0 off, 1 on, 2 on + reset totals.
  * orbx_debug_stage_time synchronises the device and returns the accumulated ms / launch-group count of a stage. */
 int orbx_debug_stage_timing(orbx_extractor* h, int enable);

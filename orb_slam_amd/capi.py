@@ -29,7 +29,7 @@ EXPORTS = [
     "orbm_count_accepted", "orbm_match_top2_segments", "orbm_match_top2_segments_device", "orbm_distinctive", "orbm_distinctive_device",
     "orbx_device_alloc", "orbx_device_free", "orbx_device_upload", "orbx_device_download",
     "orbx_stream_create", "orbx_stream_create_priority", "orbx_stream_destroy", "orbx_stream_synchronize", "orbx_event_create", "orbx_event_destroy", "orbx_event_record",
-    "orbx_stream_wait_event", "orbx_device_copy_async", "orbx_host_alloc", "orbx_host_free", "orbx_device_upload_async", "orbx_device_download_async", "orbx_debug_set_stop_after", "orbx_debug_level_size", "orbx_debug_fetch",
+    "orbx_stream_wait_event", "orbx_device_copy_async", "orbx_host_alloc", "orbx_host_free", "orbx_device_upload_async", "orbx_device_download_async", "orbx_debug_set_stop_after", "orbx_debug_set_blur_on_demand", "orbx_debug_level_size", "orbx_debug_fetch",
     "orbx_debug_eval_math", "orbx_debug_stage_timing", "orbx_debug_stage_time", "orbx_debug_nth_element", "orbx_debug_geometry",
     "orbm_debug_set_match_path",
     "orbm_debug_get_match_path",
@@ -150,6 +150,7 @@ def lib():
         L.orbm_distinctive.argtypes = [vp, vp, ci, vp, vp, ci]
         L.orbm_distinctive_device.argtypes = [vp, vp, ci, vp, vp, vp]
         L.orbx_debug_set_stop_after.argtypes = [vp, ci]
+        L.orbx_debug_set_blur_on_demand.argtypes = [vp, ci]
         L.orbx_debug_level_size.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.orbx_debug_fetch.argtypes = [vp, ci, ci, ci, vp, cl]
         L.orbx_debug_fetch.restype = cl
@@ -259,6 +260,12 @@ class ORBextractor:
     # diagnostics
     def set_stop_after(self, stage):
         self.L.orbx_debug_set_stop_after(self.h, stage)
+
+    def set_blur_on_demand(self, mode):
+        """1: the blur per keypoint window inside the description kernel (full launch groups); 0: blur kernels + blurred plane"""
+        rc = self.L.orbx_debug_set_blur_on_demand(self.h, int(mode))
+        if rc != ORBX_OK:
+            raise OrbxError(rc, "orbx_debug_set_blur_on_demand")
 
     STAGE_NAMES = ["pyramid", "fast_cells", "quota", "cell_select", "level_select", "blur", "describe"]
 

@@ -49,6 +49,7 @@ struct orbx_extractor {
     // diagnostics
     int stop_after = -1;
     bool no_xcd_affinity = false;     // ORBX_XCD_AFFINITY=0 at orbx_create (A/B measurements)
+    int blur_on_demand = ORBX_BLUR_ON_DEMAND_DEFAULT;   // ORBX_BLUR_ON_DEMAND=0/1 at orbx_create, orbx_debug_set_blur_on_demand
     StageTimer timer;
     SideStream side;
     Batch last;
@@ -170,6 +171,7 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
     // The blur runs on a side stream next to the latency-bound selection kernels (see launch_extract);
     // ORBX_OVERLAP=0 keeps everything on one stream (cleaner per-kernel timings when profiling).
     { const char* xa = getenv("ORBX_XCD_AFFINITY"); h->no_xcd_affinity = xa && xa[0] == '0'; }
+    { const char* od = getenv("ORBX_BLUR_ON_DEMAND"); if (od && (od[0] == '0' || od[0] == '1') && od[1] == 0) h->blur_on_demand = od[0] - '0'; }
     { const char* zc = getenv("ORBX_ZERO_COPY"); h->zero_copy = !(zc && zc[0] == '0'); }
     const char* ovl = getenv("ORBX_OVERLAP");
     if (ovl && ovl[0] == '0') { *out = h; return ORBX_OK; }
@@ -260,6 +262,7 @@ int orbx_extract_batch_device_phases(orbx_extractor* h, const uint8_t* d_imgs, i
         if (phases & ORBX_PHASE_DETECT) h->hint_parity ^= 1;
         b.nframes = std::min(h->p.max_batch, nframes - f0);
         b.xcd_affinity = (b.nframes >= XCD_AFFINITY_MIN_FRAMES && !h->no_xcd_affinity) ? 1 : 0;
+        b.blur_on_demand = h->blur_on_demand;
         b.img = d_imgs + (ptrdiff_t)f0 * frame_stride;
         b.img_row_stride = row_stride;
         b.img_frame_stride = frame_stride;
@@ -345,6 +348,12 @@ int orbx_extract(orbx_extractor* h, const uint8_t* img, int w, int hgt, ptrdiff_
 }
 
 // ---- diagnostics ---------------------------------------------------------------------------------
+int orbx_debug_set_blur_on_demand(orbx_extractor* h, int mode) {
+    if (!h || mode < 0 || mode > 1) return ORBX_ERR_ARG;
+    h->blur_on_demand = mode;
+    return ORBX_OK;
+}
+
 int orbx_debug_set_stop_after(orbx_extractor* h, int stage) {
     if (!h) return ORBX_ERR_ARG;
     h->stop_after = stage;

@@ -64,6 +64,9 @@ struct CellGeom {
 #ifndef ORBX_BLUR_WAVES
 #define ORBX_BLUR_WAVES 2
 #endif
+#ifndef ORBX_BLUR_ON_DEMAND_DEFAULT
+#define ORBX_BLUR_ON_DEMAND_DEFAULT 0     // (round 6) what a handle does when ORBX_BLUR_ON_DEMAND is not in the environment
+#endif
 #ifndef ORBX_DESC_PACKED_PATTERN
 #define ORBX_DESC_PACKED_PATTERN 1      // k_describe: the BRIEF pattern in LDS as packed int8 (1 KB) instead of floats (4 KB)
 #endif
@@ -238,6 +241,7 @@ struct Batch {
     int cap;
     int nframes;
     int xcd_affinity;         // 1: launches renumber their blocks so that a frame's work items share one XCD (its L2)
+    int blur_on_demand;       // 1: no blurred plane — k_describe_od blurs each keypoint's window itself (full launch groups of supported geometries)
 };
 
 // Host-side geometry builder result.
@@ -276,5 +280,8 @@ struct SideStream {
 // `phases`: ORBX_PHASE_* bits of include/orbx.h (which parts of the sequence to queue; ORBX_PHASE_ALL = everything)
 int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int stop_after, StageTimer* timer, const SideStream* side,
                    int phases = ORBX_PHASE_ALL);
+// k_describe_od.hip: the description stage with the Gaussian blur computed per keypoint window (no blurred plane)
+bool describe_od_supported(const Batch& b, const HostGeom& hg);
+int launch_describe_od(const Batch& b, const HostGeom& hg, hipStream_t stream);
 
 }  // namespace orbx

@@ -19,106 +19,9 @@
 
 #include "orb_math.h"
 #include "orbx_internal.h"
+#include "orbx_device.h"
 
 namespace orbx {
-
-__device__ __constant__ uint32_t c_pattern[256] = {
-#include "orb_pattern_packed.inc"
-};
-
-__device__ __forceinline__ const uint8_t* plain_plane(const Batch& b, const LevelGeom& L, int level, int frame, long long& stride) {
-    if (level == 0) {
-        stride = b.img_row_stride;
-        return b.img + (long long)frame * b.img_frame_stride;
-    }
-    stride = L.stride;
-    return b.pyr + (long long)frame * b.g.frame_plane_bytes + L.plane_off;
-}
-
-// threadIdx.x >> 6 is wave-uniform but the compiler cannot know it: pin it in an SGPR so that everything derived
-// from it (task -> level -> LevelGeom fields) is fetched with scalar loads instead of per-lane vector loads.
-__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
-
-// level of a flat task index: number of levels l >= 1 whose base is <= idx.  `bases` is a compact kernarg array
-// (INT_MAX beyond nlevels), so all compares are independent: one scalar-load round trip, no dependent chain.
-__device__ __forceinline__ int find_level(const int (&bases)[MAX_LEVELS], int idx) {
-    int level = 0;
-#pragma unroll
-    for (int l = 1; l < MAX_LEVELS; l++) level += idx >= bases[l] ? 1 : 0;
-    return level;
-}
-
-// Frame -> XCD affinity.  A launch deals its workgroups round-robin to the 8 XCDs (block b runs on XCD b % 8: observed dispatch
-// rule, used for speed only), each with its own 4 MiB L2.  In frame-major block order the workgroups of ONE frame would be spread
-// over all eight L2s, and every L2 would fetch its own copy of the 128-byte sectors that neighbouring cells, strips or keypoint
-// windows share.  With `xcd_affinity` a launch's blocks are renumbered so that all work items of frame f run on XCD f % 8:
-// block b -> (frame, item) = ((b >> 3) / per_frame * 8 + (b & 7), (b >> 3) % per_frame); the grid is rounded up to whole groups of
-// 8 frames and blocks of frames >= nframes exit.  Used from XCD_AFFINITY_MIN_FRAMES frames per launch (small launches want every
-// CU, not locality).
-__device__ __forceinline__ bool frame_item(const Batch& b, int block, int per_frame, int& frame, int& item) {
-    if (b.xcd_affinity) {
-        const int slot = block >> 3;
-        const int fr = slot / per_frame;
-        frame = fr * 8 + (block & 7);
-        item = slot - fr * per_frame;
-    } else {
-        frame = block / per_frame;
-        item = block - frame * per_frame;
-    }
-    return frame < b.nframes;
-}
-// The same split with the division replaced by a multiply with magic = floor(2^32 / per_frame) + 1 (host: DevGeom::nbands_magic; 0 = one
-// item per frame): umulhi(n, magic) is n / per_frame or one more for every 32-bit n (the excess n * (magic * per_frame - 2^32) / (per_frame * 2^32)
-// is below n / 2^32 < 1), so one compare corrects it.  Everything is wave-uniform: scalar multiplies instead of the ~20 vector instructions of
-// an integer division in front of every wave of a kernel whose waves are short (k_fast_cells).
-__device__ __forceinline__ bool frame_item_magic(const Batch& b, unsigned block, unsigned per_frame, unsigned magic, int& frame, int& item) {
-    const unsigned slot = b.xcd_affinity ? block >> 3 : block;
-    unsigned fr = magic ? __umulhi(slot, magic) : slot;
-    if (fr * per_frame > slot) --fr;
-    frame = (int)(b.xcd_affinity ? fr * 8u + (block & 7u) : fr);
-    item = (int)(slot - fr * per_frame);
-    return frame < b.nframes;
-}
-static inline int frame_item_blocks(const Batch& b, int per_frame) {
-    return (b.xcd_affinity ? (b.nframes + 7) / 8 * 8 : b.nframes) * per_frame;
-}
-
-constexpr unsigned long long UMAX_NIBBLES = 0x3689ABCDDEEEFFFFull;   // umax[v] for v = 0..15 (15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3)
-
-// inclusive prefix sum over the 64 lanes in six DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast15 / row_bcast31
-// across them) — no LDS round trips (__shfl_up is a ds_bpermute per step).  Needs all 64 lanes active.
-__device__ __forceinline__ int wave_scan_inclusive(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
-    return v;
-}
-
-__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_scan_inclusive(v), 63); }   // all 64 lanes active
-
-// sum over each row of 16 lanes, left in every lane of the row: four rotate-and-add steps (DPP row_ror 8, 4, 2, 1)
-__device__ __forceinline__ int row16_sum(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);
-    return v;
-}
-
-
-// p -> (p / cw, p % cw) for p < 65536, cw <= 8192 with full-rate VALU ops only (v_mul_lo/hi_u32 are quarter
-// rate): q = trunc((p + 0.5) * (1/cw)), exact for every (p, cw) in that range (exhaustively checked offline).
-__device__ __forceinline__ void split_px(int p, int cw, float inv_cw, int& y, int& x) {
-    y = (int)(((float)p + 0.5f) * inv_cw);
-    x = p - (int)__umul24((unsigned)y, (unsigned)cw);
-}
-
-typedef unsigned short us2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ us2v as_us2v(uint32_t v) { return __builtin_bit_cast(us2v, v); }
-
 
 __device__ __forceinline__ int fast_pair_test(const uint8_t* c, int S, int v, int t) {
     // ring offsets k=0..15 (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
@@ -896,7 +799,6 @@ struct RespGreater {   // KeypointResponseGreater (OpenCV keypoint.cpp)
     __host__ __device__ constexpr bool operator()(const Cand& x, const Cand& y) const { return x.resp > y.resp; }
 };
 
-__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
 __device__ __forceinline__ int mask_rank(unsigned long long m) {     // number of set bits of m below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -1465,15 +1367,6 @@ constexpr int MB_IN_CHUNKS = 2 * MB_TILES + 2;                       // 16-byte 
 constexpr int MB_IN_BYTES = 32 * MB_IN_CHUNKS * 16;                  // one input buffer: 32 rows
 constexpr int MB_OUT_PITCH = MB_TILES * 32 + 16;                     // bytes per row of the staged output (80: conflict-free ds_write_b128 of a row per lane)
 static_assert(MB_TILES == 2, "k_blur_mfma's lane maps are written for two tiles per strip");
-
-__device__ __forceinline__ int gauss7_tap(int t) {      // [18, 34, 49, 55, 49, 34, 18][t], 0 outside
-    return (unsigned)t <= 6u ? (int)((0x12223137312212ull >> (8 * t)) & 255ull) : 0;
-}
-__device__ __forceinline__ int gauss7_taps4(int t0) {   // the bytes tap(t0), tap(t0 + 1), tap(t0 + 2), tap(t0 + 3): a window of the tap string
-    const unsigned long long taps = 0x12223137312212ull;
-    const int sh = 8 * min(max(t0, -4), 7);             // |shift| <= 56 bits; beyond that the window is empty anyway
-    return (int)(uint32_t)(t0 >= 0 ? taps >> sh : taps << -sh);
-}
 
 __global__ __launch_bounds__(MB_WAVES * 64) void k_blur_mfma(Batch b) {      // (134 VGPRs: three waves per SIMD, each with two independent chains)
     // three LDS objects on purpose: hipcc orders a ds_read behind an outstanding LDS-DMA (s_waitcnt vmcnt(0)) unless it can prove that
@@ -2096,6 +1989,10 @@ struct StageScope {   // records (start, stop) events around one stage when timi
     }
 };
 
+static bool use_on_demand(const Batch& b, const HostGeom& hg, int stop_after) {
+    return b.blur_on_demand && b.nframes >= PYR_FUSED_MAX_FRAMES && stop_after < 0 && describe_od_supported(b, hg);
+}
+
 int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int stop_after, StageTimer* timer, const SideStream* side, int phases) {
     const DevGeom& g = hg.g;
     const int F = b.nframes;
@@ -2164,7 +2061,10 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     };
     // (a launch group that cannot fill the chip keeps the blur in line: its short strips take ~6 us, the fork and the join across
     //  two hardware queues cost 8 us each)
-    const bool overlap = side && side->aux && stop_after < 0 && F >= PYR_FUSED_MAX_FRAMES;
+    // blur on demand (k_describe_od.hip): full launch groups only (the one-frame call keeps the blur inside the FAST launch), never under the
+    // diagnostics' early stops (they fetch the blurred plane)
+    const bool on_demand = use_on_demand(b, hg, stop_after);
+    const bool overlap = side && side->aux && stop_after < 0 && F >= PYR_FUSED_MAX_FRAMES && !on_demand;
     const bool fuse_blur = F < PYR_FUSED_MAX_FRAMES && !b.xcd_affinity;    // k_fast_blur
     {
         StageScope sc(timer, stream, ST_FAST_CELLS);
@@ -2234,13 +2134,14 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     if (stop_after == ST_LEVEL_SELECT) return ORBX_OK;
     if (overlap) {
         if (hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) return ORBX_ERR_DEVICE;
-    } else if (!fuse_blur && launch_blur(stream) != ORBX_OK) return ORBX_ERR_DEVICE;
+    } else if (!fuse_blur && !on_demand && launch_blur(stream) != ORBX_OK) return ORBX_ERR_DEVICE;
     if (stop_after == ST_BLUR) return ORBX_OK;
     }
 describe:
     if (phases & ORBX_PHASE_DESCRIBE) {
         StageScope sc(timer, stream, ST_DESCRIBE);
-        if (g.fp_contract) hipLaunchKernelGGL(k_describe<true>, dim3(frame_item_blocks(b, (g.nquads + DESC_WAVES - 1) / DESC_WAVES)), dim3(DESC_WAVES * 64), 0, stream, b);
+        if (use_on_demand(b, hg, stop_after)) { if (launch_describe_od(b, hg, stream) != ORBX_OK) return ORBX_ERR_DEVICE; }
+        else if (g.fp_contract) hipLaunchKernelGGL(k_describe<true>, dim3(frame_item_blocks(b, (g.nquads + DESC_WAVES - 1) / DESC_WAVES)), dim3(DESC_WAVES * 64), 0, stream, b);
         else hipLaunchKernelGGL(k_describe<false>, dim3(frame_item_blocks(b, (g.nquads + DESC_WAVES - 1) / DESC_WAVES)), dim3(DESC_WAVES * 64), 0, stream, b);
         ORBX_LAUNCH_CHECK();
     }
