@@ -65,7 +65,8 @@ struct CellGeom {
 #define ORBX_BLUR_WAVES 2
 #endif
 #ifndef ORBX_BLUR_ON_DEMAND_DEFAULT
-#define ORBX_BLUR_ON_DEMAND_DEFAULT 0     // (round 6) what a handle does when ORBX_BLUR_ON_DEMAND is not in the environment
+#define ORBX_BLUR_ON_DEMAND_DEFAULT 1     // (round 6) what a handle does when ORBX_BLUR_ON_DEMAND is not in the environment: full launch groups blur per keypoint
+                                          // window (k_describe_od: VGA 381.5k -> 404.1k frames/s, 1080p 75.2k -> 90.4k on the first build; profiles/r06_ab_on_demand.txt)
 #endif
 #ifndef ORBX_DESC_PACKED_PATTERN
 #define ORBX_DESC_PACKED_PATTERN 1      // k_describe: the BRIEF pattern in LDS as packed int8 (1 KB) instead of floats (4 KB)

@@ -92,3 +92,26 @@ def test_on_demand_blur_pitched_and_unaligned_inputs(gpu_extractor_factory):
             ok, od = want[f]
             assert n[f] == len(ok)
             assert k[f, :n[f]].tobytes() == ok.tobytes() and np.array_equal(d[f, :n[f]], od), (row_stride, offset, f)
+
+
+def test_on_demand_blur_on_adversarial_frames(gpu_extractor_factory):
+    """saturated / binary / checkerboard / step frames (the rounding ties and the saturation of the filter), both rounding modes"""
+    w, h = 640, 480
+    yy, xx = np.mgrid[0:h, 0:w]
+    rng = np.random.default_rng(9)
+    fr = [(((yy // 5 + xx // 7) & 1) * 255).astype(np.uint8), (((yy // 9 + xx // 4) & 1) * 254 + 1).astype(np.uint8),
+          np.where((xx // 16 + yy // 12) & 1, 255, 0).astype(np.uint8), (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8),
+          np.where(rng.random((h, w)) < 0.02, 255, 0).astype(np.uint8), np.where(rng.random((h, w)) < 0.02, 0, 255).astype(np.uint8),
+          (((yy * 3 + xx * 5) // 11) & 255).astype(np.uint8), np.full((h, w), 255, np.uint8)]
+    fr += [synth.frame(w, h, synth.NOISE, 700 + i) for i in range(32 - len(fr))]
+    frames = np.stack(fr)
+    for mode in (capi.BLUR_X86_SSE2, capi.BLUR_HALF_UP):
+        ex = gpu_extractor_factory(max_batch=32, blur_rounding=mode)
+        ex.set_blur_on_demand(1)
+        k, d, n = _run(ex, frames, ex.max_keypoints)
+        o = orc.OracleExtractor(blur_mode=mode)
+        for f in range(len(frames)):
+            ok, od = o(frames[f])
+            assert n[f] == len(ok), (mode, f)
+            assert k[f, :n[f]].tobytes() == ok.tobytes() and np.array_equal(d[f, :n[f]], od), (mode, f)
+    assert n[:7].sum() > 1000

@@ -574,6 +574,7 @@ def test_blur_planes_of_a_full_launch_group(gpu_extractor_factory, cfg):
     buf[:, :, :w] = frames
     d_img = torch.from_numpy(buf).cuda()
     ex = gpu_extractor_factory(max_batch=B, **cfg)
+    ex.set_blur_on_demand(0)                    # this test is about the blur KERNELS' planes (round 6: full launch groups blur per keypoint window by default)
     cap = ex.max_keypoints
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
