@@ -233,7 +233,7 @@ def measure_live_traffic(frames_per_launch, timeout_s=150.0):
     if any(k.startswith(("ROCPROF", "ROCP_")) or k == "HSA_TOOLS_LIB" for k in os.environ):
         return None, "this run is itself under a profiler (its environment would reach the child runs)"
     stage = {"k_resize": "pyramid", "k_fast_cells": "fast_cells", "k_quota": "quota", "k_cell_select": "cell_select", "k_level_select": "level_select",
-             "k_blur": "blur", "k_blur_mfma": "blur", "k_describe": "describe", "k_match_batch": "match", "k_match_batch_mfma": "match"}
+             "k_blur": "blur", "k_blur_mfma": "blur", "k_describe": "describe", "k_describe_od": "describe", "k_match_batch": "match", "k_match_batch_mfma": "match"}
     td = tempfile.mkdtemp(prefix="orbx_live_traffic_", dir="/tmp")
     env = {k: v for k, v in os.environ.items()                      # the child runs are plain one-rank commands, whatever launched this one
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT") and not k.startswith("TORCHELASTIC_")}

@@ -45,12 +45,15 @@ constexpr int OD_WAVES = DESC_WAVES;
 constexpr int OD_TAIL = 512;                                     // the operand reads of row tile 2 run 5 rows past a window (garbage in, unused out)
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+__host__ __device__ constexpr int od_col0(int ct) { return ct == 0 ? 0 : ct == 1 ? 16 : 24; }      // first output column c' of column tile ct
+__host__ __device__ constexpr int od_row0(int rt) { return rt == 0 ? 0 : rt == 1 ? 16 : 21; }      // first output row ro of row tile rt
 typedef const void __attribute__((address_space(1))) * gptr_t;
 typedef void __attribute__((address_space(3))) * lptr_t;
 
 template <bool FMA>
 __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
-    __shared__ uint32_t s_pat[256];                                     // test t: x0, y0, x1, y1 as the four int8 of c_pattern[t]
+    __shared__ __attribute__((aligned(16))) float s_pat[256 * 4];       // test t: x0, y0, x1, y1 as floats (one ds_read_b128 = the two points as register pairs)
     __shared__ __attribute__((aligned(16))) uint32_t s_mask[256];       // circle byte masks of the 31 x 8 patch dwords (slots 248.. = 0)
     __shared__ __attribute__((aligned(16))) uint8_t s_win[OD_WAVES * OD_KPW * OD_WIN_BYTES + OD_TAIL];
     const DevGeom& g = b.g;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
     }
     for (int t = tid; t < 256; t += OD_WAVES * 64) {
         const uint32_t pk = t == tid ? pk_first : c_pattern[t];
-        s_pat[t] = pk;
+        reinterpret_cast<float4*>(s_pat)[t] = make_float4((float)(int)(int8_t)pk, (float)(int)(int8_t)(pk >> 8), (float)(int)(int8_t)(pk >> 16), (float)(int)(int8_t)(pk >> 24));
         const int r = t >> 3, c = t & 7;
         const int v = r - HALF_PATCH, av = v < 0 ? -v : v;
         const int um = r < 31 ? (int)((UMAX_NIBBLES >> (4 * (av & 15))) & 15ull) : -1;
@@ -139,11 +142,13 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
 
     // ---- the four windows by LDS-DMA: chunk e = 64 n + lane <-> row e / 3, chunk e % 3 of the row
     int erow[3], ecol[3];
+    unsigned eoff[3];                                        // the chunk's offset from the window's first byte in the level
 #pragma unroll
     for (int n = 0; n < 3; n++) {
         const int e = 64 * n + lane;
         erow[n] = (e * 171) >> 9;                            // e / 3 for e < 193
         ecol[n] = 16 * (e - 3 * erow[n]);
+        eoff[n] = __umul24((unsigned)erow[n], pstride) + (unsigned)ecol[n];
     }
     uint32_t fixmask = 0;                                    // (wave-uniform) bit q: window q has columns to put right; bit 4 + q: it reaches outside the level
 #pragma unroll
@@ -154,6 +159,14 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
         const int xs = (xq - 22) & ~3;
         if (xs < 0 || xs + 48 > wlim || xq + 21 >= L.w) fixmask |= 1u << q;
         if (xq < 18 || xq + 18 >= L.w || yq < 18 || yq + 21 >= L.h) fixmask |= 16u << q;
+        if (xs >= 0 && xs + 48 <= wlim && yq >= 21 && yq + 21 < L.h) {       // (wave-uniform) the whole window lies inside the level's readable rows:
+            const uint8_t* srcq = plain + (__umul24((unsigned)(yq - 21), pstride) + (unsigned)xs);      // one scalar base, the lanes' constant offsets
+#pragma unroll
+            for (int n = 0; n < 3; n++)
+                if (n < 2 || lane < OD_CHUNKS - 128)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(srcq + eoff[n]), (lptr_t)(win0 + q * OD_WIN_BYTES + 1024 * n), 16, 0, 0);
+            continue;
+        }
 #pragma unroll
         for (int n = 0; n < 3; n++) {
             if (n == 2 && lane >= OD_CHUNKS - 128) continue;
@@ -171,14 +184,17 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
 
     // ---- lane constants of the two passes (independent of the keypoint)
     const int n16 = li, g4 = grp;                            // the MFMA's view of the lane: row / column lane % 16, K block lane / 16
+    // Tile origins: output columns c' = 0 / 16 / 24 + n, output rows ro = 0 / 16 / 21 + n.  The third tile of either axis OVERLAPS the second instead
+    // of running past what is needed (c' <= 39, ro <= 36): every output of every tile is one the taps can reach or a second, identical copy
+    // of one, every store lands inside the window — no predicate anywhere (round 6: 374 -> 2xx VALU instructions per keypoint).
     v4i Trow[3], Tcol[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         int tr[4], tc[4];
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-            tr[v] = gauss7_taps4(16 * g4 + 4 * v - (16 * c + n16) - 1);       // K = window column 16 g + 4 v + byte, output column c' = 16 c + n
-            tc[v] = gauss7_taps4(16 * v + 4 * g4 - (16 * c + n16));           // K = 16 g + 4 v + byte <-> Mid row 16 v + 4 g + byte, output row ro = 16 c + n
+            tr[v] = gauss7_taps4(16 * g4 + 4 * v - (od_col0(c) + n16) - 1);   // K = window column 16 g + 4 v + byte, output column c' = col0 + n
+            tc[v] = gauss7_taps4(16 * v + 4 * g4 - (od_row0(c) + n16));       // K = 16 g + 4 v + byte <-> Mid row 16 v + 4 g + byte, output row ro = row0 + n
         }
         Trow[c] = (v4i){tr[0], tr[1], tr[2], tr[3]};
         Tcol[c] = (v4i){tc[0], tc[1], tc[2], tc[3]};
@@ -268,17 +284,13 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
     wave_lds_fence();                                          // every patch read is done before the windows are overwritten
 
     // ---- the blur, window after window, the whole wave on each
-#pragma unroll 1
-    for (int q = 0; q < OD_KPW; q++) {
-        if (q > 0 && k0 + q >= cnt) continue;                // wave-uniform
-        const unsigned posq = (unsigned)__builtin_amdgcn_readlane((int)kp.pos, 16 * q);
-        const int xq = posq & 0xFFFF, yq = posq >> 16;
-        const int xs = (xq - 22) & ~3;
-        const bool edge = ((fixmask >> (4 + q)) & 1u) != 0;
-        uint8_t* W = win0 + q * OD_WIN_BYTES;
+    const unsigned a_off = (unsigned)(n16 * OD_PITCH + 16 * g4);                 // the lane's 16 operand bytes in a row tile
+    const unsigned o_off = (unsigned)((n16 + 3) * OD_PITCH + 4 + 4 * g4);        // the lane's output dword in tile (0, 0)
+    auto blur_window = [&](auto EDGE, uint8_t* W, int xs, int yq) {
+        constexpr bool edge = decltype(EDGE)::value;
         v4i A[3];
         {
-            const unsigned ra = (unsigned)(uintptr_t)(lptr_t)(W + n16 * OD_PITCH + 16 * g4);
+            const unsigned ra = (unsigned)(uintptr_t)(lptr_t)(W + a_off);
             asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:768\n\tds_read_b128 %2, %3 offset:1536\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]) : "v"(ra) : "memory");
         }
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
         }
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) {
-            // row pass of column tile ct: z[t] = S - 32768 for Mid rows 16 t + 4 g + i, column c' = 16 ct + n
+            // row pass of column tile ct: z[t] = S - 32768 for Mid rows 16 t + 4 g + i, column c' = col0(ct) + n
             const v4i c128 = {128, 128, 128, 128};
             v4i z[3];
 #pragma unroll
@@ -303,8 +315,13 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
                 h4[t] = (int)__builtin_amdgcn_perm(p23, p01, 0x07060302u);
             }
             const v4i HI = {h4[0], h4[1], h4[2], h4[3]}, LO = {l4[0], l4[1], l4[2], l4[3]};
-            const int X0 = xs + 4 + 16 * ct + 4 * g4;        // level column of the lane's first output byte (a multiple of 4)
+            const int X0 = xs + 4 + od_col0(ct) + 4 * g4;    // level column of the lane's first output byte (a multiple of 4)
             const uint32_t tw = X0 < L.wvec ? 1u : 0u;       // ties-to-even columns (blur_wvec is a multiple of 4)
+            uint32_t keepc = 0;                              // (edge windows) bytes of the dword whose column lies outside the level
+            if (edge) {
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) keepc |= ((unsigned)(X0 + bb) < (unsigned)L.w ? 0u : 0xFFu) << (8 * bb);
+            }
 #pragma unroll
             for (int rt = 0; rt < 3; rt++) {
                 const v4i zero = {0, 0, 0, 0};
@@ -321,21 +338,26 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
                 const us2v lo2 = __builtin_elementwise_min(as_us2v(__builtin_amdgcn_perm(qv[1], qv[0], 0x07060302u)), as_us2v(0x00FF00FFu));
                 const us2v hi2 = __builtin_elementwise_min(as_us2v(__builtin_amdgcn_perm(qv[3], qv[2], 0x07060302u)), as_us2v(0x00FF00FFu));
                 uint32_t o = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi2), __builtin_bit_cast(uint32_t, lo2), 0x06040200u);
-                const int ro = 16 * rt + n16;                // output row (window row ro + 3); rows beyond 36 and columns beyond 43 are never tapped
-                bool wr = ro <= 36 && !(ct == 2 && g4 >= 2);
-                uint32_t* dst = reinterpret_cast<uint32_t*>(W + (ro + 3) * OD_PITCH + 4 + 16 * ct + 4 * g4);
+                uint32_t* dst = reinterpret_cast<uint32_t*>(W + o_off + (od_row0(rt) * OD_PITCH + od_col0(ct)));
                 if (edge) {
-                    // out-of-level positions keep the plain reflected pixel (H4): per-byte merge
-                    const int Y = yq - 18 + ro;
-                    uint32_t keep = 0;
-#pragma unroll
-                    for (int bb = 0; bb < 4; bb++) keep |= ((unsigned)(X0 + bb) < (unsigned)L.w ? 0u : 0xFFu) << (8 * bb);
-                    if ((unsigned)Y >= (unsigned)L.h) keep = 0xFFFFFFFFu;
-                    if (wr && keep != 0) { o = (o & ~keep) | (*dst & keep); }
+                    // out-of-level positions keep the plain reflected pixel (H4): per-byte merge with what the window holds
+                    const int Y = yq - 18 + od_row0(rt) + n16;
+                    const uint32_t keep = (unsigned)Y < (unsigned)L.h ? keepc : 0xFFFFFFFFu;
+                    o = (o & ~keep) | (*dst & keep);
                 }
-                if (wr) *dst = o;
+                *dst = o;
             }
         }
+    };
+#pragma unroll 1
+    for (int q = 0; q < OD_KPW; q++) {
+        if (q > 0 && k0 + q >= cnt) continue;                // wave-uniform
+        const unsigned posq = (unsigned)__builtin_amdgcn_readlane((int)kp.pos, 16 * q);
+        const int xq = posq & 0xFFFF, yq = posq >> 16;
+        const int xs = (xq - 22) & ~3;
+        uint8_t* W = win0 + q * OD_WIN_BYTES;
+        if ((fixmask >> (4 + q)) & 1u) blur_window(std::true_type{}, W, xs, yq);      // (wave-uniform)
+        else blur_window(std::false_type{}, W, xs, yq);
     }
     wave_lds_fence();
 
@@ -343,25 +365,34 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float sn, cs;
     sincosf_orb(angle * factorPI, &sn, &cs);
-    struct PatRow {
-        const uint32_t* p;
-        __device__ __forceinline__ float4 operator[](int i) const {
-            const uint32_t pk = p[i];
-            return make_float4((float)(int)(int8_t)pk, (float)(int)(int8_t)(pk >> 8), (float)(int)(int8_t)(pk >> 16), (float)(int)(int8_t)(pk >> 24));
-        }
-    } pat{s_pat + li};
+    const float4* pat = reinterpret_cast<const float4*>(s_pat) + li;
     uint32_t mybits = 0;                                        // bit j: test li + 16 j
     {
+        // Both coordinates of a point in ONE packed-fp32 instruction each step (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: IEEE single
+        // precision per half, the same roundings as the scalar forms):  (x sn, x cs), (y cs, y sn), then (x sn + y cs, x cs - y sn).
         const uint8_t* ctr = Wown + 21 * OD_PITCH + cx;
+        const f2v SC = {sn, cs};
+        const f2v P48 = {(float)OD_PITCH, (float)OD_PITCH};
+        auto rotate = [&](f2v pt) -> f2v {                      // (x, y) -> (row offset, column offset), unrounded
+            f2v m1, r;
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(m1) : "v"(pt), "v"(SC));                  // (y cs, y sn)
+            if (FMA) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(pt), "v"(SC), "v"(m1));   // fma(x, sn, y cs), fma(x, cs, -(y sn))
+            else {
+                f2v m0;
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(m0) : "v"(pt), "v"(SC));              // (x sn, x cs)
+                asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(m0), "v"(m1));                               // (x sn + y cs, x cs - y sn)
+            }
+            return r;
+        };
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const float4 P = pat[16 * j];
-            const float fy0 = FMA ? __builtin_fmaf(P.x, sn, P.y * cs) : P.x * sn + P.y * cs, fx0 = FMA ? __builtin_fmaf(P.x, cs, -(P.y * sn)) : P.x * cs - P.y * sn;
-            const float fy1 = FMA ? __builtin_fmaf(P.z, sn, P.w * cs) : P.z * sn + P.w * cs, fx1 = FMA ? __builtin_fmaf(P.z, cs, -(P.w * sn)) : P.z * cs - P.w * sn;
-            // cvRound (ties to even) of both coordinates, then iy * pitch + ix exactly in float (the fused multiply-add rounds nothing here)
-            const int o0 = (int)__builtin_fmaf(__builtin_rintf(fy0), (float)OD_PITCH, __builtin_rintf(fx0));
-            const int o1 = (int)__builtin_fmaf(__builtin_rintf(fy1), (float)OD_PITCH, __builtin_rintf(fx1));
-            const int v0 = ctr[o0], v1 = ctr[o1];
+            const f2v r0 = rotate((f2v){P.x, P.y}), r1 = rotate((f2v){P.z, P.w});
+            // cvRound (ties to even) of the four coordinates, then iy * pitch + ix of both points exactly in float, one packed fma
+            const f2v iy = {__builtin_rintf(r0.x), __builtin_rintf(r1.x)}, ix = {__builtin_rintf(r0.y), __builtin_rintf(r1.y)};
+            f2v of;
+            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(of) : "v"(iy), "v"(P48), "v"(ix));
+            const int v0 = ctr[(int)of.x], v1 = ctr[(int)of.y];
             mybits |= (uint32_t)(v0 < v1) << j;
         }
     }

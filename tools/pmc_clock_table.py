@@ -11,7 +11,7 @@ try:
     mix = json.load(open(os.path.join(root, "profiles", "valu_mix.json")))["kernels"]
 except Exception:
     mix = {}
-KEY = {"k_fast_cells": "fast_cells", "k_blur": "blur", "k_describe": "describe", "k_resize": "pyramid", "k_match_batch": "match", "k_cell_select": "cell_select",
+KEY = {"k_fast_cells": "fast_cells", "k_blur": "blur", "k_describe": "describe", "k_describe_od": "describe", "k_resize": "pyramid", "k_match_batch": "match", "k_cell_select": "cell_select",
        "k_level_select": "level_select", "k_quota": "quota"}
 for tag in ("vga", "hd"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from orb_slam_amd import capi
 fetch_csv, write_csv, out, batch = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 STAGE = {"k_resize": "pyramid", "k_fast_cells": "fast_cells", "k_quota": "quota", "k_cell_select": "cell_select",
-         "k_level_select": "level_select", "k_blur": "blur", "k_blur_mfma": "blur", "k_describe": "describe", "k_match_batch": "match", "k_match_batch_mfma": "match"}
+         "k_level_select": "level_select", "k_blur": "blur", "k_blur_mfma": "blur", "k_describe": "describe", "k_describe_od": "describe", "k_match_batch": "match", "k_match_batch_mfma": "match"}
 # (a workload runs ONE of k_blur / k_blur_mfma: VGA-class levels take the matrix-core form, wider ones the VALU form)
 def load(path, counter):
     acc = collections.defaultdict(list)

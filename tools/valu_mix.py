@@ -21,7 +21,7 @@ SLOW = {"v_and_or_b32", "v_min_u32", "v_max_u32", "v_min_i32", "v_max_i32", "v_l
         "v_pk_add_u16", "v_pk_sub_i16", "v_pk_min_u16", "v_pk_max_u16", "v_pk_lshrrev_b16", "v_lerp_u8", "v_min_f32", "v_max_f32", "v_mbcnt_lo_u32_b32",
         "v_mbcnt_hi_u32_b32", "v_add_co_u32", "v_bfi_b32", "v_alignbit_b32", "v_cvt_pk_u8_f32", "v_xnor_b32", "v_dot4_i32_i8", "v_dot8_i32_i4"}   # round 2 measurements
 STAGE = {"k_resize<true, true>": "pyramid", "k_fast_cells<true, 256, 1>": "fast_cells", "k_fast_cells<true, 256, 2>": "fast_cells_large",
-         "k_quota": "quota", "k_cell_select": "cell_select", "k_level_select": "level_select", "k_blur_mfma": "blur", "k_blur<true, 32>": "blur_valu", "k_describe": "describe",
+         "k_quota": "quota", "k_cell_select": "cell_select", "k_level_select": "level_select", "k_blur_mfma": "blur", "k_blur<true, 32>": "blur_valu", "k_describe": "describe", "k_describe_od": "describe",
          "k_match_batch_mfma4<4>": "match", "k_match_batch_mfma<4>": "match_int8"}
 hist = {}
 with tempfile.TemporaryDirectory() as td:
