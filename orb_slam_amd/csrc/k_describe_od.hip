@@ -46,6 +46,7 @@ constexpr int OD_TAIL = 512;                                     // the operand 
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int float_bits(float v) { return __builtin_bit_cast(int, v); }
 __host__ __device__ constexpr int od_col0(int ct) { return ct == 0 ? 0 : ct == 1 ? 16 : 24; }      // first output column c' of column tile ct
 __host__ __device__ constexpr int od_row0(int rt) { return rt == 0 ? 0 : rt == 1 ? 16 : 21; }      // first output row ro of row tile rt
 typedef const void __attribute__((address_space(1))) * gptr_t;
@@ -372,7 +373,6 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
         // precision per half, the same roundings as the scalar forms):  (x sn, x cs), (y cs, y sn), then (x sn + y cs, x cs - y sn).
         const uint8_t* ctr = Wown + 21 * OD_PITCH + cx;
         const f2v SC = {sn, cs};
-        const f2v P48 = {(float)OD_PITCH, (float)OD_PITCH};
         auto rotate = [&](f2v pt) -> f2v {                      // (x, y) -> (row offset, column offset), unrounded
             f2v m1, r;
             asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(m1) : "v"(pt), "v"(SC));                  // (y cs, y sn)
@@ -384,15 +384,25 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
             }
             return r;
         };
+        // cvRound (ties to even) by the magic constant: for |f| < 2^22, f + 1.5 * 2^23 rounds to the integer nearest f (ties to even, the
+        // default mode) and its bit pattern is 0x4B400000 + that integer.  iy * pitch + ix is then ONE 24-bit multiply-add on the bit patterns
+        // (the low 24 bits of the first are 0x400000 + iy); the constant it drags along is taken off the base address once.
+        f2v MAGIC = {12582912.0f, 12582912.0f};
+        asm("" : "+v"(MAGIC));                                  // in a VGPR pair: as an SGPR pair with op_sel_hi:[1,0] (what hipcc 7.2 emits for the splat) the packed add gave wrong sums
+        const uint32_t ctr_a = (uint32_t)(uintptr_t)(lptr_t)ctr - (uint32_t)(OD_PITCH * 0x400000 + 0x4B400000);
+        typedef const uint8_t __attribute__((address_space(3))) * lbyte_t;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const float4 P = pat[16 * j];
-            const f2v r0 = rotate((f2v){P.x, P.y}), r1 = rotate((f2v){P.z, P.w});
-            // cvRound (ties to even) of the four coordinates, then iy * pitch + ix of both points exactly in float, one packed fma
-            const f2v iy = {__builtin_rintf(r0.x), __builtin_rintf(r1.x)}, ix = {__builtin_rintf(r0.y), __builtin_rintf(r1.y)};
-            f2v of;
-            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(of) : "v"(iy), "v"(P48), "v"(ix));
-            const int v0 = ctr[(int)of.x], v1 = ctr[(int)of.y];
+            f2v r0 = rotate((f2v){P.x, P.y}), r1 = rotate((f2v){P.z, P.w});
+            r0 = r0 + MAGIC;                                    // (v_pk_add_f32)
+            r1 = r1 + MAGIC;
+            // (the elements go through scalar temporaries: hipcc 7.2 folds __builtin_bit_cast(int, vec.y) of a vector ELEMENT expression to element 0 —
+            //  `mad24(bits(r.x), 48, bits(r.x))` came out of the direct form; tools/microbench/bitcast_vector_element.hip)
+            const float r0y = r0.x, r0x = r0.y, r1y = r1.x, r1x = r1.y;
+            const uint32_t o0 = (uint32_t)(__mul24(float_bits(r0y), OD_PITCH) + float_bits(r0x));
+            const uint32_t o1 = (uint32_t)(__mul24(float_bits(r1y), OD_PITCH) + float_bits(r1x));
+            const int v0 = *(lbyte_t)(uintptr_t)(ctr_a + o0), v1 = *(lbyte_t)(uintptr_t)(ctr_a + o1);
             mybits |= (uint32_t)(v0 < v1) << j;
         }
     }
