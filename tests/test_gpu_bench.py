@@ -119,10 +119,15 @@ def test_traffic_is_measured_in_the_run():
     d = _bench("--steps", "2", "--warmup", "1", "--min-seconds", "0.2", "--no-also", "--no-cpu-baseline", "--live-traffic", "on")
     rf = d["roofline"]
     assert rf["traffic_source"] == "measured in this run", rf.get("traffic_source")
-    assert rf["kernel"] == "fast_cells" and 0.9 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.3         # the band staging reads each level once (+ halos)
+    # round 6: with the blur computed per keypoint window the description kernel (k_describe_od) and k_fast_cells are the two longest kernels
+    assert rf["kernel"] in ("fast_cells", "describe")
+    if rf["kernel"] == "fast_cells":
+        assert 0.9 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.3       # the band staging reads each level once (+ halos)
+    else:
+        assert 0.3 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 2.5       # one 43 x 48-byte window per key point (neighbouring windows share lines in L2) against patch + taps + outputs
     assert d["line"]["roofline"]["traffic"] == rf["traffic"] and d["line"]["roofline"]["traffic_measured_in_this_run"] is True
     per_stage = d["traffic_per_stage_this_run"]
-    assert set(per_stage) >= {"pyramid", "fast_cells", "blur", "describe", "match"} and d["roofline_pipeline"]["traffic"] == sum(per_stage.values())
+    assert set(per_stage) >= {"pyramid", "fast_cells", "describe", "match"} and d["roofline_pipeline"]["traffic"] == sum(per_stage.values())
     if rf.get("traffic_replayed"):           # the committed table of this build agrees with what the run measured
         assert abs(rf["traffic_replayed"] / rf["traffic"] - 1) < 0.05
 
