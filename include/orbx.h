@@ -119,6 +119,10 @@ int orbx_extract(orbx_extractor* h, const uint8_t* img, int w, int hgt, ptrdiff_
  * min(row_stride, w rounded up to 16) bytes — the kernels stage rows in whole 16-byte chunks (as a hipMallocPitch-style
  * buffer of row_stride x hgt bytes per frame guarantees).  Fastest when d_imgs, row_stride and frame_stride are multiples of
  * 16 (any alignment is accepted: bytes are then assembled on the fly). */
+/* Temporal coherence is used for SPEED only, per frame slot: slot f of a launch group (frame f0 + f of a call, f < max_batch) remembers which
+ * of its grid-cell bands took the reference's threshold-7 fallback (src/ORBextractor.cc:609-614) in the last launch groups and starts those at 7
+ * right away.  Outputs never depend on it; a caller that keeps each camera / sequence in the same slots of consecutive calls gets the fast pass,
+ * a slot whose content changes class pays one slower pass per band for a few calls.  ORBX_FALLBACK_HINT=0 at orbx_create switches it off. */
 int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int nframes, int w, int hgt,
                               ptrdiff_t row_stride, ptrdiff_t frame_stride,
                               orbx_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, int cap,

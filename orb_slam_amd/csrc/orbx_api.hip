@@ -29,8 +29,7 @@ struct orbx_extractor {
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;
     Cand *d_cand = nullptr, *d_sel = nullptr;
     CellState* d_cstate = nullptr;
-    int32_t* d_band_hint[2] = {nullptr, nullptr};
-    int hint_parity = 0;
+    bool fallback_hint = true;        // ORBX_FALLBACK_HINT=0 at orbx_create
     CellSel* d_csel = nullptr;
     int32_t *d_level_total = nullptr, *d_level_count = nullptr, *d_status = nullptr, *d_long_cells = nullptr;
     // single-frame staging for orbx_extract
@@ -85,7 +84,7 @@ static void dev_free(T*& p) {
 static void free_geometry(orbx_extractor* h) {
     dev_free(h->d_cells); dev_free(h->d_bands); dev_free(h->d_tabx); dev_free(h->d_taby); dev_free(h->d_pyr_tab);
     dev_free(h->d_pyr); dev_free(h->d_blur);
-    dev_free(h->d_cand); dev_free(h->d_sel); dev_free(h->d_cstate); dev_free(h->d_band_hint[0]); dev_free(h->d_band_hint[1]); dev_free(h->d_csel);
+    dev_free(h->d_cand); dev_free(h->d_sel); dev_free(h->d_cstate); dev_free(h->d_csel);
     dev_free(h->d_level_total); dev_free(h->d_level_count); dev_free(h->d_status); dev_free(h->d_long_cells);
     h->gw = h->gh = 0;
     h->have_last = false;
@@ -119,10 +118,7 @@ static int ensure_geometry(orbx_extractor* h, int w, int hgt) {
     HIPCHK(h, hipMalloc(&h->d_cand, B * std::max(g.frame_cands, 1) * sizeof(Cand)));
     HIPCHK(h, hipMalloc(&h->d_sel, (B * std::max(g.frame_sel, 1) + 4) * sizeof(Cand)));      // (+ 4: k_describe reads a wave's four keypoints as one 32-byte scalar load)
     HIPCHK(h, hipMalloc(&h->d_cstate, B * g.nbands_total * sizeof(CellState)));
-    for (int k = 0; k < 2; k++) {
-        HIPCHK(h, hipMalloc(&h->d_band_hint[k], (size_t)(g.nbands_total + 16) * sizeof(int32_t)));
-        HIPCHK(h, hipMemset(h->d_band_hint[k], 0, (size_t)(g.nbands_total + 16) * sizeof(int32_t)));
-    }
+    HIPCHK(h, hipMemset(h->d_cstate, 0, B * g.nbands_total * sizeof(CellState)));      // (the fallback runs start at 0: k_fast_cells reads its slot's state before it writes it)
     HIPCHK(h, hipMalloc(&h->d_csel, B * g.ncells_total * sizeof(CellSel)));
     HIPCHK(h, hipMalloc(&h->d_level_total, B * MAX_LEVELS * sizeof(int32_t)));
     HIPCHK(h, hipMalloc(&h->d_level_count, B * MAX_LEVELS * sizeof(int32_t)));
@@ -171,6 +167,7 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
     // The blur runs on a side stream next to the latency-bound selection kernels (see launch_extract);
     // ORBX_OVERLAP=0 keeps everything on one stream (cleaner per-kernel timings when profiling).
     { const char* xa = getenv("ORBX_XCD_AFFINITY"); h->no_xcd_affinity = xa && xa[0] == '0'; }
+    { const char* fh = getenv("ORBX_FALLBACK_HINT"); h->fallback_hint = !(fh && fh[0] == '0'); }
     { const char* od = getenv("ORBX_BLUR_ON_DEMAND"); if (od && (od[0] == '0' || od[0] == '1') && od[1] == 0) h->blur_on_demand = od[0] - '0'; }
     { const char* zc = getenv("ORBX_ZERO_COPY"); h->zero_copy = !(zc && zc[0] == '0'); }
     const char* ovl = getenv("ORBX_OVERLAP");
@@ -257,9 +254,7 @@ int orbx_extract_batch_device_phases(orbx_extractor* h, const uint8_t* d_imgs, i
         Batch b;
         memset(&b, 0, sizeof(b));
         fill_batch(h, b);
-        b.band_hint_in = h->d_band_hint[h->hint_parity];
-        b.band_hint_out = h->d_band_hint[h->hint_parity ^ 1];
-        if (phases & ORBX_PHASE_DETECT) h->hint_parity ^= 1;
+        b.fallback_hint = h->fallback_hint ? 1 : 0;
         b.nframes = std::min(h->p.max_batch, nframes - f0);
         b.xcd_affinity = (b.nframes >= XCD_AFFINITY_MIN_FRAMES && !h->no_xcd_affinity) ? 1 : 0;
         b.blur_on_demand = h->blur_on_demand;
@@ -426,7 +421,7 @@ long orbx_debug_fetch(orbx_extractor* h, int what, int frame, int level, void* h
             int32_t* o = (int32_t*)host_out + 8 * n++;
             o[0] = bgm.x0; o[1] = bgm.x1; o[2] = bgm.y0; o[3] = bgm.y1;
             o[4] = st[it].n_all; o[5] = st[it].n_hi; o[6] = st[it].n_lo;
-            o[7] = st[it].thr;          // the threshold the band's list was made at (fastTh; 7 after the second pass or on the fallback hint)
+            o[7] = st[it].thr & 0xFF;          // the threshold the band's list was made at (fastTh; 7 after the second pass or on the fallback hint)
         }
         return n * 32;
     }

@@ -171,11 +171,11 @@ constexpr int QUOTA_LDS_PER_CELL = 10;                              // k_quota: 
 constexpr int QUOTA_MAX_CELLS = 160 * 1024 / QUOTA_LDS_PER_CELL / 64 * 64;   // 16384: what one workgroup's LDS holds
 // Per FAST work item (row band of a grid cell).  `thr` is the threshold the band's list and counters were made at: fastTh when the
 // band kept more than 3 survivors@fastTh (or fastTh <= 7), else 7 — the second pass, or a pass that STARTED at 7 on the band's
-// fallback hint (Batch::band_hint_in), in which case n_hi may exceed 3.  INVARIANT the later stages rely on: in a list made at fastTh,
+// fallback hint (CellState::thr >> 8), in which case n_hi may exceed 3.  INVARIANT the later stages rely on: in a list made at fastTh,
 // n_lo counts only survivors@fastTh (not survivors@7), so n_lo may be consumed only for a cell whose bands ALL have n_hi <= 3 (then every
 // band of it was listed at 7): k_quota reads n_lo exactly when sum(n_hi) <= 3.  A list made at 7 is filtered by score >= the cell's
 // threshold in k_cell_select (survivors@fastTh = survivors@7 with score >= fastTh).
-struct CellState { int32_t n_all, n_hi, n_lo, thr; };     // survivors listed, of them with score >= fastTh, with score >= 7; list threshold
+struct CellState { int32_t n_all, n_hi, n_lo, thr; };     // survivors listed, of them with score >= fastTh, with score >= 7; list threshold (low byte) | run of fallbacks of this frame slot << 8
 struct CellSel { int32_t thr, nkeys, nretain, out_off; };
 
 struct DevGeom {
@@ -223,13 +223,8 @@ struct Batch {
     Cand* cand;               // [frame][frame_cands]
     Cand* sel;                // [frame][frame_sel]
     CellState* cstate;        // [frame][nbands_total]  (per band: survivors, and how many reach fastTh / 7)
-    // Fallback hint per FAST work item (one table per extractor handle, double-buffered across launch groups): how many launch groups
-    // in a row the band of frame 0 ended with <= 3 survivors@fastTh.  A band whose count has reached FAST_HINT_RUN starts at threshold 7
-    // right away instead of scoring at fastTh first and again at 7 (src/ORBextractor.cc:609-614 takes the fallback per cell either way;
-    // outputs do not depend on the hint: a list made at 7 is filtered by the cell's threshold later).  Read by every frame of a launch
-    // group, written by its frame 0 only (one writer: every frame writing cost 1 % of the headline).
-    const int32_t* band_hint_in;
-    int32_t* band_hint_out;
+    int fallback_hint;        // 1: a band starts at threshold 7 once its slot fell back FAST_HINT_RUN launch groups in a row (the run rides in CellState::thr);
+                              // 0 (ORBX_FALLBACK_HINT=0): every band is scored at fastTh first
     CellSel* csel;            // [frame][ncells_total]
     int32_t* level_total;     // [frame][MAX_LEVELS]  keypoints gathered from the cells
     int32_t* level_count;     // [frame][MAX_LEVELS]  after the per-level cap

@@ -361,7 +361,6 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     constexpr int WQ_BYTES = fast_wave_queue_bytes(PPT);
     const DevGeom& g = b.g;
     const BandGeom bg = b.bands[item];
-    const int hint = b.band_hint_in[item];
     const int level = bg.level;
     const LevelGeom& L = g.lv[level];
     // Wave roles rotate with the band index.  The tails of the task are wave-0 heavy (a VGA cell's survivor list is <= 70 chunks: wave 0
@@ -370,8 +369,13 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     const int lane = threadIdx.x & 63, wave = ORBX_FAST_ROTATE ? (wave_id() + item) & (NW - 1) : wave_id(), tid = wave * 64 + lane;
     const int cw = bg.x1 - bg.x0 + 1, ch = bg.ey1 - bg.ey0 + 1;      // scored rectangle: own rows + halo rows towards sibling bands
     CellState* cst = b.cstate + (long long)frame * g.nbands_total + item;
+    // Fallback hint (round 6: per FRAME SLOT): how many launch groups in a row THIS band of THIS slot of the launch group ended with <= 3
+    // survivors@fastTh.  It lives in the upper bits of CellState::thr, which the same work item of the previous launch group left behind: one
+    // load in front of the band, no store of its own (round 5 kept one table per handle, written by frame 0 and read by every frame: a launch
+    // group that mixes streams — several cameras, a handle reused across sequences — inherited frame 0's texture class).
+    const int hint = b.fallback_hint ? (int)((uint32_t)cst->thr >> 8) : 0;
     if (cw <= 0 || ch <= 0) {
-        if (tid == 0) { CellState st; st.n_all = 0; st.n_hi = 0; st.n_lo = 0; st.thr = g.tmin; *cst = st; if (frame == 0) b.band_hint_out[item] = 0; }
+        if (tid == 0) { CellState st; st.n_all = 0; st.n_hi = 0; st.n_lo = 0; st.thr = g.tmin; *cst = st; }
         return;
     }
     const int own_lo = bg.y0 - bg.ey0, own_hi = bg.y1 - bg.ey0;
@@ -461,7 +465,7 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     // list at fastTh is all the later stages read.  Only a band with <= 3 survivors@fastTh is scored again at 7 (below).  On textured
     // input (corners@7 several times corners@fastTh) the pair test, score, NMS and list phases shrink by that factor; on the S-blocks
     // stream 3 % of the bands take the second pass.  fastTh <= 7: one pass at fastTh serves both (g.tmin = fastTh).
-    // Fallback hint (round 5; Batch::band_hint_in): a band that needed the second pass in FAST_HINT_RUN launch groups in a row starts at 7
+    // Fallback hint (round 5; per frame slot since round 6, see above): a band that needed the second pass in FAST_HINT_RUN launch groups in a row starts at 7
     // (low-texture streams: every band would otherwise run twice, S-lowtex +35 % on this kernel).  A wrong hint costs one pass at 7
     // instead of one at fastTh, never a wrong result: CellState::thr tells the later stages what the list was made at.
     constexpr int FAST_HINT_RUN = 6;
@@ -681,9 +685,9 @@ __device__ __forceinline__ void fast_band_task(const Batch& b, int frame, int it
     }
     if (tid == 0) {
         CellState st;
-        st.n_all = run_base; st.n_hi = hdr->n_hi; st.n_lo = hdr->n_lo; st.thr = tmin;
+        st.n_all = run_base; st.n_hi = hdr->n_hi; st.n_lo = hdr->n_lo;
+        st.thr = tmin | ((st.n_hi <= 3 && g.fast_th > 7 ? imin(hint + 1, FAST_HINT_RUN) : 0) << 8);      // list threshold | the slot's run of fallbacks
         *cst = st;
-        if (frame == 0) b.band_hint_out[item] = st.n_hi <= 3 && g.fast_th > 7 ? imin(hint + 1, FAST_HINT_RUN) : 0;
     }
 }
 

@@ -121,7 +121,7 @@ def test_stage_parity_vga(gpu_extractor_factory, family):
 
 
 def test_fallback_hint_changes_the_pass_not_the_result(gpu_extractor_factory):
-    """Round 5: a band that ended with <= 3 survivors@fastTh in 6 launch groups in a row starts at threshold 7 (Batch::band_hint_in) instead
+    """Round 5: a band that ended with <= 3 survivors@fastTh in 6 launch groups in a row starts at threshold 7 (CellState::thr >> 8) instead
     of scoring at fastTh first and again at 7 (src/ORBextractor.cc:609-614 decides per cell either way).  The hint may be wrong — a
     textured frame arriving on a handle that saw low-texture frames — and then the band's list is made at 7 although it holds more
     than 3 survivors@20: the band reports thr = 7, its list and counters are cv::FAST's at 7, and the outputs do not change."""
@@ -588,6 +588,40 @@ def test_blur_planes_of_a_full_launch_group(gpu_extractor_factory, cfg):
             got = ex.fetch_plane(capi.DBG_BLUR, l, frame=f)
             bad = np.argwhere(got != orc.gaussian_blur7(plain, mode))
             assert bad.size == 0, "frame %d level %d (%dx%d): %d pixels differ, first %s" % (f, l, plain.shape[1], plain.shape[0], len(bad), bad[0])
+
+
+def test_fallback_hint_is_per_frame_slot_of_the_launch_group(gpu_extractor_factory):
+    """Round 6: the hint is learned per (frame slot, band), not from frame 0 for the whole launch group.  A launch
+    group that mixes two streams — slots 0..31 a low-texture camera, slots 32..63 a textured one — gives each slot its own pass: after 8 launch
+    groups every band of the low-texture slots starts at 7, the textured slots' bands with more than 3 survivors@20 are still listed at 20
+    (round 5: all 64 frames inherited frame 0's class), and every frame equals the oracle."""
+    import torch
+    F, w, h = 64, 640, 480
+    ex = gpu_extractor_factory(max_batch=F)
+    cap = ex.max_keypoints
+    o = orc.OracleExtractor()
+    kps = torch.zeros((F, cap, 28), dtype=torch.uint8, device="cuda")
+    desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(F, dtype=torch.int32, device="cuda")
+    for g in range(9):
+        frames = np.stack([synth.frame(w, h, synth.LOWTEX if f < 32 else synth.BLOCKS, 64 * g + f) for f in range(F)])
+        d = torch.from_numpy(frames).cuda()
+        if g == 8:
+            ex.set_stop_after(capi.ST_FAST_CELLS)
+        ex.extract_batch_device(d.data_ptr(), F, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), cap)
+        torch.cuda.synchronize()
+        if g in (0, 7):
+            k, dd, nn = kps.cpu().numpy(), desc.cpu().numpy(), n.cpu().numpy()
+            for f in (0, 5, 31, 32, 40, 63):
+                ok, od = o(frames[f])
+                assert nn[f] == len(ok) and k[f, :nn[f]].tobytes() == ok.tobytes() and np.array_equal(dd[f, :nn[f]], od), (g, f)
+    for f in (1, 17, 31):                                # low-texture slots: one pass at 7 everywhere
+        assert all((ex.fetch_bands(l, frame=f)[:, 7] == 7).all() for l in range(8)), f
+    for f in (32, 47, 63):                               # textured slots: bands with more than 3 survivors@20 were listed at 20
+        tabs = np.concatenate([ex.fetch_bands(l, frame=f) for l in range(8)])
+        rich = tabs[:, 5] > 3
+        assert rich.sum() > 100 and (tabs[rich, 7] == 20).all(), f
+    ex.set_stop_after(-1)
 
 
 # ---- round 6: the FMA caveat.  orbx_params::fp_contract = ORBX_FP_GCC_CONTRACT evaluates the descriptor rotation and the Harris response as
