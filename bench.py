@@ -414,13 +414,23 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
     pipe.stage_timing(0)
     kp_mean = float(pipe.counts().float().mean().item())
     bad_status = int((pipe.status() != 0).sum().item())
-    accepted = -1
+    accepted, accepted_rate = -1, None
     if do_match:
         last = pipe.lanes[G - 1]
         best = last.match[1, b - 1, :cap].cpu().numpy()
         sec = last.match[2, b - 1, :cap].cpu().numpy()
         nq = int(last.n[b].item())
         accepted = capi.count_accepted(best[:nq], sec[:nq], 50, 0.6)
+        # the accept rule of SearchByBoW (src/ORBmatcher.cc:224-226: best <= TH_LOW && (float)best < 0.6f * (float)second) over EVERY frame of the last
+        # step: what fraction of the key points finds its partner in the previous frame (S-warp: a camera-like stream; S-blocks: independent images)
+        acc_n = acc_q = 0
+        for ln in pipe.lanes:
+            nn = ln.n[1:b + 1].to(torch.int64)
+            live = torch.arange(cap, device=dev)[None, :] < nn[:, None]
+            bb, ss = ln.match[1, :b, :cap], ln.match[2, :b, :cap]
+            ok = live & (bb <= 50) & (bb.to(torch.float32) < torch.tensor(0.6, dtype=torch.float32, device=dev) * ss.to(torch.float32))
+            acc_n += int(ok.sum().item()); acc_q += int(nn.sum().item())
+        accepted_rate = round(acc_n / max(acc_q, 1), 4)
 
     def serial_pass(nser):
         """The same step with every kernel alone on the chip: one extractor over all B frames, one launch per kernel, the match
@@ -468,8 +478,11 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
         return ms1
 
     # RCCL: the only collectives of the run (MAX of the timing, all-gather of the counters)
+    ni = getattr(a, "numa_info", None) or {}
     tmax, counters, rows = dist_util.reduce_run(dist, elapsed, [nsteps * B, kp_mean * nsteps * B, bad_status, elapsed, parity["frames"],
-                                                                parity["mismatches"], host_submit_ms, float(torch.cuda.current_device())],
+                                                                parity["mismatches"], host_submit_ms, float(torch.cuda.current_device()),
+                                                                float(ni.get("pci_bus", -1)), float(ni.get("numa_node", -1)), float(ni.get("host_threads", 0)),
+                                                                float(ni.get("bound", 0))],
                                                 dev if a.backend == "nccl" else torch.device("cpu"))
     placement = pipe.placement
     if rank != 0:
@@ -574,12 +587,14 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
                    "parity_detail": parity["detail"],
                    "host_submit_ms_per_step": round(float(counters[6]) / world, 4),
                    "mean_keypoints_per_frame": round(float(counters[1]) / total_frames, 2),
-                   "frames_with_error_status": int(counters[2]), "accepted_matches_last_frame": accepted,
-                   "accepted_note": "consecutive S-blocks frames are independent images, so few matches pass best <= 50 && best < 0.6 * second; "
-                                    "what the match leg computes is checked against the oracle in the parity leg (integer-equal top-2)",
+                   "frames_with_error_status": int(counters[2]), "accepted_matches_last_frame": accepted, "accepted_match_rate_last_step": accepted_rate,
+                   "accepted_note": "best <= 50 && best < 0.6 * second over every frame of the last timed step.  Consecutive S-blocks (noise, lowtex, midtex) frames are "
+                                    "independent images, so few matches pass; S-warp (--family 5, `also.vga_warp`) is a correlated stream: consecutive frames show the "
+                                    "same corners a pixel or two apart.  What the match leg computes is checked against the oracle in the parity leg (integer-equal top-2)",
                    "library_build_id": capi.build_id()},
         "per_rank": [{"rank": r, "device": int(row[7]), "frames": int(row[0]), "elapsed_s": round(row[3], 4), "frames_per_s": round(row[0] / row[3], 1),
-                      "host_submit_ms": round(row[6], 4), "parity_checked_frames": int(row[4])} for r, row in enumerate(rows)],
+                      "host_submit_ms": round(row[6], 4), "parity_checked_frames": int(row[4]),
+                      "pci_bus": int(row[8]), "numa_node": int(row[9]), "host_threads": int(row[10]), "numa_bound": int(row[11])} for r, row in enumerate(rows)],
         "roofline": roofline,
         "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(pipe_gbs / HBM_PEAK_GBS, 5), "frac_of_achievable": round(pipe_gbs / HBM_ACHIEVABLE_GBS, 5),
@@ -805,13 +820,16 @@ def compact_line(full, also=None):
         if isinstance(full.get(k), dict):
             out[k] = _pick(full[k], ("value", "unit", "cores", "kind", "sample", "median_ms") if k == "cpu_baseline" else ("value", "unit", "cores", "kind"))
     if full.get("per_rank"):
-        keys = [k for k in ("rank", "device", "frames", "pairs", "elapsed_s", "parity_checked_frames") if k in full["per_rank"][0]]
+        keys = [k for k in ("rank", "device", "pci_bus", "numa_node", "host_threads", "numa_bound", "frames", "pairs", "elapsed_s", "parity_checked_frames")
+                if k in full["per_rank"][0]]
         out["per_rank"] = {"columns": keys, "rows": [[row.get(k) for k in keys] for row in full["per_rank"]]}
     if also:
         summ = {}
         for name, rpt in also.items():
             row = _pick(rpt, ("value", "unit", "ms_per_step", "timed_seconds"))
             row["parity_mismatches"] = rpt.get("config", {}).get("parity_mismatches")
+            if rpt.get("config", {}).get("accepted_match_rate_last_step") is not None and name == "vga_warp":
+                row["accepted_match_rate"] = rpt["config"]["accepted_match_rate_last_step"]
             rr = rpt.get("roofline") or {}
             row["roofline_frac"] = rr.get("frac")
             if rr.get("bound") != "hbm":            # (rows without the key: bound "hbm", like the headline's roofline)
@@ -839,7 +857,7 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--nfeatures", type=int, default=None)
-    ap.add_argument("--family", type=int, default=1, help="0 noise, 1 blocks (default), 3 lowtex, 4 midtex (orb_slam_amd/csrc/synth_frames.c)")
+    ap.add_argument("--family", type=int, default=1, help="0 noise, 1 blocks (default), 3 lowtex, 4 midtex, 5 warp = correlated stream (orb_slam_amd/csrc/synth_frames.c)")
     ap.add_argument("--no-match", action="store_true", help="extract only (same as --config vga_extract for the VGA stream)")
     ap.add_argument("--lanes", type=int, default=4,
                     help="a step's frames go through this many concurrent lanes (own extractor handle + HIP stream each); 1 = one stream")
@@ -888,7 +906,8 @@ def main():
         raise SystemExit("rank %d wants cuda:%d but this process sees %d device(s) (one process per GPU; --share-device for a 1-GPU functional run)"
                          % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    numa = dist_util.bind_to_gpu_numa(local_rank) if world > 1 and not a.share_device else None
+    numa = dist_util.bind_to_gpu_numa(local_rank, bind=world > 1 and not a.share_device)      # (at one rank: reported, not changed)
+    a.numa_info = numa
     dist = dist_util.init(a.backend, world, rank, local_rank, force=a.force_dist)    # "nccl" is RCCL on ROCm
     if a.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (a.gpus, world))
@@ -904,8 +923,8 @@ def main():
 
     out = run(a, a.config)
     bad = int(out.get("_mismatches", 0)) if rank != 0 else int(out["config"].get("parity_mismatches", 0))
-    if rank == 0 and numa:
-        out["config"]["host_numa_binding"] = numa
+    if rank == 0 and numa.get("desc"):
+        out["config"]["host_numa_binding"] = numa["desc"]
     also = {}
     if a.config == "vga" and a.family == synth.BLOCKS and not a.no_also:
         # BASELINE.json's other GPU configurations and the headline configuration on the other frame families, in the same run (the
@@ -915,7 +934,8 @@ def main():
         entries = [("vga_extract", "vga_extract", synth.BLOCKS, False), ("hd1080", "hd1080", synth.BLOCKS, True),
                    ("match100k", "match100k", synth.BLOCKS, True), ("match100k_int8", "match100k", synth.BLOCKS, False),
                    ("match100k_popcount", "match100k", synth.BLOCKS, False),
-                   ("vga_noise", "vga", synth.NOISE, False), ("vga_midtex", "vga", synth.MIDTEX, False), ("vga_lowtex", "vga", synth.LOWTEX, False)]
+                   ("vga_noise", "vga", synth.NOISE, False), ("vga_midtex", "vga", synth.MIDTEX, False), ("vga_lowtex", "vga", synth.LOWTEX, False),
+                   ("vga_warp", "vga", synth.WARP, False)]
         if world > 1:
             entries = [e for e in entries if e[0] in ("hd1080", "match100k")]
         for key, name, family, cpu in entries:

@@ -64,24 +64,30 @@ def reduce_run(dist, elapsed_s, counters, device):
     return float(t.item()), total.cpu().tolist(), [r.cpu().tolist() for r in rows]
 
 
-def bind_to_gpu_numa(local_rank):
+def bind_to_gpu_numa(local_rank, bind=True):
     """Multi-rank runs: keep this rank's host threads on the NUMA node its GPU hangs off (launch threads, the synthesis and parity
-    pools), intersected with the CPUs the process may already use.  Best effort: returns a short description, or None when the
-    topology is not exposed (numa_node -1, no sysfs, single node) — the rank then stays where the launcher put it."""
+    pools), intersected with the CPUs the process may already use.  Best effort.  Returns a dict every rank can put into its
+    counters row (bench.py's `per_rank`: the first real 8-GPU record then says where each rank ran): `pci_bus` of the GPU, its
+    `numa_node` (-1: not exposed), `host_threads` the rank may run on afterwards, `bound` (1 when the affinity was narrowed) and a
+    one-line `desc`."""
+    info = {"pci_bus": -1, "numa_node": -1, "host_threads": len(os.sched_getaffinity(0)), "bound": 0, "desc": None}
     try:
         p = torch.cuda.get_device_properties(local_rank)
         bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        info["pci_bus"] = int(p.pci_bus_id)
         node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
-        if node < 0:
-            return None
+        info["numa_node"] = node
+        if node < 0 or not bind:
+            return info
         cpus = set()
         for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
             lo, _, hi = part.partition("-")
             cpus.update(range(int(lo), int(hi or lo) + 1))
         mine = cpus & os.sched_getaffinity(0)
         if not mine or mine == os.sched_getaffinity(0):
-            return None
+            return info
         os.sched_setaffinity(0, mine)
-        return "cuda:%d (%s) -> NUMA node %d, %d host threads" % (local_rank, bdf, node, len(mine))
+        info.update(host_threads=len(mine), bound=1, desc="cuda:%d (%s) -> NUMA node %d, %d host threads" % (local_rank, bdf, node, len(mine)))
+        return info
     except Exception:
-        return None
+        return info

@@ -4,8 +4,9 @@ import ctypes
 import os
 import numpy as np
 
-NOISE, BLOCKS, FLAT, LOWTEX, MIDTEX = 0, 1, 2, 3, 4
-FAMILY_NAMES = {NOISE: "S-noise", BLOCKS: "S-blocks", FLAT: "S-flat", LOWTEX: "S-lowtex", MIDTEX: "S-midtex"}
+NOISE, BLOCKS, FLAT, LOWTEX, MIDTEX, WARP = 0, 1, 2, 3, 4, 5
+WARP_SEQ = 64              # S-warp: frames index // 64 share one base texture, index % 64 is the position on the camera path
+FAMILY_NAMES = {NOISE: "S-noise", BLOCKS: "S-blocks", FLAT: "S-flat", LOWTEX: "S-lowtex", MIDTEX: "S-midtex", WARP: "S-warp"}
 _LIB = None
 
 

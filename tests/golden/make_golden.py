@@ -23,6 +23,10 @@ CASES = [  # name, w, h, family, index, extractor kwargs, store full outputs?
     ("vga_blocks_f7_nf2000", 640, 480, synth.BLOCKS, 7, dict(nfeatures=2000), False),
     ("vga_blocks_f2_harris", 640, 480, synth.BLOCKS, 2, dict(nfeatures=1000, scoreType=0), False),
     ("hd_blocks_f0", 1920, 1080, synth.BLOCKS, 0, dict(nfeatures=2000), False),
+    # round 6: the correlated stream (S-warp): two consecutive frames of a sequence and one deep into the camera path (roll 5 deg, zoom 6 %)
+    ("vga_warp_f130", 640, 480, synth.WARP, 130, dict(nfeatures=1000), False),
+    ("vga_warp_f131", 640, 480, synth.WARP, 131, dict(nfeatures=1000), False),
+    ("vga_warp_f191", 640, 480, synth.WARP, 191, dict(nfeatures=1000), False),
 ]
 sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 out = {}

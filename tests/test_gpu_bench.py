@@ -98,6 +98,11 @@ def test_default_line_carries_every_baseline_config():
         f = d["also"][key]
         assert name in f["config"]["workload"] and f["value"] > 0 and f["config"]["parity_checked_frames"] == 1024 and f["config"]["parity_mismatches"] == 0, key
         assert f["stage_ms_per_step"]["fast_cells"] > 0
+    # round 6: the correlated stream — every frame of the step against the oracle like the others, and a camera-like share of accepted matches
+    wv = d["also"]["vga_warp"]
+    assert "S-warp" in wv["config"]["workload"] and wv["config"]["parity_checked_frames"] == 1024 and wv["config"]["parity_mismatches"] == 0
+    assert wv["config"]["accepted_match_rate_last_step"] > 0.30 and d["line"]["also_summary"]["vga_warp"]["accepted_match_rate"] > 0.30
+    assert d["config"]["accepted_match_rate_last_step"] < 0.05             # S-blocks: independent images
     cb = d["cpu_baseline"]
     assert cb["iterations"] >= 20 and cb["p10_ms"] <= cb["median_ms"] <= cb["p90_ms"] and cb["match_variants"]["popcountll"] > 0
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_orbextractor.so")):
