@@ -115,3 +115,45 @@ def test_on_demand_blur_on_adversarial_frames(gpu_extractor_factory):
             assert n[f] == len(ok), (mode, f)
             assert k[f, :n[f]].tobytes() == ok.tobytes() and np.array_equal(d[f, :n[f]], od), (mode, f)
     assert n[:7].sum() > 1000
+
+
+@pytest.mark.parametrize("w,row_stride", [(640, 704), (644, 704), (640, 640), (641, 641)])
+@pytest.mark.parametrize("mode", [1, 0], ids=["on_demand", "blur_kernels"])
+def test_pitched_input_ending_at_the_documented_readable_limit(gpu_extractor_factory, w, row_stride, mode):
+    """VERDICT r05 W7 / ADVICE r04: include/orbx.h promises the kernels only min(row_stride, w rounded up to 16) readable bytes per row, the LAST row of
+    the LAST frame included.  The frames sit in a larger allocation so that they END exactly there; what follows is poison.  Nothing may be written
+    behind the limit, and the outputs may not depend on what the poison is (a read past the limit that reached a result would show) — through the
+    on-demand description kernel and through both blur kernels (k_blur_mfma: 16-byte pitches; k_blur: the others)."""
+    import torch
+    h, F = 480, 33
+    frames = np.stack([synth.frame(w, h, [synth.BLOCKS, synth.MIDTEX, synth.NOISE][i % 3], 900 + i) for i in range(F)])
+    readable = min(row_stride, (w + 15) & ~15)
+    frame_stride = row_stride * h
+    used = (F - 1) * frame_stride + (h - 1) * row_stride + readable
+    tail = 8192
+    o = orc.OracleExtractor()
+    want = [o(fr) for fr in frames[[0, 1, F - 2, F - 1]]]
+    outs = []
+    for poison in (0x00, 0xFF, 0x5A):
+        buf = np.full(used + tail, poison, np.uint8)
+        for f in range(F):
+            for r in range(h):
+                o0 = f * frame_stride + r * row_stride
+                buf[o0:o0 + w] = frames[f, r]
+        ex = gpu_extractor_factory(max_batch=F)
+        ex.set_blur_on_demand(mode)
+        cap = ex.max_keypoints
+        d = torch.from_numpy(buf).cuda()
+        kps = torch.zeros((F, cap, 28), dtype=torch.uint8, device="cuda")
+        desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device="cuda")
+        n = torch.zeros(F, dtype=torch.int32, device="cuda")
+        ex.extract_batch_device(d.data_ptr(), F, w, h, row_stride, frame_stride, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), cap)
+        torch.cuda.synchronize()
+        back = d.cpu().numpy()
+        assert (back[used:] == poison).all() and np.array_equal(back[:used], buf[:used])           # the input is read-only, the tail untouched
+        outs.append((kps.cpu().numpy(), desc.cpu().numpy(), n.cpu().numpy()))
+    for k, dd, nn in outs[1:]:
+        assert np.array_equal(nn, outs[0][2]) and np.array_equal(k, outs[0][0]) and np.array_equal(dd, outs[0][1])
+    k, dd, nn = outs[0]
+    for (ok, od), f in zip(want, (0, 1, F - 2, F - 1)):
+        assert nn[f] == len(ok) and k[f, :nn[f]].tobytes() == ok.tobytes() and np.array_equal(dd[f, :nn[f]], od), f
