@@ -815,9 +815,16 @@ int orbm_count_accepted(const int32_t* best, const int32_t* second, int nq, int 
 static std::atomic<int> g_match_path{-1};        // -1: environment default
 static int match_path() {
     static const int env_default = [] {
+        // the WHOLE string: "0" = xor + popcount, "8" / "int8" / "1" (what rounds 2-4 called "on") = int8 MFMA, "4" / "fp4" = FP4 MFMA; anything else
+        // is said out loud once and ignored (a first-character parse sent "1", "80", "int8" to the FP4 default without a word)
         const char* e = getenv("ORBX_MATCH_MFMA");
         if (!e || !e[0]) return ORBX_MATCH_DEFAULT_PATH;
-        return e[0] == '0' ? 0 : e[0] == '8' ? 1 : e[0] == '4' ? 2 : ORBX_MATCH_DEFAULT_PATH;
+        const std::string v(e);
+        if (v == "0" || v == "popcount") return 0;
+        if (v == "8" || v == "int8" || v == "1") return 1;
+        if (v == "4" || v == "fp4") return 2;
+        fprintf(stderr, "liborbx: ORBX_MATCH_MFMA=%s not understood (0 | 8 | 4): keeping the default path %d\n", e, ORBX_MATCH_DEFAULT_PATH);
+        return ORBX_MATCH_DEFAULT_PATH;
     }();
     const int f = g_match_path.load(std::memory_order_relaxed);
     return f < 0 ? env_default : f;
@@ -1098,7 +1105,16 @@ int orbm_match_top2_masked_device(const uint8_t* dQ, int nq, const uint8_t* dT, 
     int rc = ORBX_OK;
     hipLaunchKernelGGL(k_mask_compact, dim3(1), dim3(1024), 0, stream, (const uint32_t*)dT, d_t_valid, nt, nq, Tc, map, counts);
     if (hipGetLastError() != hipSuccess) rc = ORBX_ERR_DEVICE;
-    if (rc == ORBX_OK) rc = orbm_match_top2_batch_device(dQ, counts, reinterpret_cast<const uint8_t*>(Tc), counts + 1, 1, cap, d_best_idx, d_best, d_second, stream);
+    // Small problems (a frame against a frame: the case the searches have) stay asynchronous: the batch form reads the compacted count on the
+    // device.  Large ones (as ONE batch problem a 100k x 100k masked match got no train splits, one workgroup per 512 queries over the
+    // whole list, and — beyond the FP4 batch capacity of 32768 — the int8 kernels) fetch the count (4 bytes, one synchronisation) and take the
+    // dense split form on the compacted set: grid by nq, FP4 capacity by the compacted nt, train splits by the cost model.
+    if (rc == ORBX_OK && cap > 8192) {
+        int32_t hc[2] = {0, 0};
+        if (hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) rc = ORBX_ERR_DEVICE;
+        if (rc == ORBX_OK) rc = orbm_match_top2_device(dQ, nq, reinterpret_cast<const uint8_t*>(Tc), hc[1], d_best_idx, d_best, d_second, stream);
+    } else if (rc == ORBX_OK)
+        rc = orbm_match_top2_batch_device(dQ, counts, reinterpret_cast<const uint8_t*>(Tc), counts + 1, 1, cap, d_best_idx, d_best, d_second, stream);
     if (rc == ORBX_OK) {
         hipLaunchKernelGGL(k_mask_remap, dim3((nq + 255) / 256), dim3(256), 0, stream, d_best_idx, map, nq);
         if (hipGetLastError() != hipSuccess) rc = ORBX_ERR_DEVICE;

@@ -1746,6 +1746,9 @@ __global__ __launch_bounds__(DESC_WAVES * 64) void k_describe(Batch b) {
         const int ks = __builtin_amdgcn_readfirstlane(max(min(k0, sel_cap - DESC_KPW), 0));        // (the sel block carries 4 slots of padding)
         const Cand* kp4 = b.sel + ((long long)frame * g.frame_sel + L.sel_base + ks);
         const int32_t* stp = b.status + frame;
+        // REQUIRES of Batch::sel: 4 readable Cand slots behind every level's list (the 32-byte load below may start up to 3 entries in front of the list's
+        // last slot: ensure_geometry pads d_sel by DESC_KPW entries) and level_count rows of MAX_LEVELS >= 16 ints (two x8 loads).
+        static_assert(MAX_LEVELS >= 16, "the per-level counts are fetched as two s_load_dwordx8");
         v8i_s kq;
         int sst;
         asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %5, 0x0\n\ts_load_dwordx8 %2, %5, 0x20\n\ts_load_dword %3, %6, 0x0\n\ts_waitcnt lgkmcnt(0)"

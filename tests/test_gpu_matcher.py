@@ -53,7 +53,7 @@ def test_ties_duplicates_and_extremes(match_path):
     _check(few[:1500], few[1500:])
 
 
-@pytest.mark.parametrize("nq,nt,keep", [(1, 1, 1.0), (5, 3, 0.5), (1000, 1000, 0.7), (300, 4097, 0.1), (513, 70001, 0.9), (64, 2000, 0.0), (2000, 100, 0.5)])
+@pytest.mark.parametrize("nq,nt,keep", [(1, 1, 1.0), (5, 3, 0.5), (1000, 1000, 0.7), (300, 4097, 0.1), (513, 70001, 0.9), (64, 2000, 0.0), (2000, 100, 0.5), (40000, 1000, 0.5), (9000, 9000, 0.8)])
 def test_train_mask(nq, nt, keep, match_path):
     """SURVEY 8b's optional t_valid mask (src/ORBmatcher.cc:205-206: already matched train features are skipped): the scan over the
     valid descriptors only = the oracle's sequential scan of the order-preserving compaction, indices mapped back to the train array"""
