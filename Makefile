@@ -13,8 +13,18 @@ all: orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle
 
 # the hash of the kernel sources travels inside the library (orbx_build_id): counters replayed by bench.py must come from THIS build
 SRC_HASH   := $(shell cat $(sort $(ORBX_SRCS) $(ORBX_HDRS)) | sha256sum | cut -c1-16)
-orb_slam_amd/liborbx.so: $(ORBX_SRCS) $(ORBX_HDRS)
-	$(HIPCC) $(HIPFLAGS) -DORBX_SRC_HASH='"$(SRC_HASH)"' -shared $(ORBX_SRCS) -o $@
+# one object per translation unit (round 6: the extractor's kernels are split by stage; `make -j` compiles them side by side).  The hash goes into
+# the one file that reports it, which therefore depends on every source.
+OBJDIR     := build/orbx
+ORBX_OBJS  := $(patsubst orb_slam_amd/csrc/%.hip,$(OBJDIR)/%.o,$(ORBX_SRCS))
+$(OBJDIR)/%.o: orb_slam_amd/csrc/%.hip $(ORBX_HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(OBJDIR)/orbx_api.o: orb_slam_amd/csrc/orbx_api.hip $(ORBX_SRCS) $(ORBX_HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DORBX_SRC_HASH='"$(SRC_HASH)"' -c $< -o $@
+orb_slam_amd/liborbx.so: $(ORBX_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared $(ORBX_OBJS) -o $@
 
 orb_slam_amd/libsynthframes.so: orb_slam_amd/csrc/synth_frames.c
 	$(CC) -O2 -fPIC -shared $< -o $@
@@ -64,6 +74,6 @@ tools/microbench/ta_shapes: tools/microbench/ta_shapes.hip
 
 clean:
 	rm -f tools/microbench/mfma_layout_fp4 tools/microbench/valu_exec_mask tools/microbench/ta_shapes tools/microbench/valu_rate tools/microbench/valu_rate2 tools/microbench/mfma_layout tools/microbench/mfma_valu_mix tools/microbench/fetch_calib orb_slam_amd/cpp/bench_single_frame orb_slam_amd/cpp/example_lanes orb_slam_amd/cpp/example_frame orb_slam_amd/cpp/example_pipeline orb_slam_amd/liborbx.so orb_slam_amd/libsynthframes.so oracle/liborb_oracle.so
-	rm -rf oracle/_ref oracle/_ref_native
+	rm -rf oracle/_ref oracle/_ref_native build/orbx
 
 .PHONY: all clean oracle_ref

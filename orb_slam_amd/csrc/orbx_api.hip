@@ -1,5 +1,5 @@
 // C ABI of the extractor (include/orbx.h): handle, device memory, launch orchestration.
-// All pixel work happens in orbx_kernels.hip; there is no host fallback.
+// All pixel work happens in the k_*.hip kernels (strung together by orbx_launch.hip); there is no host fallback.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

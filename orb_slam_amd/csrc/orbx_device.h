@@ -1,4 +1,4 @@
-// Device-side helpers shared by the kernel translation units (orbx_kernels.hip, k_describe_od.hip): block -> (frame, item) maps, wave-level
+// Device-side helpers shared by the kernel translation units (k_pyramid.hip, k_fast.hip, k_select.hip, k_blur.hip, k_describe.hip, k_describe_od.hip): block -> (frame, item) maps, wave-level
 // reductions, the BRIEF pattern, the Gaussian tap strings of the matrix-core blur.  Everything is inline / per-TU static.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -150,7 +150,7 @@ struct BandGeom {
 // Regions and ownership come from host tables (pyr_tab): per level k = 0 .. depth (k = 0: the source level) and tile index,
 // the first / last column (row) of the tile's region; a tile OWNS (= writes to HBM) the columns from its region start up to the
 // next tile's region start, which partitions every level.  Region starts are multiples of 4 (dword stores never straddle owners).
-constexpr int XCD_AFFINITY_MIN_FRAMES = 64;      // launch groups of at least this many frames keep a frame's workgroups on one XCD (orbx_kernels.hip: frame_item)
+constexpr int XCD_AFFINITY_MIN_FRAMES = 64;      // launch groups of at least this many frames keep a frame's workgroups on one XCD (orbx_device.h: frame_item)
 #ifndef ORBX_PYR_DEPTH
 #define ORBX_PYR_DEPTH 4, 4
 #endif

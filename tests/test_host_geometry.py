@@ -79,7 +79,7 @@ def test_rejections_are_classified():
 
 def test_magic_multiply_block_mapping_is_exact():
     """k_fast_cells maps a block index to (frame, band) with umulhi(n, floor(2^32 / d) + 1) and one correcting compare
-    (orbx_kernels.hip: frame_item_magic; the constant is DevGeom::nbands_magic, made by orbx_geometry.hip).  The arithmetic restated on
+    (orbx_device.h: frame_item_magic; the constant is DevGeom::nbands_magic, made by orbx_geometry.hip).  The arithmetic restated on
     32-bit integers: exact for every divisor and every block index a launch can have (boundaries of the quotient, powers of two, the
     largest grids), including the products staying below 2^32 as the device computes them."""
     rng = np.random.default_rng(3)

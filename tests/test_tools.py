@@ -8,8 +8,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 def test_prof_variant_anchors_exist_exactly_once():
     import build_prof_variant as b
-    src = open(os.path.join(ROOT, b.KERNELS)).read()
     for which, marks in (("fast", 9), ("describe", 8)):
+        src = open(os.path.join(ROOT, b.KERNEL_FILES[which])).read()
         out = b.patch_source(src, which)                 # asserts every anchor occurs exactly once
         assert out.count("PROF(") == marks + 1           # the marks + the macro's definition
         assert "orbx_debug_fast_prof" in out and "orbx_debug_fast_prof" not in src      # the product exports no such symbol

@@ -5,7 +5,8 @@ deltas in registers and writes ONE 12-dword record at its end (slot = workgroup 
 only its own contention.  usage: python tools/build_prof_variant.py fast|describe"""
 import os, shutil, subprocess, sys, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = os.path.join("orb_slam_amd", "csrc", "orbx_kernels.hip")
+KERNEL_FILES = {"fast": os.path.join("orb_slam_amd", "csrc", "k_fast.hip"),            # (round 6: one translation unit per stage)
+                "describe": os.path.join("orb_slam_amd", "csrc", "k_describe.hip")}    # the blurred-plane form (ORBX_BLUR_ON_DEMAND=0); k_describe_od has no marks yet
 
 DECL = ("constexpr int PROF_SLOTS = 1 << 19;\n__device__ unsigned g_fast_prof[PROF_SLOTS * 12];\n"
         "#define PROF(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); pacc[i] += (unsigned)(t_ - tprev); tprev = t_; } while (0)\n")
@@ -56,7 +57,7 @@ def main(which):
     for d in ("Makefile", "include", "orb_slam_amd", "oracle"):
         src = os.path.join(R, d)
         (shutil.copytree if os.path.isdir(src) else shutil.copy)(src, os.path.join(tmp, d))
-    p = os.path.join(tmp, KERNELS)
+    p = os.path.join(tmp, KERNEL_FILES[which])
     patched = patch_source(open(p).read(), which)        # (read BEFORE the file is opened for writing)
     open(p, "w").write(patched)
     lib = os.path.join(tmp, "orb_slam_amd/liborbx.so")

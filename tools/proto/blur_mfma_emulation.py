@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Integer model of k_blur_mfma (orb_slam_amd/csrc/orbx_kernels.hip): the per-lane data flow of the MFMA formulation of the 7x7
+"""Integer model of k_blur_mfma (orb_slam_amd/csrc/k_blur.hip): the per-lane data flow of the MFMA formulation of the 7x7
 Gaussian blur — operand slots, the +128 constant slot, the 16-bit -> (hi, lo) byte split, the previous / current row-tile pair, the
 column permutation that leaves every lane 12 contiguous output pixels — on numpy, checked against the oracle's gaussian_blur7
 (both rounding modes).  v_mfma_i32_32x32x32_i8 is modelled by what the layout probe measured (profiles/r02_mfma_layout.txt):

@@ -21,11 +21,11 @@ SLOW = {"v_and_or_b32", "v_min_u32", "v_max_u32", "v_min_i32", "v_max_i32", "v_l
         "v_pk_add_u16", "v_pk_sub_i16", "v_pk_min_u16", "v_pk_max_u16", "v_pk_lshrrev_b16", "v_lerp_u8", "v_min_f32", "v_max_f32", "v_mbcnt_lo_u32_b32",
         "v_mbcnt_hi_u32_b32", "v_add_co_u32", "v_bfi_b32", "v_alignbit_b32", "v_cvt_pk_u8_f32", "v_xnor_b32", "v_dot4_i32_i8", "v_dot8_i32_i4"}   # round 2 measurements
 STAGE = {"k_resize<true, true>": "pyramid", "k_fast_cells<true, 256, 1>": "fast_cells", "k_fast_cells<true, 256, 2>": "fast_cells_large",
-         "k_quota": "quota", "k_cell_select": "cell_select", "k_level_select": "level_select", "k_blur_mfma": "blur", "k_blur<true, 32>": "blur_valu", "k_describe": "describe", "k_describe_od": "describe",
+         "k_quota": "quota", "k_cell_select": "cell_select", "k_level_select": "level_select", "k_blur_mfma": "blur", "k_blur<true, 32>": "blur_valu", "k_describe<false>": "describe_plane", "k_describe_od<false>": "describe",
          "k_match_batch_mfma4<4>": "match", "k_match_batch_mfma<4>": "match_int8"}
 hist = {}
 with tempfile.TemporaryDirectory() as td:
-    for src in ("orbx_kernels.hip", "orbm_match.hip"):
+    for src in ("k_pyramid.hip", "k_fast.hip", "k_select.hip", "k_blur.hip", "k_describe.hip", "k_describe_od.hip", "orbm_match.hip"):
         asm = os.path.join(td, src + ".s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-I" + ROOT + "/include",
                         "-mllvm", "-amdgpu-mfma-vgpr-form", "-I" + ROOT + "/orb_slam_amd/csrc", "--cuda-device-only", "-S", ROOT + "/orb_slam_amd/csrc/" + src, "-o", asm],
