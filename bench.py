@@ -233,16 +233,20 @@ def measure_live_traffic(frames_per_launch, timeout_s=150.0):
     if any(k.startswith(("ROCPROF", "ROCP_")) or k == "HSA_TOOLS_LIB" for k in os.environ):
         return None, "this run is itself under a profiler (its environment would reach the child runs)"
     stage = {"k_resize": "pyramid", "k_fast_cells": "fast_cells", "k_quota": "quota", "k_cell_select": "cell_select", "k_level_select": "level_select",
-             "k_blur": "blur", "k_blur_mfma": "blur", "k_describe": "describe", "k_describe_od": "describe", "k_match_batch": "match", "k_match_batch_mfma": "match"}
+             "k_blur": "blur", "k_blur_mfma": "blur", "k_describe": "describe", "k_describe_od": "describe", "k_match_batch": "match",
+             "k_match_batch_mfma": "match"}
     td = tempfile.mkdtemp(prefix="orbx_live_traffic_", dir="/tmp")
     env = {k: v for k, v in os.environ.items()                      # the child runs are plain one-rank commands, whatever launched this one
-           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT") and not k.startswith("TORCHELASTIC_")}
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+           and not k.startswith("TORCHELASTIC_")}
     env.update(ORBX_OVERLAP="0", TMPDIR="/tmp")
     acc, t0 = {}, time.perf_counter()
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            cmd = [rp, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", td, "-o", ctr.lower(), "--", sys.executable, os.path.join(ROOT, "bench.py"),
-                   "--steps", "3", "--warmup", "1", "--batch", str(frames_per_launch), "--no-cpu-baseline", "--lanes", "1", "--region-timing", "--min-seconds", "0",
+            cmd = [rp, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", td, "-o", ctr.lower(), "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"),
+                   "--steps", "3", "--warmup", "1", "--batch", str(frames_per_launch), "--no-cpu-baseline", "--lanes", "1", "--region-timing",
+                   "--min-seconds", "0",
                    "--no-also", "--no-parity", "--live-traffic", "off"]
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
@@ -274,7 +278,8 @@ def measure_live_traffic(frames_per_launch, timeout_s=150.0):
         disp[st] = len(f)
     if not out:
         return None, "no kernel of the library in the counter files"
-    return out, ("HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, in KB) of one launch of this kernel over all %d frames, MEASURED IN THIS RUN: two child runs of the "
+    return out, ("HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, in KB) of one launch of this kernel over all %d frames, "
+                 "MEASURED IN THIS RUN: two child runs of the "
                  "serial command under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; kernel trace only) after the timed regions, %d dispatches averaged, %.0f s"
                  % (frames_per_launch, disp.get("fast_cells", 0), time.perf_counter() - t0))
 
@@ -302,7 +307,8 @@ def spawn_ranks(n, share_device=False, timeout=1500.0):
     if not share_device:
         have = visible_gpus()
         if have < n:
-            sys.stderr.write("bench.py: --gpus %d but this node shows %d device(s) (HIP_VISIBLE_DEVICES=%s)\n" % (n, have, os.environ.get("HIP_VISIBLE_DEVICES")))
+            sys.stderr.write("bench.py: --gpus %d but this node shows %d device(s) (HIP_VISIBLE_DEVICES=%s)\n"
+                             % (n, have, os.environ.get("HIP_VISIBLE_DEVICES")))
             return 2
     port = free_port()
     procs = []
@@ -537,7 +543,8 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
         if "fast_cells_large" in mix:
             mix["fast_cells"] = mix["fast_cells_large"]    # ... and the large launch shape of k_fast_cells (two dwords per lane and round)
     stage_kernel = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "blur": "k_blur" if wl_tag == "hd_1920x1080_nf2000" else "k_blur_mfma",
-                    "describe": "k_describe", "match": "k_match_batch_mfma4", "cell_select": "k_cell_select", "level_select": "k_level_select", "quota": "k_quota"}
+                    "describe": "k_describe", "match": "k_match_batch_mfma4", "cell_select": "k_cell_select", "level_select": "k_level_select",
+                    "quota": "k_quota"}
     clocks = (rep["clock"] or {}).get("hd" if wl_tag == "hd_1920x1080_nf2000" else "vga", {}) if wl_tag else {}
 
     def clock_ghz(stage):          # measured shader clock under this kernel, GHz (nominal 2.4 where there is no usable measurement)
@@ -588,13 +595,17 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
                    "host_submit_ms_per_step": round(float(counters[6]) / world, 4),
                    "mean_keypoints_per_frame": round(float(counters[1]) / total_frames, 2),
                    "frames_with_error_status": int(counters[2]), "accepted_matches_last_frame": accepted, "accepted_match_rate_last_step": accepted_rate,
-                   "accepted_note": "best <= 50 && best < 0.6 * second over every frame of the last timed step.  Consecutive S-blocks (noise, lowtex, midtex) frames are "
-                                    "independent images, so few matches pass; S-warp (--family 5, `also.vga_warp`) is a correlated stream: consecutive frames show the "
-                                    "same corners a pixel or two apart.  What the match leg computes is checked against the oracle in the parity leg (integer-equal top-2)",
+                   "accepted_note": "best <= 50 && best < 0.6 * second over every frame of the last timed step.  Consecutive S-blocks (noise, lowtex, "
+                                    "midtex) frames are "
+                                    "independent images, so few matches pass; S-warp (--family 5, `also.vga_warp`) is a correlated stream: "
+                                    "consecutive frames show the "
+                                    "same corners a pixel or two apart.  What the match leg computes is checked against the oracle in the parity leg "
+                                    "(integer-equal top-2)",
                    "library_build_id": capi.build_id()},
         "per_rank": [{"rank": r, "device": int(row[7]), "frames": int(row[0]), "elapsed_s": round(row[3], 4), "frames_per_s": round(row[0] / row[3], 1),
                       "host_submit_ms": round(row[6], 4), "parity_checked_frames": int(row[4]),
-                      "pci_bus": int(row[8]), "numa_node": int(row[9]), "host_threads": int(row[10]), "numa_bound": int(row[11])} for r, row in enumerate(rows)],
+                      "pci_bus": int(row[8]), "numa_node": int(row[9]), "host_threads": int(row[10]), "numa_bound": int(row[11])}
+                     for r, row in enumerate(rows)],
         "roofline": roofline,
         "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(pipe_gbs / HBM_PEAK_GBS, 5), "frac_of_achievable": round(pipe_gbs / HBM_ACHIEVABLE_GBS, 5),
@@ -611,7 +622,8 @@ def run_frontend(a, cfg, world, rank, local_rank, dist, torch):
             "peak": round(SIMD_CYCLES_PER_S / (lo / n_inst) / 1e9, 2), "frac": round(value / world * lo / SIMD_CYCLES_PER_S, 4),
             "frac_range": [round(value / world * lo / SIMD_CYCLES_PER_S, 4), round(value / world * hi / SIMD_CYCLES_PER_S, 4)],
             "cycles_per_inst_range": [round(lo / n_inst, 3), round(hi / n_inst, 3)],
-            "frac_at_clock": round(value / world * sum(v * mix[k]["cycles_per_inst_lo"] / (256 * 4 * clock_ghz(k) * 1e9) for k, v in valu_insts.items()), 4) if clocks else None,
+            "frac_at_clock": (round(value / world * sum(v * mix[k]["cycles_per_inst_lo"] / (256 * 4 * clock_ghz(k) * 1e9)
+                                                           for k, v in valu_insts.items()), 4) if clocks else None),
             "clock_note": "frac prices every kernel's instructions at the nominal 2.4 GHz; frac_at_clock at the clock measured under that kernel "
                           "(profiles/clock.json = tools/run_pmc_clock.sh on this build)" if clocks else None,
             "source": "whole step in the timed region: SQ_INSTS_VALU of every kernel per frame (profiles/traffic.json, same source hash as the library) "
@@ -647,7 +659,8 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
     nq = (n + world - 1) // world
     q0 = rank * nq
     nq = max(0, min(nq, n - q0))
-    capi.set_match_path(getattr(a, "match_path", -1))          # -1: the process default (the FP4 MFMA kernels); 0: the xor + popcount kernels north_star names; 1: int8 MFMA
+    # -1: the process default (the FP4 MFMA kernels); 0: the xor + popcount kernels north_star names; 1: int8 MFMA
+    capi.set_match_path(getattr(a, "match_path", -1))
     path = capi.get_match_path()                               # the kernels in effect (environment default or the forced path): 0 / 1 / 2
     Qall = synth.descriptors(n, 1)
     Q = torch.from_numpy(Qall[q0:q0 + nq].copy()).to(dev)
@@ -731,9 +744,11 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
                 "unit": ("TOP/s (FP4 multiply-accumulates x 2)" if fp4 else "TOP/s (int8 multiply-accumulates x 2)") if mfma
                         else "10^12 pairs/s (16 lane-operations per pair: 8 v_xor + 8 v_bcnt)",
                 "frac": round(tops / (peak_override or mfma_peak), 4),
-                "peak_note": ("dense FP4 through v_mfma_scale_f32_32x32x64_f8f6f4 = 2 x the int8 / FP8 dense peak (the guide measures 9.1 POP/s); the same call "
+                "peak_note": ("dense FP4 through v_mfma_scale_f32_32x32x64_f8f6f4 = 2 x the int8 / FP8 dense peak (the guide measures 9.1 POP/s); the "
+                              "same call "
                               "through the int8 kernels (ORBX_MATCH_MFMA=8) is priced against 5 POP/s" if fp4 else
-                              "dense int8 MFMA = 2 x the 2.5 PFLOP/s bf16 dense peak; tools/microbench/valu_rate2 measures 4470 TOP/s for v_mfma_i32_32x32x32_i8"),
+                              "dense int8 MFMA = 2 x the 2.5 PFLOP/s bf16 dense peak; tools/microbench/valu_rate2 measures 4470 TOP/s for "
+                              "v_mfma_i32_32x32x32_i8"),
                 "avg_launch_ms": round(kernel_ms, 4), "pairs_per_launch": float(nq) * n,
                 "per_call_ms": {"min": round(per_call[0], 4), "median": round(kernel_ms, 4), "max": round(per_call[-1], 4), "calls": len(per_call),
                                 "timed_region_average": round(region_ms, 4)},
@@ -748,13 +763,17 @@ def run_match(a, cfg, world, rank, local_rank, dist, torch):
         # top-2 bookkeeping: 1024 SIMDs x 64 / 53.5 x 2.4 GHz.  (SURVEY 8d's 4.9e12 assumes one lane-operation per lane and clock.)
         ceil = 1024 * 64 / (8 * 2.61 + 8 * 4.08) * 2.4e9 / 1e12
         roofline["measured_issue_ceiling"] = {"peak": round(ceil, 3), "unit": "10^12 pairs/s", "frac": round(tops / ceil, 4),
-                                              "note": "8 v_xor (2.61 cycles) + 8 v_bcnt (4.08 cycles) per 64 pairs and SIMD at 2.4 GHz, top-2 bookkeeping not counted"}
+                                              "note": "8 v_xor (2.61 cycles) + 8 v_bcnt (4.08 cycles) per 64 pairs and SIMD at 2.4 GHz, top-2 "
+                              "bookkeeping not counted"}
     out = {
         "metric": "pairs/s Hamming top-2, %d x %d 256-bit descriptors" % (n, n),
         "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "repeats": repeats, "timed_steps": nsteps,
         "timed_seconds": round(tmax, 3), "ms_per_step": round(tmax / nsteps * 1e3, 4), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": ("fp4 e2m1 (+-1 encoded bits, f32 accumulate, exact)" if fp4 else "i8 (+-1 encoded bits, i32 accumulate)") if mfma else "u32 xor + popcount", "data": "synthetic",
-        "config": {"workload": "match100k: batched N-to-M descriptor match, %d x %d random 256-bit descriptors, dense top-2 (BASELINE.json configs[4])" % (n, n),
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": ("fp4 e2m1 (+-1 encoded bits, f32 accumulate, exact)" if fp4 else "i8 (+-1 encoded bits, i32 accumulate)") if mfma else "u32 xor + popcount",
+        "data": "synthetic",
+        "config": {"workload": "match100k: batched N-to-M descriptor match, %d x %d random 256-bit descriptors, dense top-2 (BASELINE.json "
+                               "configs[4])" % (n, n),
                    "queries_per_gpu": nq, "train_descriptors": n, "parallelism": "queries sharded by rank, train set replicated, no exchange",
                    "best_distance_checksum": int(counters[1]), "parity_checked_rows": int(counters[3]), "parity_mismatches": int(counters[4]),
                    "parity_note": "64 evenly spaced query rows per rank of the last call vs the oracle's sequential scan (index, best, second)",
@@ -857,7 +876,8 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--nfeatures", type=int, default=None)
-    ap.add_argument("--family", type=int, default=1, help="0 noise, 1 blocks (default), 3 lowtex, 4 midtex, 5 warp = correlated stream (orb_slam_amd/csrc/synth_frames.c)")
+    ap.add_argument("--family", type=int, default=1,
+                    help="0 noise, 1 blocks (default), 3 lowtex, 4 midtex, 5 warp = correlated stream (orb_slam_amd/csrc/synth_frames.c)")
     ap.add_argument("--no-match", action="store_true", help="extract only (same as --config vga_extract for the VGA stream)")
     ap.add_argument("--lanes", type=int, default=4,
                     help="a step's frames go through this many concurrent lanes (own extractor handle + HIP stream each); 1 = one stream")
@@ -879,7 +899,8 @@ def main():
                     help="timed region of each other frame configuration (as long as the headline's: sustained clocks)")
     ap.add_argument("--also-match-min-seconds", type=float, default=2.0, help="timed region of the 100k x 100k configurations")
     ap.add_argument("--live-traffic", default="auto", choices=["auto", "on", "off"],
-                    help="measure roofline.traffic in this run (two rocprofv3 --pmc child runs, ~40 s); auto = only in the full default command (one rank, --config vga with its `also` entries)")
+                    help="measure roofline.traffic in this run (two rocprofv3 --pmc child runs, ~40 s); auto = only in the full default command "
+                         "(one rank, --config vga with its `also` entries)")
     ap.add_argument("--detail-file", default=None, help="also write the full reports (headline + also + the compact line) to this JSON file")
     ap.add_argument("--rank-timeout", type=float, default=1500.0, help="bare --gpus N command: kill the ranks when the run exceeds this many seconds")
     ap.add_argument("--also-cpu-seconds", type=float, default=5.0, help="CPU baseline sample of each embedded configuration")
@@ -887,7 +908,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-allcores-seconds", type=float, default=8.0, help="0 disables the all-core CPU baseline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo")
-    ap.add_argument("--share-device", action="store_true", help="functional smoke of the N>1 path on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="functional smoke of the N>1 path on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     a = ap.parse_args()
     if a.no_parity:
         a.parity = "none"
