@@ -52,6 +52,45 @@ __host__ __device__ constexpr int od_row0(int rt) { return rt == 0 ? 0 : rt == 1
 typedef const void __attribute__((address_space(1))) * gptr_t;
 typedef void __attribute__((address_space(3))) * lptr_t;
 
+// Everything the kernel's lanes need that does not depend on the key point, computed by the COMPILER (constant memory, one load each instead of
+// ~170 VALU instructions per wave): the circle masks of the IC_Angle patch, the BRIEF pattern as floats, and the tap operands of the two passes.
+constexpr int od_tap(int t) { return t >= 0 && t <= 6 ? (int)((0x12223137312212ull >> (8 * t)) & 255ull) : 0; }      // [18, 34, 49, 55, 49, 34, 18][t], 0 outside
+constexpr uint32_t od_taps4(int t0) { return (uint32_t)od_tap(t0) | (uint32_t)od_tap(t0 + 1) << 8 | (uint32_t)od_tap(t0 + 2) << 16 | (uint32_t)od_tap(t0 + 3) << 24; }
+struct OdTables {
+    uint32_t mask[256];            // circle byte masks of the 31 x 8 patch dwords (umax[] of reference :495-510; slots 248.. = 0)
+    float pat[256][4];             // test t: x0, y0, x1, y1
+    uint32_t trow[3][64][4];       // row pass, column tile ct, lane: K = window column 16 g + 4 v + byte, output column c' = col0(ct) + n
+    uint32_t tcol[3][64][4];       // column pass, row tile rt, lane: K = 16 g + 4 v + byte <-> Mid row 16 v + 4 g + byte, output row ro = row0(rt) + n
+};
+constexpr uint32_t c_pattern_host[256] = {
+#include "orb_pattern_packed.inc"
+};
+constexpr OdTables make_od_tables() {
+    OdTables T{};
+    for (int t = 0; t < 256; t++) {
+        const int r = t >> 3, c = t & 7;
+        const int v = r - HALF_PATCH, av = v < 0 ? -v : v;
+        const int um = r < 31 ? (int)((UMAX_NIBBLES >> (4 * (av & 15))) & 15ull) : -1;
+        uint32_t mask = 0;
+        for (int kk = 0; kk < 4; kk++) {
+            const int u = 4 * c + kk - HALF_PATCH;
+            if ((u < 0 ? -u : u) <= um) mask |= 0xFFu << (8 * kk);
+        }
+        T.mask[t] = mask;
+        const uint32_t pk = c_pattern_host[t];
+        for (int e = 0; e < 4; e++) T.pat[t][e] = (float)(int)(int8_t)(uint8_t)(pk >> (8 * e));
+    }
+    for (int c = 0; c < 3; c++)
+        for (int l = 0; l < 64; l++)
+            for (int v = 0; v < 4; v++) {
+                const int n = l & 15, g = l >> 4;
+                T.trow[c][l][v] = od_taps4(16 * g + 4 * v - (od_col0(c) + n) - 1);
+                T.tcol[c][l][v] = od_taps4(16 * v + 4 * g - (od_row0(c) + n));
+            }
+    return T;
+}
+static __device__ __constant__ OdTables c_od = make_od_tables();
+
 template <bool FMA>
 __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
     __shared__ __attribute__((aligned(16))) float s_pat[256 * 4];       // test t: x0, y0, x1, y1 as floats (one ds_read_b128 = the two points as register pairs)
@@ -62,7 +101,8 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
     if (!frame_item(b, blockIdx.x, (g.nquads + OD_WAVES - 1) / OD_WAVES, frame, wgi)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int grp = lane >> 4, li = lane & 15;
-    const uint32_t pk_first = c_pattern[tid & 255];
+    const float4 pat_first = *reinterpret_cast<const float4*>(c_od.pat[tid & 255]);      // requested first: loads return in order, the tables are built while the key points are on their way
+    const uint32_t mask_first = c_od.mask[tid & 255];
     const int32_t* counts = b.level_count + frame * MAX_LEVELS;
     const int quad = wgi * OD_WAVES + wave_id();
     const bool live = quad < g.nquads;
@@ -97,20 +137,9 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
         kp.pos = (uint32_t)(e == 0 ? kq[0] : e == 1 ? kq[2] : e == 2 ? kq[4] : kq[6]);
         kp.resp = __builtin_bit_cast(float, e == 0 ? kq[1] : e == 1 ? kq[3] : e == 2 ? kq[5] : kq[7]);
     }
-    for (int t = tid; t < 256; t += OD_WAVES * 64) {
-        const uint32_t pk = t == tid ? pk_first : c_pattern[t];
-        reinterpret_cast<float4*>(s_pat)[t] = make_float4((float)(int)(int8_t)pk, (float)(int)(int8_t)(pk >> 8), (float)(int)(int8_t)(pk >> 16), (float)(int)(int8_t)(pk >> 24));
-        const int r = t >> 3, c = t & 7;
-        const int v = r - HALF_PATCH, av = v < 0 ? -v : v;
-        const int um = r < 31 ? (int)((UMAX_NIBBLES >> (4 * (av & 15))) & 15ull) : -1;
-        uint32_t mask = 0;
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            const int u = 4 * c + kk - HALF_PATCH;
-            if ((u < 0 ? -u : u) <= um) mask |= 0xFFu << (8 * kk);
-        }
-        s_mask[t] = mask;
-    }
+    static_assert(OD_WAVES * 64 == 256, "one table entry per thread");
+    reinterpret_cast<float4*>(s_pat)[tid] = pat_first;
+    s_mask[tid] = mask_first;
     int out_base = 0, total = 0, cnt = 0;
     for (int l = 0; l < g.nlevels; l++) {
         int c = 0;
@@ -194,14 +223,8 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
     v4i Trow[3], Tcol[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        int tr[4], tc[4];
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            tr[v] = gauss7_taps4(16 * g4 + 4 * v - (od_col0(c) + n16) - 1);   // K = window column 16 g + 4 v + byte, output column c' = col0 + n
-            tc[v] = gauss7_taps4(16 * v + 4 * g4 - (od_row0(c) + n16));       // K = 16 g + 4 v + byte <-> Mid row 16 v + 4 g + byte, output row ro = row0 + n
-        }
-        Trow[c] = (v4i){tr[0], tr[1], tr[2], tr[3]};
-        Tcol[c] = (v4i){tc[0], tc[1], tc[2], tc[3]};
+        Trow[c] = *reinterpret_cast<const v4i*>(c_od.trow[c][lane]);
+        Tcol[c] = *reinterpret_cast<const v4i*>(c_od.tcol[c][lane]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the windows have landed
     wave_lds_fence();
@@ -395,7 +418,7 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
         const uint32_t ctr_a = (uint32_t)(uintptr_t)(lptr_t)ctr - (uint32_t)(OD_PITCH * 0x400000 + 0x4B400000);
         typedef const uint8_t __attribute__((address_space(3))) * lbyte_t;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 15; j >= 0; j--) {                       // downwards: the bits are shifted in from the bottom, test li + 16 j ends at bit j
             const float4 P = pat[16 * j];
             f2v r0 = rotate((f2v){P.x, P.y}), r1 = rotate((f2v){P.z, P.w});
             r0 = r0 + MAGIC;                                    // (v_pk_add_f32)
@@ -405,8 +428,9 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
             const float r0y = r0.x, r0x = r0.y, r1y = r1.x, r1x = r1.y;
             const uint32_t o0 = (uint32_t)(__mul24(float_bits(r0y), OD_PITCH) + float_bits(r0x));
             const uint32_t o1 = (uint32_t)(__mul24(float_bits(r1y), OD_PITCH) + float_bits(r1x));
-            const int v0 = *(lbyte_t)(uintptr_t)(ctr_a + o0), v1 = *(lbyte_t)(uintptr_t)(ctr_a + o1);
-            mybits |= (uint32_t)(v0 < v1) << j;
+            const uint32_t v0 = *(lbyte_t)(uintptr_t)(ctr_a + o0), v1 = *(lbyte_t)(uintptr_t)(ctr_a + o1);
+            // mybits = 2 mybits + (v0 < v1): the comparison's carry straight into the add (two instructions instead of compare, select, or)
+            asm("v_cmp_lt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mybits) : "v"(v0), "v"(v1) : "vcc");
         }
     }
     // 16 x 16 bit-matrix transpose inside the group (ds_swizzle butterflies, as k_describe)
