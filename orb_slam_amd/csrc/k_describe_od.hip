@@ -344,6 +344,7 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
             const v4i HI = {h4[0], h4[1], h4[2], h4[3]}, LO = {l4[0], l4[1], l4[2], l4[3]};
             const int X0 = xs + 4 + od_col0(ct) + 4 * g4;    // level column of the lane's first output byte (a multiple of 4)
             const uint32_t tw = X0 < L.wvec ? 1u : 0u;       // ties-to-even columns (blur_wvec is a multiple of 4)
+            const uint32_t cadd = (uint32_t)(257 * 32896 + 0x7FFF) + (tw ^ 1u);      // the centring offsets + the rounding constant (+ 1 more: half up)
             uint32_t keepc = 0;                              // (edge windows) bytes of the dword whose column lies outside the level
             if (edge) {
 #pragma unroll
@@ -354,13 +355,15 @@ __global__ __launch_bounds__(OD_WAVES * 64) void k_describe_od(Batch b) {
                 const v4i zero = {0, 0, 0, 0};
                 v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(HI, Tcol[rt], zero, 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 4; i++) acc[i] = (int)(((uint32_t)acc[i] << 8) + (uint32_t)(257 * 32896 + 0x7FFF));   // the centring offsets + the rounding constant
+                for (int i = 0; i < 4; i++) acc[i] = (int)(((uint32_t)acc[i] << 8) + cadd);
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(LO, Tcol[rt], acc, 0, 0, 0);
                 uint32_t qv[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
+                    // + bit 16 (ties to even; the half-up columns carry their + 1 in `cadd`): shift, and, add — three 2-cycle instructions instead of a
+                    // bit-field extract and a three-operand add at 4 cycles each (profiles/r02_valu_issue_rates2.txt)
                     const uint32_t t = (uint32_t)acc[i];
-                    qv[i] = t + __builtin_amdgcn_ubfe(t, 16u, tw) + (tw ^ 1u);      // + bit 16 (ties to even) or + 1 (half up)
+                    qv[i] = t + ((t >> 16) & tw);
                 }
                 const us2v lo2 = __builtin_elementwise_min(as_us2v(__builtin_amdgcn_perm(qv[1], qv[0], 0x07060302u)), as_us2v(0x00FF00FFu));
                 const us2v hi2 = __builtin_elementwise_min(as_us2v(__builtin_amdgcn_perm(qv[3], qv[2], 0x07060302u)), as_us2v(0x00FF00FFu));
