@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised differential test of the THROUGHPUT path (orbx_extract_batch_device: per-level k_resize, full-batch k_fast_cells /
-k_blur / k_blur_mfma / k_describe, frame -> XCD block renumbering from 64 frames): random image sizes, constructor arguments, families and launch
+"""Randomised differential test of the THROUGHPUT path (orbx_extract_batch_device: per-level k_resize, full-batch k_fast_cells, k_describe_od with the blur
+per keypoint window — or, in one case of seven, k_blur / k_blur_mfma + k_describe —, frame -> XCD block renumbering from 64 frames): random image sizes,
+constructor arguments (both float modes, both blur roundings), families incl. the correlated S-warp stream, row pitches incl. byte-unaligned ones, and launch
 group sizes (32 .. 96 frames, max_batch sometimes smaller than the batch so that a call spans several launch groups); every frame
 of every case against the CPU oracle, byte for byte.  tools/fuzz_parity.py does the same for the one-frame call (orbx_extract).
 usage: fuzz_batch.py [cases] [seed]   — prints one JSON line."""
@@ -22,7 +23,7 @@ try:
 except Exception:
     workers = len(os.sched_getaffinity(0))
 workers = max(1, min(workers, 32))
-ok = geo = lim = frames_checked = 0
+ok = geo = lim = frames_checked = n_od = n_fpc = 0
 bad = []
 t0 = time.time()
 for c in range(cases):
@@ -40,7 +41,12 @@ for c in range(cases):
     pad = int(rng.choice([0, 0, 4, 8]))                      # row stride beyond the width (multiple of 4: the aligned kernels)
     if rng.random() < 0.5:
         pad = (-w) % 16 + 16 * int(rng.integers(0, 3))       # rows of whole 16-byte chunks: what k_blur_mfma (levels up to 1024 px wide) takes
-    fams = rng.choice([0, 1, 1, 1, 3, 4], size=B)
+    fams = rng.choice([0, 1, 1, 1, 3, 4, 5, 5], size=B)
+    r = rng.random()
+    if r < 0.15:
+        pad = int(rng.choice([1, 2, 3, 5, 7, 13]))           # byte-unaligned pitches (round 6: the 16-byte LDS-DMA takes any source alignment)
+    fpc = bool(rng.random() < 0.25)                          # orbx_params::fp_contract: the reference as its own build flags contract it
+    od = 0 if rng.random() < 0.15 else 1                     # 0: blur kernels + k_describe; 1 (default): k_describe_od
     try:
         capi.geometry(w, h, nfeatures=nf, scaleFactor=sf, nlevels=nl, scoreType=st, fastTh=th)
     except capi.OrbxError as e:
@@ -55,7 +61,9 @@ for c in range(cases):
     buf = np.zeros((B, h, rs), np.uint8)
     buf[:, :, :w] = frames
     d_img = torch.from_numpy(buf).cuda()
-    ex = capi.ORBextractor(nfeatures=nf, scaleFactor=sf, nlevels=nl, scoreType=st, fastTh=th, blur_rounding=blur, max_batch=max_batch)
+    ex = capi.ORBextractor(nfeatures=nf, scaleFactor=sf, nlevels=nl, scoreType=st, fastTh=th, blur_rounding=blur, max_batch=max_batch, fp_contract=fpc)
+    ex.set_blur_on_demand(od)
+    n_od += od; n_fpc += int(fpc)
     cap = ex.max_keypoints
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
@@ -69,7 +77,7 @@ for c in range(cases):
     ex.close()
 
     def oracle(idx):
-        o = ol.OracleExtractor(nf, sf, nl, st, th, blur_mode=blur)
+        o = ol.OracleExtractor(nf, sf, nl, st, th, blur_mode=blur, fp_contract=fpc)
         return [(j, o(frames[j])) for j in idx]
     want = [None] * B
     with ThreadPoolExecutor(workers) as pool:
@@ -80,8 +88,8 @@ for c in range(cases):
              or desc[j, :n[j]].tobytes() != want[j][1].tobytes()]
     frames_checked += B
     if wrong:
-        bad.append(dict(case=c, w=w, h=h, nf=nf, sf=sf, nl=nl, st=st, th=th, blur=blur, B=B, max_batch=max_batch, pad=pad, frames=wrong[:8]))
+        bad.append(dict(case=c, w=w, h=h, nf=nf, sf=sf, nl=nl, st=st, th=th, blur=blur, B=B, max_batch=max_batch, pad=pad, fp_contract=fpc, on_demand=od, frames=wrong[:8]))
     else:
         ok += 1
 print(json.dumps({"cases": cases, "seed": seed, "bit_exact_cases": ok, "frames_checked": frames_checked, "geometry_the_reference_cannot_process": geo,
-                  "implementation_limit": lim, "mismatches": bad, "seconds": round(time.time() - t0, 1), "build": capi.build_id()}))
+                  "implementation_limit": lim, "cases_on_demand": n_od, "cases_fp_contract": n_fpc, "mismatches": bad, "seconds": round(time.time() - t0, 1), "build": capi.build_id()}))

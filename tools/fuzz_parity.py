@@ -24,11 +24,12 @@ for c in range(cases):
     nl = int(rng.integers(1, 9))
     st = int(rng.random() < 0.25) ^ 1            # mostly FAST_SCORE (1), sometimes HARRIS_SCORE (0)
     th = int(rng.choice([5, 7, 10, 20, 20, 30, 50]))
-    fam = int(rng.choice([0, 1, 1, 1, 3]))
+    fam = int(rng.choice([0, 1, 1, 1, 3, 4, 5]))
+    fpc = bool(rng.random() < 0.25)                  # orbx_params::fp_contract (round 6)
     blur = int(rng.random() < 0.2)
     img = synth.frame(w, h, fam, int(rng.integers(0, 1000)))
     try:
-        ex = capi.ORBextractor(nfeatures=nf, scaleFactor=sf, nlevels=nl, scoreType=st, fastTh=th, blur_rounding=blur)
+        ex = capi.ORBextractor(nfeatures=nf, scaleFactor=sf, nlevels=nl, scoreType=st, fastTh=th, blur_rounding=blur, fp_contract=fpc)
         got = ex(img)
         ex.close()
     except capi.OrbxError as e:
@@ -40,7 +41,7 @@ for c in range(cases):
             continue
         bad.append(dict(case=c, w=w, h=h, nf=nf, sf=sf, nl=nl, st=st, th=th, fam=fam, err=e.code))
         continue
-    k, d = ol.OracleExtractor(nf, sf, nl, st, th, blur_mode=blur)(img)
+    k, d = ol.OracleExtractor(nf, sf, nl, st, th, blur_mode=blur, fp_contract=fpc)(img)
     if len(k) == len(got[0]) and k.tobytes() == got[0].tobytes() and d.tobytes() == got[1].tobytes():
         ok += 1
     else:
