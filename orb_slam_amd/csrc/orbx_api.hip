@@ -48,6 +48,7 @@ struct orbx_extractor {
     // diagnostics
     int stop_after = -1;
     bool no_xcd_affinity = false;     // ORBX_XCD_AFFINITY=0 at orbx_create (A/B measurements)
+    int od_min_frames = ORBX_OD_MIN_FRAMES_DEFAULT;    // ORBX_OD_MIN_FRAMES at orbx_create (A/B measurements)
     int blur_on_demand = ORBX_BLUR_ON_DEMAND_DEFAULT;   // ORBX_BLUR_ON_DEMAND=0/1 at orbx_create, orbx_debug_set_blur_on_demand
     StageTimer timer;
     SideStream side;
@@ -168,6 +169,7 @@ int orbx_create(const orbx_params* p, orbx_extractor** out) {
     // ORBX_OVERLAP=0 keeps everything on one stream (cleaner per-kernel timings when profiling).
     { const char* xa = getenv("ORBX_XCD_AFFINITY"); h->no_xcd_affinity = xa && xa[0] == '0'; }
     { const char* fh = getenv("ORBX_FALLBACK_HINT"); h->fallback_hint = !(fh && fh[0] == '0'); }
+    { const char* om = getenv("ORBX_OD_MIN_FRAMES"); if (om && atoi(om) >= 1) h->od_min_frames = atoi(om); }
     { const char* od = getenv("ORBX_BLUR_ON_DEMAND"); if (od && (od[0] == '0' || od[0] == '1') && od[1] == 0) h->blur_on_demand = od[0] - '0'; }
     { const char* zc = getenv("ORBX_ZERO_COPY"); h->zero_copy = !(zc && zc[0] == '0'); }
     const char* ovl = getenv("ORBX_OVERLAP");
@@ -258,6 +260,7 @@ int orbx_extract_batch_device_phases(orbx_extractor* h, const uint8_t* d_imgs, i
         b.nframes = std::min(h->p.max_batch, nframes - f0);
         b.xcd_affinity = (b.nframes >= XCD_AFFINITY_MIN_FRAMES && !h->no_xcd_affinity) ? 1 : 0;
         b.blur_on_demand = h->blur_on_demand;
+        b.od_min_frames = h->od_min_frames;
         b.img = d_imgs + (ptrdiff_t)f0 * frame_stride;
         b.img_row_stride = row_stride;
         b.img_frame_stride = frame_stride;

@@ -68,6 +68,9 @@ struct CellGeom {
 #define ORBX_BLUR_ON_DEMAND_DEFAULT 1     // (round 6) what a handle does when ORBX_BLUR_ON_DEMAND is not in the environment: full launch groups blur per keypoint
                                           // window (k_describe_od: VGA 381.5k -> 404.1k frames/s, 1080p 75.2k -> 90.4k on the first build; profiles/r06_ab_on_demand.txt)
 #endif
+#ifndef ORBX_OD_MIN_FRAMES_DEFAULT
+#define ORBX_OD_MIN_FRAMES_DEFAULT 32    // launch groups below this keep the blur kernels (the one-frame call: FAST + blur in one launch)
+#endif
 #ifndef ORBX_DESC_PACKED_PATTERN
 #define ORBX_DESC_PACKED_PATTERN 1      // k_describe: the BRIEF pattern in LDS as packed int8 (1 KB) instead of floats (4 KB)
 #endif
@@ -237,6 +240,7 @@ struct Batch {
     int cap;
     int nframes;
     int xcd_affinity;         // 1: launches renumber their blocks so that a frame's work items share one XCD (its L2)
+    int od_min_frames;        // ... from this many frames per launch group on
     int blur_on_demand;       // 1: no blurred plane — k_describe_od blurs each keypoint's window itself (full launch groups of supported geometries)
 };
 

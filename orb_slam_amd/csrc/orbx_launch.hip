@@ -22,7 +22,7 @@
 namespace orbx {
 
 static bool use_on_demand(const Batch& b, const HostGeom& hg, int stop_after) {
-    return b.blur_on_demand && b.nframes >= PYR_FUSED_MAX_FRAMES && stop_after < 0 && describe_od_supported(b, hg);
+    return b.blur_on_demand && b.nframes >= b.od_min_frames && stop_after < 0 && describe_od_supported(b, hg);
 }
 
 int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int stop_after, StageTimer* timer, const SideStream* side, int phases) {
@@ -52,7 +52,7 @@ int launch_extract(const Batch& b, const HostGeom& hg, hipStream_t stream, int s
     // (a launch group that cannot fill the chip keeps the blur in line: its short strips take ~6 us, the fork and the join across
     //  two hardware queues cost 8 us each)
     const bool overlap = side && side->aux && stop_after < 0 && F >= PYR_FUSED_MAX_FRAMES && !on_demand;
-    const bool fuse_blur = F < PYR_FUSED_MAX_FRAMES && !b.xcd_affinity;    // k_fast_blur
+    const bool fuse_blur = F < PYR_FUSED_MAX_FRAMES && !b.xcd_affinity && !on_demand;    // k_fast_blur
     {
         StageScope sc(timer, stream, ST_FAST_CELLS);
         if (launch_fast(b, hg, stream, fuse_blur) != ORBX_OK) return ORBX_ERR_DEVICE;
