@@ -97,6 +97,10 @@ size_t orbs_lds_bytes(int cap, int qcap);
 /* test hook: -1 = process default (ORBS_BUCKETS in the environment, on unless "0"), 0 = plain CSR scan for every size,
  * 1 = bucketed index where it fits.  Same results either way under the precondition above (tests/test_gpu_search.py runs both). */
 int orbs_debug_set_buckets(int mode);
+/* Launches of up to `nproblems` problems take the 1024-thread form of the search kernel (sixteen waves per problem: the latency form, what a
+ * one-problem call of ORB_SLAM::ORBmatcher gets), larger ones the 256-thread form.  Same results.  Default: ORBS_WIDE_MAX in the environment, else 64;
+ * -2 restores it; 0 = never, a large number = always (tests/test_gpu_search.py runs both). */
+int orbs_debug_set_wide_max(int nproblems);
 
 /* Outputs per problem: d_q2t[qcap] the train feature each query is finally matched to (-1 none), d_t2q[cap] the query each
  * train feature is finally matched to (-1 none), d_best / d_second[qcap] the two distances the scan left (INT_MAX as in the

@@ -40,7 +40,7 @@ EXPORTS_F = [
     "orbf_features_in_area_device",
 ]
 # include/orbs.h (greedy grid-window searches)
-EXPORTS_S = ["orbs_lds_bytes", "orbs_debug_set_buckets", "orbs_three_maxima", "orbs_window_search_batch_device", "orbs_list_search_batch_device",
+EXPORTS_S = ["orbs_lds_bytes", "orbs_debug_set_buckets", "orbs_debug_set_wide_max", "orbs_three_maxima", "orbs_window_search_batch_device", "orbs_list_search_batch_device",
              "orbs_bow_ranges_batch_device", "orbs_triangulation_search_batch_device", "orbs_epipolar_bound", "orbs_agreement_batch_device"]
 PHASE_PYRAMID, PHASE_DETECT, PHASE_DESCRIBE, PHASE_ALL = 1, 2, 4, 7
 RULE_MAPPOINTS, RULE_WINDOW, RULE_BEST, RULE_INIT, RULE_BOW, RULE_FREE, RULE_TRIANGULATION = 0, 1, 2, 3, 4, 5, 6
@@ -141,6 +141,7 @@ def lib():
         L.orbm_debug_set_match_path.argtypes = [ci]
         L.orbm_debug_get_match_path.argtypes = []
         L.orbs_debug_set_buckets.argtypes = [ci]
+        L.orbs_debug_set_wide_max.argtypes = [ci]
         L.orbm_match_top2_segments.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci]
         L.orbm_match_top2_segments_device.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp]
         L.orbx_device_alloc.argtypes = [ci, ctypes.c_size_t, ctypes.POINTER(vp)]
@@ -401,6 +402,13 @@ def set_search_buckets(mode):
     rc = lib().orbs_debug_set_buckets(mode)
     if rc != ORBX_OK:
         raise OrbxError(rc, "orbs_debug_set_buckets")
+
+
+def set_search_wide_max(nproblems):
+    """test hook: launches of up to `nproblems` problems take the 1024-thread (latency) form of the search kernel; -2 = process default (64), 0 = never"""
+    rc = lib().orbs_debug_set_wide_max(nproblems)
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbs_debug_set_wide_max")
 
 
 def count_accepted(best, second, th=50, ratio=0.6):

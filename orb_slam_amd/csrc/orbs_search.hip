@@ -329,9 +329,12 @@ __device__ __forceinline__ bool accept_rule(const orbs_params& prm, int bestDist
 //      earlier lane of the same round would affect (its best or second was just claimed) or whose list ran dry.  Affected
 //      lanes simply go again next round under the refreshed state; a dry lane has the whole wave rescan its window.
 //      With little contention a wave commits its 64 queries in two or three rounds.
-constexpr int GROUP = 256;
+// GROUP = queries scanned speculatively at a time = threads of the workgroup.  256 (four waves) for launches with many problems; 1024 for launches
+// with FEW problems (round 6: the one-problem calls of orb_slam_amd/cpp/ORBmatcher.cc) — a lone four-wave workgroup has one wave per SIMD and nothing to
+// hide its LDS round trips behind; sixteen waves scan a 1000-query frame in one pass.  Results do not depend on it (speculation + in-order commit).
+constexpr int GROUP_BATCH = 256, GROUP_WIDE = 1024;
 
-template <bool BK>
+template <bool BK, int GROUP>
 __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_params prm, Args a) {
     extern __shared__ __align__(16) uint8_t lds[];
     const Layout L = make_layout(a.cap, a.qcap, a.desc_in_lds != 0, BK);
@@ -708,10 +711,24 @@ __global__ __launch_bounds__(256) void k_agreement(const int32_t* __restrict__ m
 }  // namespace orbs
 
 // the kernel may use up to the whole 160 KiB of LDS: raise the dynamic-LDS limit of the current device
-static int orbs_set_lds(size_t, bool bucketed = false) {
-    // the attribute belongs to the CURRENT device: set it on every launch path (a cheap runtime call), not once per process
-    const void* k = bucketed ? (const void*)orbs::k_window_search<true> : (const void*)orbs::k_window_search<false>;
-    return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+static std::atomic<int> g_wide_max{-2};          // launches of up to this many problems take the 1024-thread form (-2: ORBS_WIDE_MAX in the environment, else 64)
+static bool orbs_wide(int nproblems) {
+    int m = g_wide_max.load(std::memory_order_relaxed);
+    if (m == -2) { const char* e = getenv("ORBS_WIDE_MAX"); m = e ? atoi(e) : 64; g_wide_max.store(m, std::memory_order_relaxed); }
+    return nproblems <= m;
+}
+template <bool BK>
+static int orbs_launch(int nproblems, size_t lds, hipStream_t stream, const orbf_bounds& b, const orbs_params& prm, const orbs::Args& a) {
+    // the kernel may use up to the whole 160 KiB of LDS: raise the dynamic-LDS limit (the attribute belongs to the CURRENT device: set on every launch
+    // path — a cheap runtime call —, not once per process)
+    if (orbs_wide(nproblems)) {
+        if (hipFuncSetAttribute((const void*)orbs::k_window_search<BK, orbs::GROUP_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ORBX_ERR_DEVICE;
+        hipLaunchKernelGGL((orbs::k_window_search<BK, orbs::GROUP_WIDE>), dim3(nproblems), dim3(orbs::GROUP_WIDE), lds, stream, b, prm, a);
+    } else {
+        if (hipFuncSetAttribute((const void*)orbs::k_window_search<BK, orbs::GROUP_BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ORBX_ERR_DEVICE;
+        hipLaunchKernelGGL((orbs::k_window_search<BK, orbs::GROUP_BATCH>), dim3(nproblems), dim3(orbs::GROUP_BATCH), lds, stream, b, prm, a);
+    }
+    return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
 
 extern "C" {
@@ -723,6 +740,12 @@ static bool orbs_use_buckets() {
     static const bool env_default = [] { const char* e = getenv("ORBS_BUCKETS"); return !(e && e[0] == '0'); }();
     const int f = g_buckets.load(std::memory_order_relaxed);
     return f < 0 ? env_default : f != 0;
+}
+
+int orbs_debug_set_wide_max(int nproblems) {
+    if (nproblems < -2) return ORBX_ERR_ARG;
+    g_wide_max.store(nproblems, std::memory_order_relaxed);      // -2: back to the process default
+    return ORBX_OK;
 }
 
 int orbs_debug_set_buckets(int mode) {
@@ -778,14 +801,11 @@ int orbs_window_search_batch_device(const orbf_bounds* b, const orbs_params* prm
     const size_t lds_bk = orbs::make_layout(cap, qcap, true, true).total;
     const bool bucketed = desc_in_lds && lds_bk <= 160 * 1024 && orbs_use_buckets();
     if (bucketed) lds = lds_bk;
-    if (orbs_set_lds(lds, bucketed) != ORBX_OK) return ORBX_ERR_DEVICE;
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
     orbs::Args a{d_kps_un, d_desc, d_cell_off, d_cell_feat, d_nt, d_claimed, d_qxyr, d_qlev, d_qdesc, d_qangle, d_qvalid, d_nq,
                  d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, desc_in_lds, bucketed ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
-    if (bucketed) hipLaunchKernelGGL(orbs::k_window_search<true>, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, *b, prm2, a);
-    else hipLaunchKernelGGL(orbs::k_window_search<false>, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, *b, prm2, a);
-    return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+    return bucketed ? orbs_launch<true>(nproblems, lds, (hipStream_t)stream, *b, prm2, a) : orbs_launch<false>(nproblems, lds, (hipStream_t)stream, *b, prm2, a);
 }
 
 
@@ -801,14 +821,12 @@ int orbs_list_search_batch_device(const orbs_params* prm, const orbx_keypoint* d
     int desc_in_lds = 1;
     const size_t lds = orbs_choose_layout(cap, qcap, desc_in_lds);
     if (lds > 160 * 1024) return ORBX_ERR_CAPACITY;
-    if (orbs_set_lds(lds) != ORBX_OK) return ORBX_ERR_DEVICE;
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
     orbs::Args a{d_kps, d_desc, nullptr, d_list, d_nt, d_claimed, nullptr, nullptr, d_qdesc, d_qangle, d_qvalid, d_nq,
                  d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, desc_in_lds, 0, d_nlist, d_qrange, d_qindex, nullptr, nullptr, {}};
     orbf_bounds nob{};
-    hipLaunchKernelGGL(orbs::k_window_search<false>, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, nob, prm2, a);
-    return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+    return orbs_launch<false>(nproblems, lds, (hipStream_t)stream, nob, prm2, a);
 }
 
 int orbs_triangulation_search_batch_device(const orbs_params* prm, const float* d_F12, const float* level_sigma2, int nlevels,
@@ -825,15 +843,13 @@ int orbs_triangulation_search_batch_device(const orbs_params* prm, const float* 
     int desc_in_lds = 1;
     const size_t lds = orbs_choose_layout(cap, qcap, desc_in_lds);
     if (lds > 160 * 1024) return ORBX_ERR_CAPACITY;
-    if (orbs_set_lds(lds) != ORBX_OK) return ORBX_ERR_DEVICE;
     orbs_params prm2 = *prm;
     prm2.check_orientation = prm->check_orientation ? 1 : 0;
     orbs::Args a{d_kps2, d_desc2, nullptr, d_list, d_nt, d_claimed, nullptr, nullptr, d_qdesc, nullptr, d_qvalid, d_nq,
                  d_q2t, d_t2q, d_best, d_second, d_nmatches, cap, qcap, desc_in_lds, 0, d_nlist, d_qrange, d_qindex, d_kps1, d_F12, {}};
     for (int i = 0; i < ORBS_MAX_LEVELS; ++i) a.epi_thr[i] = orbs_epipolar_bound(level_sigma2[i < nlevels ? i : nlevels - 1]);
     orbf_bounds nob{};
-    hipLaunchKernelGGL(orbs::k_window_search<false>, dim3(nproblems), dim3(orbs::GROUP), lds, (hipStream_t)stream, nob, prm2, a);
-    return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
+    return orbs_launch<false>(nproblems, lds, (hipStream_t)stream, nob, prm2, a);
 }
 
 int orbs_agreement_batch_device(const int32_t* d_match12, const int32_t* d_n1, int cap1, const int32_t* d_match21, const int32_t* d_n2, int cap2,

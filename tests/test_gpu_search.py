@@ -11,13 +11,16 @@ pytestmark = pytest.mark.gpu
 CAM = capi.Camera.make(517.3, 516.5, 318.6, 255.3, (0.2624, -0.9531, -0.0054, 0.0026), 640, 480)
 
 
-@pytest.fixture(params=["bucketed", "plain"])
+@pytest.fixture(params=["bucketed", "plain", "bucketed-wide", "plain-wide"])
 def index_form(request):
-    """The grid searches come in two forms with the same results (include/orbs.h): the level-bucketed index (frames up to ~2400
-    features) and the plain 64 x 48 CSR scan (larger frames, or ORBS_BUCKETS=0).  The same problems go through both."""
-    capi.set_search_buckets(1 if request.param == "bucketed" else 0)
+    """The grid searches come in two index forms with the same results (include/orbs.h): the level-bucketed index (frames up to ~2400
+    features) and the plain 64 x 48 CSR scan (larger frames, or ORBS_BUCKETS=0) — and, since round 6, in two launch shapes: 256 threads per
+    problem (launches with many problems) and 1024 (few problems: the one-problem calls of ORB_SLAM::ORBmatcher).  The same problems go through all."""
+    capi.set_search_buckets(1 if request.param.startswith("bucketed") else 0)
+    capi.set_search_wide_max(1 << 30 if request.param.endswith("wide") else 0)
     yield request.param
     capi.set_search_buckets(-1)
+    capi.set_search_wide_max(-2)
 
 
 def _problem(seed, nt, nq, radius, crowd=False, level_mode="pm1"):
