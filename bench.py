@@ -845,7 +845,7 @@ def compact_line(full, also=None):
     if also:
         summ = {}
         for name, rpt in also.items():
-            row = _pick(rpt, ("value", "unit", "ms_per_step", "timed_seconds"))
+            row = _pick(rpt, ("value", "unit", "ms_per_step"))          # (timed_seconds is in the #detail report: the line stays well under 4 KB)
             row["parity_mismatches"] = rpt.get("config", {}).get("parity_mismatches")
             if rpt.get("config", {}).get("accepted_match_rate_last_step") is not None and name == "vga_warp":
                 row["accepted_match_rate"] = rpt["config"]["accepted_match_rate_last_step"]
