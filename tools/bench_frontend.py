@@ -20,6 +20,7 @@ ap.add_argument("--nfeatures", type=int, default=1000)
 ap.add_argument("--batch", type=int, default=512); ap.add_argument("--ring", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--window", type=float, default=100.0)
 ap.add_argument("--voc-k", type=int, default=10); ap.add_argument("--voc-l", type=int, default=6)
+ap.add_argument("--family", type=int, default=1, help="synthetic frame family: 1 S-blocks (independent frames), 5 S-warp (a correlated stream: the window search finds its partners)")
 ap.add_argument("--lanes", type=int, default=4, help="the step's frames go through this many free-running lanes (own handles + stream each, NOTES.md §4.5)")
 a = ap.parse_args()
 B, w, h = a.batch, a.w, a.h
@@ -27,7 +28,7 @@ G = max(1, min(a.lanes, B))
 while B % G:
     G -= 1
 b = B // G
-frames = synth.frames(w, h, synth.BLOCKS, 0, a.ring)
+frames = synth.frames(w, h, a.family, 0, a.ring)
 d_img = torch.from_numpy(frames).cuda()
 voc = synth.vocabulary(a.voc_k, a.voc_l, seed=1)
 cam = capi.Camera.make(517.3, 516.5, 318.6, 255.3, (0.2624, -0.9531, -0.0054, 0.0026), w, h)
@@ -118,7 +119,7 @@ for i in range(3 + a.steps, 3 + 2 * a.steps):
     step(i, True)
 cat = lambda f: torch.cat([f(ln) for ln in lanes])
 out = {"metric": "frontend_frames_per_s", "value": round(B / (total_ms * 1e-3), 1), "unit": "frames/s", "ms_per_step": round(total_ms, 4),
-       "config": {"workload": "%dx%d, %d kp, %d frames per step in %d lanes: extract + undistort/grid + BoW(k=%d,L=%d) + WindowSearch(r=%g, rot) + dense top-2" %
+       "config": {"family": synth.FAMILY_NAMES.get(a.family, str(a.family)), "workload": "%dx%d, %d kp, %d frames per step in %d lanes: extract + undistort/grid + BoW(k=%d,L=%d) + WindowSearch(r=%g, rot) + dense top-2" %
                   (w, h, a.nfeatures, B, G, a.voc_k, a.voc_l, a.window), "lanes": G},
        "stage_ms_per_step": {k: round(v / a.steps, 4) for k, v in acc.items()},
        "stage_timing": "every lane's stages alone on the chip (a serial pass after the timed loop), summed over the lanes",

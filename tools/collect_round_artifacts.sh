@@ -39,5 +39,7 @@ timeout 100 tools/microbench/mfma_layout > $D/mfma_layout.txt 2>&1
 timeout 200 python tools/bench_kf_search.py 2>/dev/null | tail -1 > $D/kf_search.json
 timeout 300 python tools/bench_frontend.py --window 15 2>/dev/null | tail -1 > $D/frontend_w15.json
 timeout 300 python tools/bench_frontend.py 2>/dev/null | tail -1 > $D/frontend_w100.json
+timeout 300 python tools/bench_frontend.py --window 15 --family 5 2>/dev/null | tail -1 > $D/frontend_w15_warp.json      # the correlated stream: the window search finds its partners
+timeout 300 python tools/bench_orbmatcher_dropin.py --out $D/orbmatcher_dropin.json > $D/orbmatcher_dropin.txt 2>/dev/null    # one-problem latency of the drop-in ORBmatcher beside the reference's ORBmatcher.cc on the host
 ls $D | wc -l
 python -c "import json; d=json.load(open('$D/bench.json')); print(d['value'], d['ms_per_step'], d['roofline'], d['cpu_baseline']['value'], d.get('cpu_baseline_allcores')); print({k: (v['value'], v['roofline']['frac']) for k, v in d['also'].items()})"
