@@ -236,6 +236,12 @@ Found list_search(int device, int rule, int th, float ratio, bool check, const L
     const int npos = (int)nw.qslot.size();
     if (P.nT == 0 || P.nQ == 0 || npos == 0 || nw.list.empty()) return f;
     const int cap = P.nT, qcap = std::max(P.nQ, npos);
+    // a FeatureVector holds every feature of its frame at most once (DBoW2 FeatureVector::addFeature): anything else is not one of this frame
+    if ((int)nw.list.size() > cap) throw std::logic_error("ORBmatcher: the scanned frame's FeatureVector lists more features than the frame has");
+    for (size_t j = 0; j < nw.list.size(); j++)
+        if ((unsigned)nw.list[j] >= (unsigned)P.nT) throw std::logic_error("ORBmatcher: a FeatureVector entry of the scanned frame is not one of its features");
+    for (size_t j = 0; j < nw.qslot.size(); j++)
+        if ((unsigned)nw.qslot[j] >= (unsigned)P.nQ) throw std::logic_error("ORBmatcher: a FeatureVector entry of the query key frame is not one of its features");
     Workspace& w = workspace(device);
     w.begin(workspace_bytes(cap, qcap) + (size_t)P.nQ * 64);
     const orbx_keypoint* kpsT = w.put((const orbx_keypoint*)P.kpsT, (size_t)P.nT).d;
