@@ -10,7 +10,7 @@
 //     (cells x-major, then y, then push_back order), so the two smallest keys are exactly the best / second-best the
 //     reference's `if(d<best)... else if(d<best2)` scan ends with, first-listed candidate on ties.
 // Queries go 256 at a time, one per thread (four waves): every lane scans its own window SPECULATIVELY against the claim
-// state of the group start and keeps its four smallest keys; the group is then committed in query order, wave after wave,
+// state of the group start and keeps its four (six in the few-problem form) smallest keys; the group is then committed in query order, wave after wave,
 // in vectorised rounds (see k_window_search).  Claims only ever remove candidates, so a query's exact best / second are
 // the first two still-admissible entries of its list; only a list that runs dry makes the wave rescan that one window
 // (8 columns x 8 lanes, two DPP min-reductions).  Nothing on the in-order path touches global memory.
@@ -320,11 +320,11 @@ __device__ __forceinline__ bool accept_rule(const orbs_params& prm, int bestDist
 
 // Per group of 256 queries (one per thread, four waves):
 //  (1) speculative, parallel: every lane scans its own query's window against the claim state as of the group start and
-//      keeps its FOUR smallest keys with the train index / octave of each.
+//      keeps its NK (four / six) smallest keys with the train index / octave of each.
 //  (2) commit, wave after wave, in query order.  A claim can only REMOVE candidates (claims are never released during the
 //      scan; SearchForInitialization's matched distance only decreases), so at any moment a query's exact best / second are
 //      the first two STILL-ADMISSIBLE entries of its list — as long as two survive or the list was never full.  A commit
-//      round therefore refreshes every lane's 4-bit alive mask from the state array, lets every accepting lane post its
+//      round therefore refreshes every lane's alive mask (one bit per key) from the state array, lets every accepting lane post its
 //      claim (LDS atomicMax of stamp | lane: the earliest lane wins), and finalises ALL lanes up to the first one that an
 //      earlier lane of the same round would affect (its best or second was just claimed) or whose list ran dry.  Affected
 //      lanes simply go again next round under the refreshed state; a dry lane has the whole wave rescan its window.
@@ -334,8 +334,21 @@ __device__ __forceinline__ bool accept_rule(const orbs_params& prm, int bestDist
 // hide its LDS round trips behind; sixteen waves scan a 1000-query frame in one pass.  Results do not depend on it (speculation + in-order commit).
 constexpr int GROUP_BATCH = 256, GROUP_WIDE = 1024;
 
+// NK = keys a query keeps from its speculative scan.  A list that runs dry (fewer than two of its entries still admissible) makes the committing wave
+// rescan that query's window, alone, while the other waves wait: with four keys the 1000 x 1000, r = 100 problems of the one-problem calls paid 27-44
+// rescans and 59-98 commit rounds (121-260 us of a 176-373 us kernel); with six, 4-24 and 31-49 (WindowSearch 176 -> 98 us, SearchForInitialization
+// 373 -> 213, SearchByProjection(last frame) 212 -> 103; eight: no further gain but for the initialisation search).  The batched form (512 problems, r = 15:
+// short windows, few claims per window) has nothing to gain and pays the longer insertion (0.097 -> 0.100 ms): it keeps four.
+#ifndef ORBS_LIST_KEYS_WIDE
+#define ORBS_LIST_KEYS_WIDE 6
+#endif
+#ifndef ORBS_LIST_KEYS_BATCH
+#define ORBS_LIST_KEYS_BATCH 4
+#endif
 template <bool BK, int GROUP>
 __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_params prm, Args a) {
+    constexpr int NK = GROUP == GROUP_WIDE ? ORBS_LIST_KEYS_WIDE : ORBS_LIST_KEYS_BATCH;
+    static_assert(NK >= 2 && NK <= 15, "alive / on_line are bit masks; TRIANGULATION keeps bit 15 of a key for the line test");
     extern __shared__ __align__(16) uint8_t lds[];
     const Layout L = make_layout(a.cap, a.qcap, a.desc_in_lds != 0, BK);
     uint16_t* off16 = (uint16_t*)(lds + L.off16);
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
             qd0 = d[0];
             qd1 = d[1];
         }
-        // ---- (1) speculative scan of the lane's own query: four smallest keys e0 <= e1 <= e2 <= e3
+        // ---- (1) speculative scan of the lane's own query: the NK smallest keys e[0] <= e[1] <= ...
         int wx0 = 0, wx1 = -1, wy0 = 0, wy1 = 0;
         const EpiLine E = epi_line(qx, qy, F, prm.th);
         if (list_mode) {
@@ -483,14 +496,17 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
             if (qi < nq && qv) { wy0 = min(max(a.qrange[(qb + qi) * 2], 0), m); wy1 = min(max(a.qrange[(qb + qi) * 2 + 1], wy0), m); wx1 = 0; }
         } else if (qv && !orbf::window_cells(b, qx, qy, qr, &wx0, &wx1, &wy0, &wy1)) { wx0 = 0; wx1 = -1; }
         if (!qv) wx1 = -1;
-        uint32_t e0 = KEY_NONE, e1 = KEY_NONE, e2 = KEY_NONE, e3 = KEY_NONE;
+        uint32_t e[NK];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) e[i] = KEY_NONE;
         bool any = false;
-        auto take = [&](uint32_t t) {                    // insertion into the four smallest keys
-            uint32_t lo;
-            lo = min(e0, t); t = max(e0, t); e0 = lo;
-            lo = min(e1, t); t = max(e1, t); e1 = lo;
-            lo = min(e2, t); t = max(e2, t); e2 = lo;
-            e3 = min(e3, t);
+#ifdef ORBS_PROBE_NO_SCAN                                 // (timing probe, never in the product: results are wrong) no speculative scan
+        wx1 = -1;
+#endif
+        auto take = [&](uint32_t t) {                    // insertion into the NK smallest keys
+#pragma unroll
+            for (int i = 0; i < NK - 1; ++i) { const uint32_t lo = min(e[i], t); t = max(e[i], t); e[i] = lo; }
+            e[NK - 1] = min(e[NK - 1], t);
         };
         if (BK) {
             int lb0, lb1;
@@ -519,46 +535,49 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
         }
         // train index | octave << 16 of the four entries
         auto slot_of = [&](uint32_t key) -> uint32_t { return BK ? (uint32_t)r2s[key & 0xFFFFu] : (key & pos_mask); };   // the staged entry a key names
-        const uint32_t f0 = e0 != KEY_NONE ? tmeta[slot_of(e0)] : 0u, f1 = e1 != KEY_NONE ? tmeta[slot_of(e1)] : 0u;
-        const uint32_t f2 = e2 != KEY_NONE ? tmeta[slot_of(e2)] : 0u, f3 = e3 != KEY_NONE ? tmeta[slot_of(e3)] : 0u;
-        const uint32_t on_line = tri ? ((e0 >> 15) & 1u) | ((e1 >> 14) & 2u) | ((e2 >> 13) & 4u) | ((e3 >> 12) & 8u) : 0u;
-        const bool full = e3 != KEY_NONE;              // a fifth candidate may exist
+        uint32_t f[NK], on_line = 0u;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            f[i] = e[i] != KEY_NONE ? tmeta[slot_of(e[i])] : 0u;
+            if (tri) on_line |= ((e[i] >> 15) & 1u) << i;
+        }
+        const bool full = e[NK - 1] != KEY_NONE;       // one more candidate may exist
         int my_best = -1, my_second = -1;
         __syncthreads();
 
         // ---- (2) commit: wave after wave, rounds inside a wave
+#ifdef ORBS_PROBE_NO_COMMIT                               // (timing probe, never in the product: results are wrong) no in-order commit
+        { uint32_t x = 0; for (int i = 0; i < NK; ++i) x ^= e[i] ^ f[i]; if (x == 0xDEADBEEFu) hist[30] = 1; }      // keeps the scan alive
+        any = false;
+#endif
         for (int w = 0; w < GROUP / 64; ++w) {
             if (wave == w) {
                 int cursor = 0;
                 for (int round = 0;; ++round) {
                     // alive = entries still admissible under the current claim state
                     uint32_t alive = 0;
-                    if (rule == ORBS_RULE_INIT) {
-                        if (e0 != KEY_NONE && state[f0 & 0xFFFFu] > (e0 >> 16)) alive |= 1u;
-                        if (e1 != KEY_NONE && state[f1 & 0xFFFFu] > (e1 >> 16)) alive |= 2u;
-                        if (e2 != KEY_NONE && state[f2 & 0xFFFFu] > (e2 >> 16)) alive |= 4u;
-                        if (e3 != KEY_NONE && state[f3 & 0xFFFFu] > (e3 >> 16)) alive |= 8u;
-                    } else {
-                        if (e0 != KEY_NONE && state[f0 & 0xFFFFu] == 0) alive |= 1u;
-                        if (e1 != KEY_NONE && state[f1 & 0xFFFFu] == 0) alive |= 2u;
-                        if (e2 != KEY_NONE && state[f2 & 0xFFFFu] == 0) alive |= 4u;
-                        if (e3 != KEY_NONE && state[f3 & 0xFFFFu] == 0) alive |= 8u;
+#pragma unroll
+                    for (int i = 0; i < NK; ++i) {
+                        const uint32_t st = state[f[i] & 0xFFFFu];
+                        if (e[i] != KEY_NONE && (rule == ORBS_RULE_INIT ? st > (e[i] >> 16) : st == 0)) alive |= 1u << i;
                     }
                     // current best / second = first two alive entries
                     // (TRIANGULATION: "second" = the first alive entry ON the epipolar line — possibly the best itself)
-                    const int ib = alive ? (__ffs((int)alive) - 1) : 4;
-                    const uint32_t rest = tri ? (alive & on_line) : (alive & ~(1u << (ib & 3)));
-                    const int is = rest ? (__ffs((int)rest) - 1) : 4;
-                    const uint32_t kb = ib == 0 ? e0 : ib == 1 ? e1 : ib == 2 ? e2 : ib == 3 ? e3 : KEY_NONE;
-                    const uint32_t mb = ib == 0 ? f0 : ib == 1 ? f1 : ib == 2 ? f2 : f3;
-                    const uint32_t ks = is == 0 ? e0 : is == 1 ? e1 : is == 2 ? e2 : is == 3 ? e3 : KEY_NONE;
-                    const uint32_t ms = is == 0 ? f0 : is == 1 ? f1 : is == 2 ? f2 : f3;
+                    const int ib = alive ? (__ffs((int)alive) - 1) : NK;
+                    const uint32_t rest = tri ? (alive & on_line) : (alive & (alive - 1u));      // (without its lowest set bit)
+                    const int is = rest ? (__ffs((int)rest) - 1) : NK;
+                    uint32_t kb = KEY_NONE, mb = 0u, ks = KEY_NONE, ms = 0u;
+#pragma unroll
+                    for (int i = 0; i < NK; ++i) {
+                        if (ib == i) { kb = e[i]; mb = f[i]; }
+                        if (is == i) { ks = e[i]; ms = f[i]; }
+                    }
                     const int vBest = kb != KEY_NONE ? (int)(kb >> 16) : INT_MAX, vBest2 = ks != KEY_NONE ? (int)(ks >> 16) : INT_MAX;
                     const int vLev = kb != KEY_NONE ? (int)(mb >> 16) : -1, vLev2 = ks != KEY_NONE ? (int)(ms >> 16) : -1;
                     const bool active = any && lane >= cursor;
                     // list exhausted: the exact answer needs a rescan.  TRIANGULATION: no alive on-line entry left, and a fifth
-                    // candidate could still lie within DistTh (it has distance >= e3's)
-                    const bool dry = tri ? (full && is == 4 && (ib == 4 || (int)(e3 >> 16) <= 2 * vBest)) : (full && __popc(alive) < 2);
+                    // candidate could still lie within DistTh (it has distance >= the last entry's)
+                    const bool dry = tri ? (full && is == NK && (ib == NK || (int)(e[NK - 1] >> 16) <= 2 * vBest)) : (full && __popc(alive) < 2);
                     const bool vAccept = !dry && accept_rule(prm, vBest, vBest2, vLev, vLev2);
                     // accepting lanes post their claim; the earliest lane of this round wins the slot
                     const uint32_t stamp = (uint32_t)((group * (GROUP / 64) + w) * 128 + round + 1);
@@ -592,6 +611,9 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
                         }
                     }
                     cursor = F;
+#ifdef ORBS_PROBE_ROUNDS                                  // (counting probe, never in the product) nmatches = rounds + 1000 * rescans
+                    if (lane == 0) hist[30] += 1 + (F < 64 && __builtin_amdgcn_readlane((int)dry, F) ? 1000 : 0);
+#endif
                     if (F >= 64) break;
                     if (__builtin_amdgcn_readlane((int)dry, F)) {
                         // the whole wave rescans query F under the current state
@@ -661,7 +683,11 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
     __syncthreads();
     if (lane == 0) atomicAdd(&hist[31], cnt);           // hist[31] is never a rotation bin (HISTO_LENGTH = 30): zero since the start
     __syncthreads();
+#ifdef ORBS_PROBE_ROUNDS
+    if (tid == 0) a.nmatches[p] = hist[30];
+#else
     if (tid == 0) a.nmatches[p] = hist[31];
+#endif
 }
 
 

@@ -36,6 +36,8 @@ class Timed(drop.Both):
                     ret = f(*args)
                     ts.append((time.perf_counter() - t0) * 1e3)
                 best[key] = min(ts)
+            if os.environ.get("DROPIN_PRINT_RETURNS"):
+                print(f"  {name}: returns {ret}")
             self.rows.setdefault(name, []).append(best)
             return ret
         return call
