@@ -27,6 +27,7 @@
 #include <deque>
 
 #include "ORBmatcher.h"
+#include <chrono>
 
 using namespace ORB_SLAM;
 
@@ -116,6 +117,14 @@ cv::Mat pose_44(float scale) {                 // [scale*R | scale*t; 0 0 0 1]
 float Frame::fx = 0, Frame::fy = 0, Frame::cx = 0, Frame::cy = 0;
 int Frame::mnMinX = 0, Frame::mnMaxX = 0, Frame::mnMinY = 0, Frame::mnMaxY = 0;
 
+// the duration of the LAST ORBmatcher method call made through this library, without the harness around it (tools/bench_orbmatcher_dropin.py)
+static thread_local double g_last_call_ms = 0.0;
+struct CallTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~CallTimer() { g_last_call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+#define TIMED(call) ([&] { CallTimer timer_; return (call); }())
+
 extern "C" {
 
 void ref_set_pose(const float* Rt, float scale) {
@@ -176,7 +185,7 @@ int ref_search_by_projection_mappoints(const void* bounds, float ratio, float th
         q[i] = &m;
     }
     ORBmatcher matcher(ratio, true);
-    const int n = matcher.SearchByProjection(F, q, th);
+    const int n = TIMED(matcher.SearchByProjection(F, q, th));
     for (int i = 0; i < nt; i++) t2q[i] = F.mvpMapPoints[i] == &old ? -2 : index_of(q, F.mvpMapPoints[i]);
     return n;
 }
@@ -194,7 +203,7 @@ int ref_window_search(const void* bounds, float ratio, int check, const void* kp
     F1.mvpMapPoints = map_points(pool, state1, n1);
     std::vector<MapPoint*> m2;
     ORBmatcher matcher(ratio, check != 0);
-    const int n = matcher.WindowSearch(F1, F2, windowSize, m2, minLevel, maxLevel);
+    const int n = TIMED(matcher.WindowSearch(F1, F2, windowSize, m2, minLevel, maxLevel));
     for (int i = 0; i < n2; i++) t2q[i] = index_of(F1.mvpMapPoints, m2[i]);
     return n;
 }
@@ -211,7 +220,7 @@ int ref_search_for_initialization(const void* bounds, float ratio, int check, co
     for (int i = 0; i < n1; i++) pm[i] = cv::Point2f(prev[2 * i], prev[2 * i + 1]);
     std::vector<int> m12;
     ORBmatcher matcher(ratio, check != 0);
-    const int n = matcher.SearchForInitialization(F1, F2, pm, m12, windowSize);
+    const int n = TIMED(matcher.SearchForInitialization(F1, F2, pm, m12, windowSize));
     for (int i = 0; i < n1; i++) { q2t[i] = m12[i]; prev[2 * i] = pm[i].x; prev[2 * i + 1] = pm[i].y; }
     return n;
 }
@@ -249,7 +258,7 @@ int ref_search_by_projection_last_frame(const void* bounds, float ratio, int che
         }
     }
     ORBmatcher matcher(ratio, check != 0);
-    const int n = matcher.SearchByProjection(C, L, th);
+    const int n = TIMED(matcher.SearchByProjection(C, L, th));
     for (int i = 0; i < n2; i++) t2q[i] = C.mvpMapPoints[i] == &old ? -2 : index_of(L.mvpMapPoints, C.mvpMapPoints[i]);
     return n;
 }
@@ -277,7 +286,7 @@ int ref_search_by_projection_two_frames(const void* bounds, float ratio, const f
     }
     std::vector<MapPoint*> m2;
     ORBmatcher matcher(ratio, true);
-    const int n = matcher.SearchByProjection(F1, F2, windowSize, m2);
+    const int n = TIMED(matcher.SearchByProjection(F1, F2, windowSize, m2));
     for (int i = 0; i < n2; i++) t2q[i] = m2[i] == &old ? -2 : index_of(F1.mvpMapPoints, m2[i]);
     return n;
 }
@@ -316,7 +325,7 @@ int ref_search_by_projection_keyframe(const void* bounds, int check, float th, i
         if (kf_state[i] == 3) found.insert(&m);
     }
     ORBmatcher matcher(0.75f, check != 0);
-    const int n = matcher.SearchByProjection(C, &kf, found, th, orbdist);
+    const int n = TIMED(matcher.SearchByProjection(C, &kf, found, th, orbdist));
     for (int i = 0; i < n2; i++) t2q[i] = C.mvpMapPoints[i] == &old ? -2 : index_of(kf.mapPoints, C.mvpMapPoints[i]);
     return n;
 }
@@ -341,7 +350,7 @@ int ref_search_by_bow(float ratio, int check, const uint32_t* kf_node, const int
     F.mvpMapPoints.assign(nF, (MapPoint*)0);
     std::vector<MapPoint*> out;
     ORBmatcher matcher(ratio, check != 0);
-    const int n = matcher.SearchByBoW(&kf, F, out);
+    const int n = TIMED(matcher.SearchByBoW(&kf, F, out));
     for (int i = 0; i < nF; i++) t2q[i] = index_of(kf.mapPoints, out[i]);
     return n;
 }
@@ -360,7 +369,7 @@ int ref_search_by_bow_kf(float ratio, int check, const uint32_t* node1, const in
     k2.mapPoints = map_points(pool, state2, n2);
     std::vector<MapPoint*> out;
     ORBmatcher matcher(ratio, check != 0);
-    const int n = matcher.SearchByBoW(&k1, &k2, out);
+    const int n = TIMED(matcher.SearchByBoW(&k1, &k2, out));
     for (int i = 0; i < n1; i++) q2t[i] = index_of(k2.mapPoints, out[i]);
     return n;
 }
@@ -382,7 +391,7 @@ int ref_search_for_triangulation(float ratio, int check, const float* F12, const
     std::vector<cv::KeyPoint> mk1, mk2;
     std::vector<std::pair<size_t, size_t> > pairs;
     ORBmatcher matcher(ratio, check != 0);
-    const int n = matcher.SearchForTriangulation(&k1, &k2, F, mk1, mk2, pairs);
+    const int n = TIMED(matcher.SearchForTriangulation(&k1, &k2, F, mk1, mk2, pairs));
     for (int i = 0; i < n1; i++) q2t[i] = -1;
     if ((int)pairs.size() != n || mk1.size() != pairs.size() || mk2.size() != pairs.size()) return -1000;
     for (size_t j = 0; j < pairs.size(); j++) {
@@ -443,7 +452,7 @@ int ref_search_by_projection_scw(const void* bounds, int th, const float* cam, c
     std::vector<MapPoint*> before = matched;
     cv::Mat Scw = pose_44(g_scale);
     ORBmatcher matcher(0.75f, true);
-    const int n = matcher.SearchByProjection(&kf, Scw, q, matched, th);
+    const int n = TIMED(matcher.SearchByProjection(&kf, Scw, q, matched, th));
     for (int i = 0; i < nKF; i++) t2q[i] = before[i] ? -2 : index_of(q, matched[i]);
     return n;
 }
@@ -462,12 +471,12 @@ int ref_fuse(int which, const void* bounds, float th, const float* cam, const fl
     std::vector<MapPoint*> q = query_points(pool, qstate, world, mindist, qdesc, nq);
     ORBmatcher matcher(0.75f, true);
     int n;
-    if (which == 0) n = matcher.Fuse(&kf, q, th);
+    if (which == 0) n = TIMED(matcher.Fuse(&kf, q, th));
     else {
         cv::Mat Scw = pose_44(g_scale);
         std::vector<MapPoint*> q2;
         for (MapPoint* p : q) if (p) q2.push_back(p);               // this overload does not accept NULL entries
-        n = matcher.Fuse(&kf, Scw, q2, th);
+        n = TIMED(matcher.Fuse(&kf, Scw, q2, th));
     }
     *nlog = (int)kf.getMapPointLog.size();
     for (size_t i = 0; i < kf.getMapPointLog.size(); i++) log[i] = kf.getMapPointLog[i];
@@ -509,9 +518,11 @@ int ref_search_by_sim3(const void* bounds, float th, const float* cam, const flo
     std::vector<MapPoint*> m12(n1, (MapPoint*)0);
     ORBmatcher matcher(0.75f, true);
     const float s12 = g_sim_scale;
-    const int n = matcher.SearchBySim3(&k1, &k2, m12, s12, R12, t12, th);
+    const int n = TIMED(matcher.SearchBySim3(&k1, &k2, m12, s12, R12, t12, th));
     for (int i = 0; i < n1; i++) match12[i] = index_of(k2.mapPoints, m12[i]);
     return n;
 }
+
+double ref_last_call_ms() { return g_last_call_ms; }
 
 }  // extern "C"
