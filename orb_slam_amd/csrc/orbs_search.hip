@@ -10,7 +10,7 @@
 //     (cells x-major, then y, then push_back order), so the two smallest keys are exactly the best / second-best the
 //     reference's `if(d<best)... else if(d<best2)` scan ends with, first-listed candidate on ties.
 // Queries go 256 at a time, one per thread (four waves): every lane scans its own window SPECULATIVELY against the claim
-// state of the group start and keeps its four (six in the few-problem form) smallest keys; the group is then committed in query order, wave after wave,
+// state of the group start and keeps its six smallest keys; the group is then committed in query order, wave after wave,
 // in vectorised rounds (see k_window_search).  Claims only ever remove candidates, so a query's exact best / second are
 // the first two still-admissible entries of its list; only a list that runs dry makes the wave rescan that one window
 // (8 columns x 8 lanes, two DPP min-reductions).  Nothing on the in-order path touches global memory.
@@ -320,7 +320,7 @@ __device__ __forceinline__ bool accept_rule(const orbs_params& prm, int bestDist
 
 // Per group of 256 queries (one per thread, four waves):
 //  (1) speculative, parallel: every lane scans its own query's window against the claim state as of the group start and
-//      keeps its NK (four / six) smallest keys with the train index / octave of each.
+//      keeps its NK (six) smallest keys with the train index / octave of each.
 //  (2) commit, wave after wave, in query order.  A claim can only REMOVE candidates (claims are never released during the
 //      scan; SearchForInitialization's matched distance only decreases), so at any moment a query's exact best / second are
 //      the first two STILL-ADMISSIBLE entries of its list — as long as two survive or the list was never full.  A commit
@@ -337,13 +337,14 @@ constexpr int GROUP_BATCH = 256, GROUP_WIDE = 1024;
 // NK = keys a query keeps from its speculative scan.  A list that runs dry (fewer than two of its entries still admissible) makes the committing wave
 // rescan that query's window, alone, while the other waves wait: with four keys the 1000 x 1000, r = 100 problems of the one-problem calls paid 27-44
 // rescans and 59-98 commit rounds (121-260 us of a 176-373 us kernel); with six, 4-24 and 31-49 (WindowSearch 176 -> 98 us, SearchForInitialization
-// 373 -> 213, SearchByProjection(last frame) 212 -> 103; eight: no further gain but for the initialisation search).  The batched form (512 problems, r = 15:
-// short windows, few claims per window) has nothing to gain and pays the longer insertion (0.097 -> 0.100 ms): it keeps four.
+// 373 -> 213, SearchByProjection(last frame) 212 -> 103; eight: no further gain but for the initialisation search).  The batched form (512 problems) pays the longer
+// insertion where windows hold few real candidates (independent S-blocks frames, r = 15: 0.478 -> 0.497 ms per 512 frames) and gains where they hold many:
+// r = 100 1.457 -> 1.345 ms, the correlated S-warp stream 1.105 -> 1.055 (r = 15) and 2.21 -> 1.70 (r = 40) - a camera's case: six there as well.
 #ifndef ORBS_LIST_KEYS_WIDE
 #define ORBS_LIST_KEYS_WIDE 6
 #endif
 #ifndef ORBS_LIST_KEYS_BATCH
-#define ORBS_LIST_KEYS_BATCH 4
+#define ORBS_LIST_KEYS_BATCH 6
 #endif
 template <bool BK, int GROUP>
 __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_params prm, Args a) {
@@ -586,6 +587,8 @@ __global__ __launch_bounds__(GROUP) void k_window_search(orbf_bounds b, orbs_par
                     if (claims && active && vAccept) atomicMax(&claim_by[cIdx], (stamp << 6) | (uint32_t)(63 - lane));
                     bool affected = false;
                     if (claims && active && kb != KEY_NONE) { const uint32_t c = claim_by[bIdx]; affected |= (c >> 6) == stamp && (int)(63u - (c & 63u)) < lane; }
+                    // (measured and dropped, NOTES 11.6: letting an ACCEPTING query keep going when only its second was taken — WINDOW / BOW / INIT accept
+                    //  monotonically in the second — saved 3-7 rounds of 28-49 and no measurable time)
                     if (claims && active && ks != KEY_NONE) { const uint32_t c = claim_by[sIdx]; affected |= (c >> 6) == stamp && (int)(63u - (c & 63u)) < lane; }
                     const unsigned long long stop = __ballot(active && (affected || dry));
                     const int F = stop ? (__ffsll((long long)stop) - 1) : 64;

@@ -85,7 +85,13 @@ def run_bow_kf(S, cap, th_low, ratio, check):
                                   S["nlist"].data_ptr(), S["B"]["n"].data_ptr(), cap, dC2.data_ptr(), S["qrange"].data_ptr(), S["A"]["feat"].data_ptr(),
                                   S["A"]["D"].data_ptr(), dA1.data_ptr(), dV1.data_ptr(), S["nq"].data_ptr(), cap, P, q2t.data_ptr(), t2q.data_ptr(),
                                   best.data_ptr(), second.data_ptr(), nm.data_ptr(), st)
+    q2t_n, t2q_n, _, _, nm_n = outputs(torch, P, cap)                                # ... and without the distance outputs: the same matches
+    capi.list_search_batch_device(capi.RULE_BOW, th_low - 1, ratio, check, S["dK2"].data_ptr(), S["B"]["D"].data_ptr(), S["B"]["feat"].data_ptr(),
+                                  S["nlist"].data_ptr(), S["B"]["n"].data_ptr(), cap, dC2.data_ptr(), S["qrange"].data_ptr(), S["A"]["feat"].data_ptr(),
+                                  S["A"]["D"].data_ptr(), dA1.data_ptr(), dV1.data_ptr(), S["nq"].data_ptr(), cap, P, q2t_n.data_ptr(), t2q_n.data_ptr(),
+                                  0, 0, nm_n.data_ptr(), st)
     torch.cuda.synchronize()
+    assert torch.equal(nm, nm_n) and torch.equal(q2t, q2t_n) and torch.equal(t2q, t2q_n), "results depend on whether best / second are asked for"
     return tuple(x.cpu().numpy() for x in (q2t, t2q, nm, S["nq"])) + (V1, V2)
 
 

@@ -105,7 +105,15 @@ def _run_batch(problems, rule, th, ratio, check, use_claimed, use_valid, cap, qc
                                     dC.data_ptr() if use_claimed else 0, dQX.data_ptr(), dQL.data_ptr(), dQD.data_ptr(), dQA.data_ptr(),
                                     dQV.data_ptr() if use_valid else 0, dnq.data_ptr(), qcap, P, q2t.data_ptr(), t2q.data_ptr(), best.data_ptr(),
                                     second.data_ptr(), nm.data_ptr(), st)
+    # the same launch WITHOUT the two distance outputs (what ORB_SLAM::ORBmatcher asks for): matches and counts must not depend on
+    # which outputs are asked for
+    q2t_n = torch.full((P, qcap), -9, dtype=torch.int32, device="cuda"); t2q_n = torch.full((P, cap), -9, dtype=torch.int32, device="cuda")
+    nm_n = torch.full((P,), -9, dtype=torch.int32, device="cuda")
+    capi.window_search_batch_device(b, rule, th, ratio, check, dUn.data_ptr(), dD.data_ptr(), dOff.data_ptr(), dFeat.data_ptr(), dnt.data_ptr(), cap,
+                                    dC.data_ptr() if use_claimed else 0, dQX.data_ptr(), dQL.data_ptr(), dQD.data_ptr(), dQA.data_ptr(),
+                                    dQV.data_ptr() if use_valid else 0, dnq.data_ptr(), qcap, P, q2t_n.data_ptr(), t2q_n.data_ptr(), 0, 0, nm_n.data_ptr(), st)
     torch.cuda.synchronize()
+    assert torch.equal(nm, nm_n) and torch.equal(q2t, q2t_n) and torch.equal(t2q, t2q_n), "results depend on whether best / second are asked for"
     un = dUn.cpu().numpy().reshape(P, cap * 28).view(capi.KP_DTYPE).reshape(P, cap)
     off, feat = dOff.cpu().numpy(), dFeat.cpu().numpy()
     q2t, t2q, best, second, nm = (t.cpu().numpy() for t in (q2t, t2q, best, second, nm))
@@ -246,7 +254,12 @@ def test_search_by_bow_pipeline(check):
     capi.list_search_batch_device(capi.RULE_BOW, capi.TH_LOW, 0.75, check, dFK.data_ptr(), F["D"].data_ptr(), F["feat"].data_ptr(), nlist.data_ptr(),
                                   F["n"].data_ptr(), cap, 0, qrange.data_ptr(), K["feat"].data_ptr(), K["D"].data_ptr(), dKA.data_ptr(), dKV.data_ptr(),
                                   nq.data_ptr(), cap, P, q2t.data_ptr(), t2q.data_ptr(), best.data_ptr(), second.data_ptr(), nm.data_ptr(), st)
+    q2t_n = torch.full((P, cap), -9, dtype=i32, device="cuda"); t2q_n = torch.full((P, cap), -9, dtype=i32, device="cuda"); nm_n = torch.zeros(P, dtype=i32, device="cuda")
+    capi.list_search_batch_device(capi.RULE_BOW, capi.TH_LOW, 0.75, check, dFK.data_ptr(), F["D"].data_ptr(), F["feat"].data_ptr(), nlist.data_ptr(),
+                                  F["n"].data_ptr(), cap, 0, qrange.data_ptr(), K["feat"].data_ptr(), K["D"].data_ptr(), dKA.data_ptr(), dKV.data_ptr(),
+                                  nq.data_ptr(), cap, P, q2t_n.data_ptr(), t2q_n.data_ptr(), 0, 0, nm_n.data_ptr(), st)      # without the distance outputs
     torch.cuda.synchronize()
+    assert torch.equal(nm, nm_n) and torch.equal(q2t, q2t_n) and torch.equal(t2q, t2q_n), "results depend on whether best / second are asked for"
     k_node, k_off, k_feat, k_cnt = (K[x].cpu().numpy() for x in ("node", "off", "feat", "cnt"))
     f_node, f_feat = F["node"].cpu().numpy(), F["feat"].cpu().numpy()
     q2t, t2q, best, second, nm, nqh = (x.cpu().numpy() for x in (q2t, t2q, best, second, nm, nq))

@@ -125,7 +125,14 @@ for c in range(cases):
         capi.window_search_batch_device(b, rule, th, ratio, check, dUn.data_ptr(), dD.data_ptr(), dOff.data_ptr(), dFeat.data_ptr(), dnt.data_ptr(), cap,
                                         dC.data_ptr() if rule == 0 else 0, dQX.data_ptr(), dQL.data_ptr(), dQD.data_ptr(), dQA.data_ptr(), dQV.data_ptr(), dnq.data_ptr(), cap, 1,
                                         o_q2t.data_ptr(), o_t2q.data_ptr(), o_b.data_ptr(), o_s.data_ptr(), o_n.data_ptr(), st)
+        # the same without the distance outputs: matches and count must not differ
+        n_q2t = torch.zeros(cap, dtype=torch.int32, device="cuda"); n_t2q = torch.zeros(cap, dtype=torch.int32, device="cuda"); n_n = torch.zeros(1, dtype=torch.int32, device="cuda")
+        capi.window_search_batch_device(b, rule, th, ratio, check, dUn.data_ptr(), dD.data_ptr(), dOff.data_ptr(), dFeat.data_ptr(), dnt.data_ptr(), cap,
+                                        dC.data_ptr() if rule == 0 else 0, dQX.data_ptr(), dQL.data_ptr(), dQD.data_ptr(), dQA.data_ptr(), dQV.data_ptr(), dnq.data_ptr(), cap, 1,
+                                        n_q2t.data_ptr(), n_t2q.data_ptr(), 0, 0, n_n.data_ptr(), st)
         torch.cuda.synchronize()
+        if not (torch.equal(o_n, n_n) and torch.equal(o_q2t[:nq], n_q2t[:nq]) and torch.equal(o_t2q[:nt], n_t2q[:nt])):
+            bad.append(("search without distance outputs", c, rule, th, ratio, check, nt, nq, float(rad)))
         wnt = ol.window_search(b, rule, th, ratio, check, wun, desc, woff, wfeat, claimed if rule == 0 else None, qxyr, qlev, qdesc, qangle, qvalid)
         got = (int(o_n.item()), o_q2t.cpu().numpy()[:nq], o_t2q.cpu().numpy()[:nt], o_b.cpu().numpy()[:nq], o_s.cpu().numpy()[:nq])
         if got[0] != wnt[0] or any(not np.array_equal(x, y) for x, y in zip(got[1:], wnt[1:])):
