@@ -107,6 +107,27 @@ struct GridView {
     }
 };
 
+#ifdef ORBM_STUB_REAL_SHAPES
+// (oracle/_ref/libprod_orbmatcher_realaccess.so) the members ORB_SLAM's real Frame / KeyFrame offer and the product's orb_slam_amd/cpp/ORBmatcherAccess.h
+// reads - `F.mGrid[x][y]` as vectors of feature indices, the inverse cell sizes - served from the flattened GridView, so that the access header written
+// for the REAL classes is the one compiled and executed (the harness keeps filling `grid` only).
+struct GridCells {                                   // stands for `std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS]` (include/Frame.h:90)
+    const GridView* g;
+    struct Column {
+        const GridView* g; int x;
+        std::vector<std::size_t> operator[](int y) const {
+            const int c = x * FRAME_GRID_ROWS + y;
+            return std::vector<std::size_t>(g->cell_feat.begin() + g->cell_off[c], g->cell_feat.begin() + g->cell_off[c + 1]);
+        }
+    };
+    Column operator[](int x) const { return Column{g, x}; }
+};
+struct GridInv {                                     // stands for `float mfGridElementWidthInv` / `...HeightInv` (include/KeyFrame.h:148-149)
+    const GridView* g; bool width;
+    operator float() const { return width ? g->bounds.inv_w : g->bounds.inv_h; }
+};
+#endif
+
 #ifdef ORB_ORACLE_REAL_FRAME
 // what src/Frame.cc calls on its collaborators: an "extractor" that hands out preset key points (unless the product's extractor is
 // under test), a vocabulary and a converter that are never used
@@ -150,6 +171,13 @@ public:
     std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel = -1, const int maxLevel = -1) const {
         return grid.query(mvKeysUn, x, y, r, minLevel, maxLevel);
     }
+#ifdef ORBM_STUB_REAL_SHAPES
+    static float mfGridElementWidthInv, mfGridElementHeightInv;      // (include/Frame.h:88-89; set by the harness's fill_grid)
+    GridCells mGrid{&grid};
+    Frame() {}
+    Frame(const Frame&) = delete;                                    // (mGrid points into this object)
+    Frame& operator=(const Frame&) = delete;
+#endif
 };
 
 #endif
@@ -191,6 +219,13 @@ public:
     cv::Mat GetCameraCenter() { return Ow.clone(); }
     bool IsInImage(const float& x, const float& y) const { return x >= minX && x < maxX && y >= minY && y < maxY; }
     std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r) const { return grid.query(keysUn, x, y, r, -1, -1); }
+#ifdef ORBM_STUB_REAL_SHAPES
+    GridInv mfGridElementWidthInv{&grid, true}, mfGridElementHeightInv{&grid, false};
+    std::vector<float> GetVectorScaleSigma2() const { return levelSigma2; }      // (include/KeyFrame.h:126)
+    KeyFrame() {}
+    KeyFrame(const KeyFrame&) = delete;
+    KeyFrame& operator=(const KeyFrame&) = delete;
+#endif
 };
 
 }  // namespace ORB_SLAM

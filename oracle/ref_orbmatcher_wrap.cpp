@@ -55,6 +55,11 @@ std::vector<cv::KeyPoint> kp_vec(const void* kps, int n) {
 }
 void fill_grid(GridView& g, const void* bounds, const int32_t* cell_off, const int32_t* cell_feat, int n) {
     memcpy(&g.bounds, bounds, sizeof(g.bounds));
+#ifdef ORBM_STUB_REAL_SHAPES
+    // the camera's statics ORB_SLAM's Frame::Frame computes once (src/Frame.cc:88-101): ORBmatcherAccess.h reads the bounds from there
+    Frame::mnMinX = g.bounds.min_x; Frame::mnMaxX = g.bounds.max_x; Frame::mnMinY = g.bounds.min_y; Frame::mnMaxY = g.bounds.max_y;
+    Frame::mfGridElementWidthInv = g.bounds.inv_w; Frame::mfGridElementHeightInv = g.bounds.inv_h;
+#endif
     g.cell_off.assign(cell_off, cell_off + FRAME_GRID_COLS * FRAME_GRID_ROWS + 1);
     (void)n;
     g.cell_feat.assign(cell_feat, cell_feat + g.cell_off.back());      // only the features inside the image bounds are in the grid
@@ -116,6 +121,9 @@ cv::Mat pose_44(float scale) {                 // [scale*R | scale*t; 0 0 0 1]
 
 float Frame::fx = 0, Frame::fy = 0, Frame::cx = 0, Frame::cy = 0;
 int Frame::mnMinX = 0, Frame::mnMaxX = 0, Frame::mnMinY = 0, Frame::mnMaxY = 0;
+#ifdef ORBM_STUB_REAL_SHAPES
+float Frame::mfGridElementWidthInv = 0, Frame::mfGridElementHeightInv = 0;
+#endif
 
 // the duration of the LAST ORBmatcher method call made through this library, without the harness around it (tools/bench_orbmatcher_dropin.py)
 static thread_local double g_last_call_ms = 0.0;

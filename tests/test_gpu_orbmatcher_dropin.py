@@ -20,6 +20,10 @@ import test_ref_pin_matcher as trm
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libref_orbmatcher.so")
 PROD_PATH = os.path.join(ROOT, "oracle", "_ref", "libprod_orbmatcher.so")
+# the same product sources with orb_slam_amd/cpp/ORBmatcherAccess.h (the access header for ORB_SLAM's REAL Frame / KeyFrame: flattens Frame::mGrid, rebuilds a
+# KeyFrame's grid from its key points by the PosInGrid rule) instead of oracle/matcherstub/access.h; the stand-ins serve the real classes' member shapes there
+PROD_REAL_ACCESS_PATH = os.path.join(ROOT, "oracle", "_ref", "libprod_orbmatcher_realaccess.so")
+PROD_PATHS = {"stand-in access header": PROD_PATH, "ORBmatcherAccess.h": PROD_REAL_ACCESS_PATH}
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not (os.path.exists(REF_PATH) and os.path.exists(PROD_PATH)), reason="oracle/_ref/lib{ref,prod}_orbmatcher.so are built where /root/reference exists")]
 
@@ -31,8 +35,8 @@ class DropInMismatch(Exception):
 class Both:
     """ref_* calls to the reference's ORBmatcher.cc (on copies) and to the product's; results compared; the product's are what the caller sees"""
 
-    def __init__(self):
-        self.ref, self.prod = trm.load(REF_PATH), trm.load(PROD_PATH)
+    def __init__(self, prod_path=PROD_PATH):
+        self.ref, self.prod = trm.load(REF_PATH), trm.load(prod_path)
         self.arrays = {}
         self.calls = []          # (name, return value)
 
@@ -70,11 +74,13 @@ class Both:
         return call
 
 
-@pytest.fixture()
-def both(monkeypatch):
+@pytest.fixture(params=list(PROD_PATHS))
+def both(monkeypatch, request):
     import torch
     assert torch.cuda.is_available()
-    b = Both()
+    if not os.path.exists(PROD_PATHS[request.param]):
+        pytest.skip(PROD_PATHS[request.param] + " is built where /root/reference exists")
+    b = Both(PROD_PATHS[request.param])
     monkeypatch.setattr(trm, "ref", lambda: b)
     monkeypatch.setattr(trm, "P", b.P)
     yield b

@@ -7,7 +7,8 @@ orientation check, crowded and sparse frames) at a random camera pose and simila
 every array argument) and to the product second; the return value and every array the call could have written must be equal.  The reference is the only judge here (the oracle
 restatement is pinned against the same reference library by tests/test_ref_pin_matcher.py on the CPU).
 
-    python tools/fuzz_orbmatcher.py [cases] [seed]         (GPU box; test infrastructure, not product)
+    python tools/fuzz_orbmatcher.py [cases] [seed] [real]  (GPU box; test infrastructure, not product; `real`: the product library built with
+                                                            orb_slam_amd/cpp/ORBmatcherAccess.h, libprod_orbmatcher_realaccess.so)
 """
 import json
 import os
@@ -78,7 +79,8 @@ def main():
     assert torch.cuda.is_available(), "the product side runs on the GPU"
     from orb_slam_amd import capi
     rng = np.random.default_rng(seed)
-    both = drop.Both()
+    real = len(sys.argv) > 3 and sys.argv[3] == "real"
+    both = drop.Both(drop.PROD_REAL_ACCESS_PATH if real else drop.PROD_PATH)
     trm.ref = lambda: both
     trm.P = both.P
     names = sorted(CASES)
@@ -112,7 +114,7 @@ def main():
         per[name] = per.get(name, 0) + 1
         calls += len(both.calls)
         matches += sum(int(r) for c, r in both.calls if c.startswith("ref_search") or c in ("ref_window_search", "ref_fuse"))
-    out = {"cases": cases, "seed": seed, "general_pose_cases": posed, "harness_calls_compared": calls, "matches_returned": matches, "by_case": per,
+    out = {"cases": cases, "seed": seed, "access_header": "orb_slam_amd/cpp/ORBmatcherAccess.h" if real else "oracle/matcherstub/access.h", "general_pose_cases": posed, "harness_calls_compared": calls, "matches_returned": matches, "by_case": per,
            "cases_the_generator_could_not_build": len(unbuilt), "unbuilt": unbuilt[:10], "mismatches": bad, "seconds": round(time.time() - t0, 1), "build": capi.build_id() if hasattr(capi, "build_id") else None}
     print(json.dumps(out))
     sys.exit(1 if bad else 0)

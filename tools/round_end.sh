@@ -19,7 +19,7 @@ from orb_slam_amd import synth
 synth.frames(640, 480, synth.BLOCKS, 0, 2048).tofile("/tmp/frames.raw")
 PY
 (orb_slam_amd/cpp/example_lanes 640 480 1024 2 4 /tmp/frames.raw "" 200; orb_slam_amd/cpp/example_lanes 640 480 1024 2 1 /tmp/frames.raw "" 200) > gpurun_out/$N/cpp_example_lanes.txt 2>&1; grep "frames/s\|IDENT" gpurun_out/$N/cpp_example_lanes.txt
-timeout 600 python tools/fuzz_batch.py 400 5102 > gpurun_out/$N/fuzz_batch_400.json 2>/dev/null; tail -c 200 gpurun_out/$N/fuzz_batch_400.json; timeout 600 python tools/fuzz_parity.py 4000 5101 > gpurun_out/$N/fuzz_parity_4000.json 2>/dev/null; tail -c 200 gpurun_out/$N/fuzz_parity_4000.json; timeout 600 python tools/fuzz_frontend.py 3000 5104 > gpurun_out/$N/fuzz_frontend_3000.json 2>/dev/null; tail -c 200 gpurun_out/$N/fuzz_frontend_3000.json; timeout 600 python tools/fuzz_match.py 20000 5105 > gpurun_out/$N/fuzz_match_20000.json 2>/dev/null; tail -c 300 gpurun_out/$N/fuzz_match_20000.json; timeout 600 python tools/fuzz_orbmatcher.py 10000 5106 > gpurun_out/$N/fuzz_orbmatcher_10000.json 2>/dev/null; tail -c 300 gpurun_out/$N/fuzz_orbmatcher_10000.json
+timeout 600 python tools/fuzz_batch.py 400 5102 > gpurun_out/$N/fuzz_batch_400.json 2>/dev/null; tail -c 200 gpurun_out/$N/fuzz_batch_400.json; timeout 600 python tools/fuzz_parity.py 4000 5101 > gpurun_out/$N/fuzz_parity_4000.json 2>/dev/null; tail -c 200 gpurun_out/$N/fuzz_parity_4000.json; timeout 600 python tools/fuzz_frontend.py 3000 5104 > gpurun_out/$N/fuzz_frontend_3000.json 2>/dev/null; tail -c 200 gpurun_out/$N/fuzz_frontend_3000.json; timeout 600 python tools/fuzz_match.py 20000 5105 > gpurun_out/$N/fuzz_match_20000.json 2>/dev/null; tail -c 300 gpurun_out/$N/fuzz_match_20000.json; timeout 600 python tools/fuzz_orbmatcher.py 10000 5106 > gpurun_out/$N/fuzz_orbmatcher_10000.json 2>/dev/null; tail -c 300 gpurun_out/$N/fuzz_orbmatcher_10000.json; timeout 600 python tools/fuzz_orbmatcher.py 10000 5107 real > gpurun_out/$N/fuzz_orbmatcher_real_access_10000.json 2>/dev/null; tail -c 200 gpurun_out/$N/fuzz_orbmatcher_real_access_10000.json
 tools/run_pmc_match.sh ${N}mfma 2>&1 | tail -6 | cut -c1-400          # matrix-pipe counters of the matcher (FP4 kernels)
 timeout 900 python bench.py --detail-file gpurun_out/$N/bench_final.json > gpurun_out/$N/bench_final.stdout 2> gpurun_out/$N/bench_final.err || tail -5 gpurun_out/$N/bench_final.err; python -c "
 import json; d=json.load(open('gpurun_out/$N/bench_final.json')); print(d['value'], d['roofline']['frac'], d['roofline']['traffic'], d['config']['parity_mismatches'], {k:(v['value'], v['roofline'].get('frac'), v['roofline'].get('traffic'), v['config']['parity_mismatches']) for k,v in d['also'].items()})"
