@@ -18,7 +18,13 @@ PROD = os.path.join(ROOT, "oracle", "_ref", "libprod_orbmatcher.so")
 pytestmark = pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(PROD)), reason="oracle/_ref/lib{ref,prod}_orbmatcher.so are built where /root/reference exists")
 
 
-def test_product_library_links_the_c_abi_and_no_oracle():
+PROD_REAL_ACCESS = os.path.join(ROOT, "oracle", "_ref", "libprod_orbmatcher_realaccess.so")      # the same with orb_slam_amd/cpp/ORBmatcherAccess.h
+
+
+@pytest.mark.parametrize("PROD", [PROD, PROD_REAL_ACCESS], ids=["stand-in access header", "ORBmatcherAccess.h"])
+def test_product_library_links_the_c_abi_and_no_oracle(PROD):
+    if not os.path.exists(PROD):
+        pytest.skip(PROD + " is built where /root/reference exists")
     out = subprocess.run(["ldd", PROD], capture_output=True, text=True).stdout
     assert "liborbx.so" in out and "orb_oracle" not in out and "libref_" not in out
     syms = subprocess.run(["nm", "-D", "--undefined-only", PROD], capture_output=True, text=True).stdout
