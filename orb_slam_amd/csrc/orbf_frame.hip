@@ -2,9 +2,10 @@
 // the 64x48 search grid, and the grid window query, all on device-resident data.
 //
 //   k_undistort_grid   one workgroup per frame.  Lane i: cvUndistortPoints on keypoint i (f64, 5 iterations — ~150
-//                      f64 ops), cell = PosInGrid.  The grid is a stable counting sort by cell: keys (cell << 13 | i)
-//                      are bitonic-sorted in LDS (ascending i inside a cell = the reference's push_back order) and each
-//                      cell offset is a binary search in the sorted keys.  HBM traffic: 28 B in, 28 + 4 B out per
+//                      f64 ops), cell = PosInGrid.  The grid is a stable counting sort by cell in LDS: counts by atomics, one
+//                      scan over the 3073 offsets, an unordered placement and a rank pass (ascending i inside a cell = the
+//                      reference's push_back order).  (Rounds 2-5 bitonic-sorted keys (cell << 13 | i): 55 barrier-separated
+//                      passes, 90 us a frame's workgroup; this form: NOTES 11.7.)  HBM traffic: 28 B in, 28 + 4 B out per
 //                      keypoint + 12 KB of offsets per frame.
 //   k_area<FILL>       one lane per window query: pass 1 counts, a single-block scan turns counts into CSR offsets,
 //                      pass 2 writes the indices in the reference's order (cells x-major / y / cell order).
@@ -23,56 +24,71 @@ constexpr int FR_BLOCK = 256;
 constexpr int IDX_BITS = 13;                      // ORBF_MAX_FEATURES = 8192
 static_assert((1 << IDX_BITS) == ORBF_MAX_FEATURES, "index bits");
 
+// LDS of k_undistort_grid for a frame capacity: cell of each feature + the unordered placement (u16 each), cell offsets + fill cursors (u32 each)
+__host__ __device__ constexpr size_t undistort_grid_lds(int cap) { return ((size_t)cap * 2 * 2 + 15) / 16 * 16 + (size_t)(ORBF_GRID_CELLS + 1) * 4 * 2; }
+
 __global__ __launch_bounds__(FR_BLOCK) void k_undistort_grid(orbf_camera cam, orbf_bounds b, const orbx_keypoint* __restrict__ kps,
-                                                            const int32_t* __restrict__ d_n, int n_or_cap, int P,
+                                                            const int32_t* __restrict__ d_n, int n_or_cap,
                                                             orbx_keypoint* __restrict__ kps_un, int32_t* __restrict__ cell_off,
                                                             int32_t* __restrict__ cell_feat) {
-    extern __shared__ uint32_t keys[];             // P
-    __shared__ int s_m;
-    const int frame = blockIdx.x;
+    extern __shared__ __align__(16) uint8_t lds[];
+    __shared__ int s_part[FR_BLOCK / 64];
+    uint16_t* cell_of = reinterpret_cast<uint16_t*>(lds);                         // [cap]  0xFFFF: in no cell
+    uint16_t* placed = cell_of + n_or_cap;                                        // [cap]  features grouped by cell, order inside a cell arbitrary
+    uint32_t* off = reinterpret_cast<uint32_t*>(lds + ((size_t)n_or_cap * 4 + 15) / 16 * 16);      // [CELLS + 1]
+    uint32_t* fill = off + (ORBF_GRID_CELLS + 1);                                 // [CELLS + 1]
+    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = d_n ? min(d_n[frame], n_or_cap) : n_or_cap;
     kps += (size_t)frame * n_or_cap;
     kps_un += (size_t)frame * n_or_cap;
     cell_feat += (size_t)frame * n_or_cap;
     cell_off += (size_t)frame * (ORBF_GRID_CELLS + 1);
-    if (threadIdx.x == 0) s_m = 0;
+    for (int c = tid; c <= ORBF_GRID_CELLS; c += FR_BLOCK) fill[c] = 0;
     __syncthreads();
+    // ---- every feature: undistort, its cell, the cell's count (fill[c + 1])
     const bool distorted = cam.dist[0] != 0.0f;    // src/Frame.cc:291: `if(mDistCoef.at<float>(0)==0.0) mvKeysUn=mvKeys`
-    int valid = 0;
-    for (int i = threadIdx.x; i < P; i += FR_BLOCK) {
-        uint32_t key = 0xFFFFFFFFu;
-        if (i < n) {
-            orbx_keypoint kp = kps[i];
-            if (distorted) undistort_point(cam, kp.x, kp.y, &kp.x, &kp.y);
-            kps_un[i] = kp;
-            const int c = grid_cell(b, kp.x, kp.y);
-            if (c >= 0) { key = ((uint32_t)c << IDX_BITS) | (uint32_t)i; valid++; }
-        }
-        keys[i] = key;
+    for (int i = tid; i < n; i += FR_BLOCK) {
+        orbx_keypoint kp = kps[i];
+        if (distorted) undistort_point(cam, kp.x, kp.y, &kp.x, &kp.y);
+        kps_un[i] = kp;
+        const int c = grid_cell(b, kp.x, kp.y);
+        cell_of[i] = (uint16_t)(c >= 0 ? c : 0xFFFF);
+        if (c >= 0) atomicAdd(&fill[c + 1], 1u);
     }
-    if (valid) atomicAdd(&s_m, valid);
     __syncthreads();
-    for (int k = 2; k <= P; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < P; i += FR_BLOCK) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint32_t a = keys[i], c = keys[ixj];
-                    if ((a > c) == ((i & k) == 0)) { keys[i] = c; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
+    // ---- inclusive scan of fill[0 .. CELLS] (fill[0] = 0): entry c becomes the start of cell c; consecutive entries per thread, wave scan, wave totals
+    {
+        constexpr int CH = (ORBF_GRID_CELLS + 1 + FR_BLOCK - 1) / FR_BLOCK;
+        int sum = 0;
+        for (int k = 0; k < CH; ++k) { const int c = tid * CH + k; if (c <= ORBF_GRID_CELLS) sum += (int)fill[c]; }
+        int incl = sum;
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        int run = incl - sum;
+        for (int w = 0; w < wave; ++w) run += s_part[w];
+        for (int k = 0; k < CH; ++k) {
+            const int c = tid * CH + k;
+            if (c <= ORBF_GRID_CELLS) { run += (int)fill[c]; off[c] = (uint32_t)run; fill[c] = (uint32_t)run; cell_off[c] = run; }
         }
-    const int m = s_m;
-    for (int i = threadIdx.x; i < m; i += FR_BLOCK) cell_feat[i] = (int32_t)(keys[i] & (ORBF_MAX_FEATURES - 1));
-    for (int c = threadIdx.x; c <= ORBF_GRID_CELLS; c += FR_BLOCK) {
-        const uint32_t want = (uint32_t)c << IDX_BITS;      // first key of cell c or later
-        int lo = 0, hi = m;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (keys[mid] < want) lo = mid + 1; else hi = mid;
-        }
-        cell_off[c] = lo;
+    }
+    __syncthreads();
+    // ---- group by cell (whoever comes first takes the next slot of its cell) ...
+    for (int i = tid; i < n; i += FR_BLOCK) {
+        const uint32_t c = cell_of[i];
+        if (c != 0xFFFFu) placed[atomicAdd(&fill[c], 1u)] = (uint16_t)i;
+    }
+    __syncthreads();
+    // ... and put every feature at its rank inside the cell: the number of smaller indices there (ascending i inside a cell = the reference's
+    // push_back order, src/Frame.cc:116-123).  A cell holds a handful of features; the walk is per feature, so a crowded cell costs its square spread
+    // over the workgroup, never one thread's serial sort.
+    for (int i = tid; i < n; i += FR_BLOCK) {
+        const uint32_t c = cell_of[i];
+        if (c == 0xFFFFu) continue;
+        const uint32_t s0 = off[c], s1 = off[c + 1];
+        uint32_t rank = 0;
+        for (uint32_t k = s0; k < s1; ++k) rank += placed[k] < (uint32_t)i;
+        cell_feat[s0 + rank] = i;
     }
 }
 
@@ -150,9 +166,7 @@ int orbf_undistort_grid_batch_device(const orbf_camera* cam, const orbf_bounds* 
     if (!cam || !b || nframes < 0 || cap < 1 || cap > ORBF_MAX_FEATURES || cam->ndist < 0 || cam->ndist > 8) return ORBX_ERR_ARG;
     if (nframes == 0) return ORBX_OK;
     if (!d_kps || !d_kps_un || !d_cell_off || !d_cell_feat) return ORBX_ERR_ARG;
-    int P = 1;
-    while (P < cap) P <<= 1;
-    hipLaunchKernelGGL(orbf::k_undistort_grid, dim3(nframes), dim3(orbf::FR_BLOCK), (size_t)P * 4, (hipStream_t)stream, *cam, *b, d_kps, d_n, cap, P,
+    hipLaunchKernelGGL(orbf::k_undistort_grid, dim3(nframes), dim3(orbf::FR_BLOCK), orbf::undistort_grid_lds(cap), (hipStream_t)stream, *cam, *b, d_kps, d_n, cap,
                        d_kps_un, d_cell_off, d_cell_feat);
     return hipGetLastError() == hipSuccess ? ORBX_OK : ORBX_ERR_DEVICE;
 }
