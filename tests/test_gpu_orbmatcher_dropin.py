@@ -166,3 +166,81 @@ def test_product_equals_reference_at_general_poses(name, angle, shift, scale, bo
     both.set_sim3(_pose(int(angle * 100) + 7, angle / 2, shift / 2), 2.0 - scale)
     n = _run_all(getattr(trm, name), both, swallow=True)
     assert len(n) >= 3 and min(n) > 60, n          # the windows moved, the searches still find matches to disagree about
+
+
+# ---- concurrent callers -------------------------------------------------------------------------------------------------------------------
+class _Recorder:
+    """ref_* calls to ONE library; remembers (name, return value, bytes of every array argument after the call) per call"""
+
+    def __init__(self, lib):
+        self.lib, self.arrays, self.log = lib, {}, []
+
+    def P(self, a):
+        self.arrays[a.ctypes.data] = a
+        return a.ctypes.data
+
+    def __getattr__(self, name):
+        f = getattr(self.lib, name)
+
+        def call(*args):
+            ret = f(*args)
+            self.log.append((name, ret, [self.arrays[a].tobytes() for a in args if isinstance(a, int) and a in self.arrays]))
+            return ret
+        return call
+
+
+def test_concurrent_callers_each_get_their_own_results():
+    """Tracking, LocalMapping and LoopClosing call ORBmatcher concurrently; the product keeps one pinned block + one stream per HOST
+    THREAD (ORBmatcher.cc: thread_local Workspace).  Three threads run different searches of the product library at the same time, fifty rounds each
+    (ctypes releases the GIL inside the calls); every call's return value and output arrays must equal what the reference library gave for the same
+    case single-threaded."""
+    import threading
+    import torch
+    assert torch.cuda.is_available()
+    ref, prod = trm.load(REF_PATH), trm.load(PROD_PATH)
+    cases = {"test_window_search": dict(seed=12, n1=700, n2=1000, win=15, check=True, lo=1, hi=5, crowd=True),
+             "test_search_by_bow_keyframe_frame": dict(seed=32, n1=600, n2=1000, check=False),
+             "test_fuse": dict(which=0, seed=112, nkf=1000, nq=700, th=4.0, crowd=True)}
+    # the case functions take the library through the module globals trm.ref / trm.P: one module object per thread
+    import importlib.util
+
+    def private_module():
+        spec = importlib.util.spec_from_file_location("trm_private_%d" % threading.get_ident(), trm.__file__)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    def run(lib, name, kw, rounds):
+        m = private_module()
+        logs = []
+        for _ in range(rounds):
+            rec = _Recorder(lib)
+            m.ref, m.P = (lambda rec=rec: rec), rec.P
+            try:
+                getattr(m, name)(**kw)
+            except AssertionError:
+                pass                                     # the case's oracle / sanity assertions are not the subject here
+            logs.append(rec.log)
+        return logs
+
+    want = {name: run(ref, name, kw, 1)[0] for name, kw in cases.items()}
+    got, errors = {}, []
+
+    def worker(name, kw):
+        try:
+            got[name] = run(prod, name, kw, 50)
+        except Exception as e:                            # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(n, kw)) for n, kw in cases.items()]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for name in cases:
+        assert len(want[name]) >= 1
+        for r, log in enumerate(got[name]):
+            assert [(c, v) for c, v, _ in log] == [(c, v) for c, v, _ in want[name]], (name, r)
+            for (_, _, a), (_, _, b) in zip(log, want[name]):
+                assert a == b, (name, r, "an output array differs from the reference's")
