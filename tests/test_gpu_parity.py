@@ -688,3 +688,39 @@ def test_fp_contract_mode_through_the_batch_path(gpu_extractor_factory):
             assert k[f, :n[f]].tobytes() == wk.tobytes() and np.array_equal(dd[f, :n[f]], wd)
         bits += int(np.unpackbits(od ^ idd).sum())
     print("descriptor bits separating the two modes on %d frames: %d" % (F, bits))
+
+
+def test_two_host_threads_two_handles(gpu_extractor_factory):
+    """ORB_SLAM keeps two extractors alive (Tracking's normal one and the 2 x nFeatures one of the initialiser, src/Tracking.cc:124-127); the boundary's
+    contract is one handle per host thread, distinct handles concurrently (include/orbx.h).  Two threads drive their own handle through the one-frame
+    call at the same time (ctypes releases the GIL inside orbx_extract): every output equals the oracle's for that extractor."""
+    import threading
+    frames = [synth.frame(640, 480, synth.BLOCKS, 100 + i) for i in range(6)] + [synth.frame(512, 384, synth.MIDTEX, 7)]
+    setups = [dict(nfeatures=1000), dict(nfeatures=2000)]
+    want = []
+    for kw in setups:
+        o = orc.OracleExtractor(**kw)
+        want.append([o(f) for f in frames])
+    handles = [gpu_extractor_factory(**kw) for kw in setups]
+    got, errors = [None, None], []
+
+    def worker(t):
+        try:
+            out = []
+            for _ in range(5):
+                out.append([handles[t](f) for f in frames])
+            got[t] = out
+        except Exception as e:                            # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(2):
+        for rnd in got[t]:
+            for (gk, gd), (ok, od) in zip(rnd, want[t]):
+                _assert_kps_equal(gk, ok)
+                np.testing.assert_array_equal(gd, od)
