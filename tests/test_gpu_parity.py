@@ -691,7 +691,7 @@ def test_fp_contract_mode_through_the_batch_path(gpu_extractor_factory):
 
 
 def test_two_host_threads_two_handles(gpu_extractor_factory):
-    """ORB_SLAM keeps two extractors alive (Tracking's normal one and the 2 x nFeatures one of the initialiser, src/Tracking.cc:124-127); the boundary's
+    """ORB_SLAM keeps two extractors alive (Tracking's normal one and the 2 x nFeatures one of the initialiser, src/Tracking.cc:111, :126); the boundary's
     contract is one handle per host thread, distinct handles concurrently (include/orbx.h).  Two threads drive their own handle through the one-frame
     call at the same time (ctypes releases the GIL inside orbx_extract): every output equals the oracle's for that extractor."""
     import threading
